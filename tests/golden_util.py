@@ -31,3 +31,17 @@ def case_inputs(g, case, dtype=torch.float64):
     valid = t('valid_classes') if pre + 'valid_classes' in g else None
     cons = t('constraints').to(dtype) if pre + 'constraints' in g else None
     return p, feats, lengths, valid, cons, cfg
+
+
+def assert_spans_equivalent(spans, ref_spans, lengths, eos_id, scores=None, v=None, pos_lengths=None):
+    """Span encodings must give identical frame labels and EOS placement.  Boundaries may differ only
+    between consecutive spans of ONE class -- (a,b) and (b,a) splits of a run score exactly the same in
+    real arithmetic, so which one wins is rounding noise -- and then the path must re-score to the optimum."""
+    spans, ref_spans = np.asarray(spans), np.asarray(ref_spans)
+    for i, t in enumerate(np.asarray(lengths).tolist()):
+        assert spans[i, t] == ref_spans[i, t] == eos_id, (i, spans[i, t], ref_spans[i, t])
+        assert (spans[i, t + 1:] == -1).all()
+        np.testing.assert_array_equal(O.spans_to_labels(spans[i:i + 1, :t]), O.spans_to_labels(ref_spans[i:i + 1, :t]))
+    if scores is not None and not np.array_equal(spans, ref_spans):
+        np.testing.assert_allclose(O.rescore(scores, torch.from_numpy(spans), pos_lengths).numpy(),
+                                   np.asarray(v), rtol=1e-9, atol=1e-7)

@@ -1,0 +1,53 @@
+"""ctypes binding of libsmmdp.so (include/smmdp.h).  No fallback: a missing library is an error."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmmdp.so")
+
+SYMBOLS = [
+    "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
+    "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
+]
+
+
+class SmmShape(ctypes.Structure):
+    _fields_ = [("b", ctypes.c_int32), ("d", ctypes.c_int32), ("n_groups", ctypes.c_int32),
+                ("c_max", ctypes.c_int32), ("k_rows", ctypes.c_int32), ("t_max", ctypes.c_int32),
+                ("total_frames", ctypes.c_int64)]
+
+
+class SmmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the CDLL.  Raises SmmError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmmError("libsmmdp.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                       "there is no CPU fallback for the semi-Markov decode path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        getattr(lib, name)   # AttributeError if the ABI and the header drifted apart
+    lib.smm_strerror.restype = ctypes.c_char_p
+    lib.smm_strerror.argtypes = [ctypes.c_int]
+    lib.smm_version.restype = ctypes.c_char_p
+    lib.smm_workspace_bytes.restype = ctypes.c_size_t
+    lib.smm_workspace_bytes.argtypes = [ctypes.POINTER(SmmShape), ctypes.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        lib = load()
+        msg = lib.smm_strerror(status).decode()
+        if status == -4:
+            msg += " (hipError %d)" % lib.smm_last_hip_error()
+        raise SmmError("libsmmdp: %s" % msg)

@@ -1,0 +1,270 @@
+// smm_api.hip -- host side of libsmmdp.so: argument checks, launch planning, C ABI (include/smmdp.h).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/smmdp.h"
+#include "smm_device.h"
+#include "smm_launch.h"
+
+static thread_local int g_last_hip = 0;
+
+#define SMM_HIP(call)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return SMM_ERR_HIP; }   \
+    } while (0)
+
+extern "C" const char *smm_strerror(int status)
+{
+    switch (status) {
+    case SMM_OK: return "ok";
+    case SMM_ERR_ARG: return "invalid argument";
+    case SMM_ERR_UNSUPPORTED: return "shape not supported by the compiled kernels";
+    case SMM_ERR_WORKSPACE: return "workspace too small";
+    case SMM_ERR_HIP: return "HIP runtime error";
+    case SMM_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown smm_status";
+    }
+}
+
+extern "C" int smm_last_hip_error(void) { return g_last_hip; }
+extern "C" const char *smm_version(void) { return "smmdp 0.1 (gfx950)"; }
+
+extern "C" int smm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ planning
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct SmmPlan {
+    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err
+    size_t o_order, o_nstates, o_err;
+    size_t hist_doubles;   // sum over videos of 2*c_max*(T+1)
+    size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
+    size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
+    size_t total;
+};
+
+static bool shape_ok(const smm_shape *s)
+{
+    return s && s->b > 0 && s->n_groups > 0 && s->c_max > 0 && s->k_rows >= 2 && s->t_max > 0 && s->total_frames > 0;
+}
+
+static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
+{
+    SmmPlan p{};
+    p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
+    p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
+    p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
+    p.meta_bytes = p.o_err + 256;
+    size_t h = 0;
+    for (int i = 0; i < s->b; ++i) h += 2 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
+    p.hist_doubles = h;
+    p.elp_doubles = (size_t)s->total_frames * s->c_max;
+    p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
+    p.total = p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles) + 1024;
+    return p;
+}
+
+extern "C" size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host)
+{
+    if (!shape_ok(shape) || !lengths_host) return 0;
+    for (int i = 0; i < shape->b; ++i)
+        if (lengths_host[i] < 1 || lengths_host[i] > shape->t_max) return 0;
+    return make_plan(shape, lengths_host).total;
+}
+
+struct Staged {
+    SmmVideo *videos;
+    int32_t *order;
+    int32_t *n_states;
+    int32_t *err;
+    double *hist;
+    double *elp;
+    double *tabs;
+    int kp_max, c_need;
+};
+
+// Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
+static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
+                 const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out)
+{
+    if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
+    if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
+    int c_need = 0;
+    for (int g = 0; g < s->n_groups; ++g) {
+        if (n_states[g] < 1 || n_states[g] > s->c_max) return SMM_ERR_ARG;
+        c_need = std::max(c_need, n_states[g]);
+    }
+    for (int i = 0; i < s->b; ++i)
+        if (lengths[i] < 1 || lengths[i] > s->t_max) return SMM_ERR_ARG;
+    const SmmPlan p = make_plan(s, lengths);
+    if (ws_bytes < p.total) return SMM_ERR_WORKSPACE;
+
+    std::vector<char> host(p.meta_bytes, 0);
+    SmmVideo *hv = reinterpret_cast<SmmVideo *>(host.data());
+    int32_t *ho = reinterpret_cast<int32_t *>(host.data() + p.o_order);
+    int32_t *hn = reinterpret_cast<int32_t *>(host.data() + p.o_nstates);
+
+    size_t hoff = 0;
+    int kp_max = 2;
+    for (int i = 0; i < s->b; ++i) {
+        const int64_t t = lengths[i];
+        if (frame_off[i] < 0 || frame_off[i] + t > s->total_frames) return SMM_ERR_ARG;
+        const int g = group ? group[i] : 0;
+        if (g < 0 || g >= s->n_groups) return SMM_ERR_ARG;
+        const int k = kp ? kp[i] : std::min<int>(s->k_rows, s->t_max);
+        if (k < 1 || k > s->k_rows) return SMM_ERR_ARG;
+        hv[i].frame_off = frame_off[i];
+        hv[i].hist_off = (int64_t)hoff;
+        hv[i].T = (int32_t)t;
+        hv[i].group = g;
+        hv[i].kp = k;
+        hoff += 2 * (size_t)s->c_max * (size_t)(t + 1);
+        kp_max = std::max(kp_max, k);
+    }
+    std::iota(ho, ho + s->b, 0);
+    // most work first, so the tail of the grid is made of short videos
+    std::stable_sort(ho, ho + s->b, [&](int a, int b) {
+        return (int64_t)hv[a].T * n_states[hv[a].group] > (int64_t)hv[b].T * n_states[hv[b].group];
+    });
+    std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
+
+    char *base = static_cast<char *>(ws);
+    // pageable source: the runtime copies it out before returning, so `host` may die with this frame
+    SMM_HIP(hipMemcpyAsync(base, host.data(), p.meta_bytes, hipMemcpyHostToDevice, stream));
+    out->videos = reinterpret_cast<SmmVideo *>(base);
+    out->order = reinterpret_cast<int32_t *>(base + p.o_order);
+    out->n_states = reinterpret_cast<int32_t *>(base + p.o_nstates);
+    out->err = reinterpret_cast<int32_t *>(base + p.o_err);
+    out->hist = reinterpret_cast<double *>(base + p.meta_bytes);
+    out->elp = out->hist + p.hist_doubles;
+    out->tabs = out->elp + p.elp_doubles;
+    out->kp_max = kp_max;
+    out->c_need = c_need;
+    return SMM_OK;
+}
+
+static int ring_regs(int kp_max)
+{
+    int r = 1;
+    while (64 * r < kp_max) r *= 2;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ pieces
+static int run_emission(const smm_shape *s, const Staged &st, const float *x, const double *w, const double *cst,
+                        const double *inv_var, const float *cons, double *elp64, float *elp32, hipStream_t stream)
+{
+    if (!x || !w || !cst || !inv_var || s->d < 1 || (!elp64 && !elp32)) return SMM_ERR_ARG;
+    SmmEmArgs a{st.videos, st.n_states, x, w, cst, inv_var, cons, elp64, elp32, s->d, s->c_max, s->b};
+    smm_launch_emission(a, st.c_need, s->t_max, stream);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
+}
+
+static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, const double *trans, const double *init,
+                       const double *len_scores, const double *endpen, const int64_t *class_map, int64_t *spans,
+                       int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream)
+{
+    if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
+    SmmDpArgs a{};
+    a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
+    a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = endpen; a.class_map = class_map;
+    a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
+    a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
+    const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
+    if (rc != SMM_OK) return rc;
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" int smm_emission_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                                const int32_t *group_host, const int32_t *n_states_host, const float *x, const double *w,
+                                const double *cst, const double *inv_var, const float *cons, double *elp64, float *elp32,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, nullptr, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    return run_emission(shape, st, x, w, cst, inv_var, cons, elp64, elp32, hs);
+}
+
+extern "C" int smm_viterbi_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                               const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                               const double *elp, const double *trans, const double *init, const double *len_scores,
+                               const double *endpen, const int64_t *class_map, int64_t *spans, int64_t *labels,
+                               double *best, int32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream)
+{
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    return run_viterbi(shape, st, elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
+}
+
+extern "C" int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                               const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                               const float *elp, const float *trans, const float *init, const float *len_scores,
+                               const float *endpen, const int64_t *class_map, int64_t *spans, int64_t *labels,
+                               double *best, int32_t *n_segs, void *workspace, size_t workspace_bytes, void *stream)
+{
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
+    const size_t g = shape->n_groups, cm = shape->c_max;
+    double *t64 = st.tabs, *i64 = t64 + g * cm * cm, *l64 = i64 + g * cm, *e64 = l64 + g * shape->k_rows * cm;
+    smm_launch_widen(trans, t64, g * cm * cm, hs);
+    smm_launch_widen(init, i64, g * cm, hs);
+    smm_launch_widen(len_scores, l64, g * shape->k_rows * cm, hs);
+    if (endpen) smm_launch_widen(endpen, e64, (size_t)shape->b * cm, hs);
+    smm_launch_widen(elp, st.elp, (size_t)shape->total_frames * cm, hs);
+    SMM_HIP(hipGetLastError());
+    return run_viterbi(shape, st, st.elp, t64, i64, l64, endpen ? e64 : nullptr, class_map, spans, labels, best, n_segs, hs);
+}
+
+extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                              const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                              const float *x, const double *w, const double *cst, const double *inv_var, const float *cons,
+                              const double *trans, const double *init, const double *len_scores, const double *endpen,
+                              const int64_t *class_map, int64_t *spans, int64_t *labels, double *best, int32_t *n_segs,
+                              float *elp32, void *workspace, size_t workspace_bytes, void *stream)
+{
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs);
+    if (rc != SMM_OK) return rc;
+    return run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
+}
+
+extern "C" int smm_logz_f64(const smm_shape *, const int64_t *, const int64_t *, const int32_t *, const int32_t *,
+                            const int32_t *, const double *, const double *, const double *, const double *, const double *,
+                            double *, void *, size_t, void *)
+{
+    return SMM_ERR_UNSUPPORTED;   // LogSemiring forward kernel: not built yet
+}
+
+extern "C" int smm_logz_bwd_f64(const smm_shape *, const int64_t *, const int64_t *, const int32_t *, const int32_t *,
+                                const int32_t *, const double *, const double *, const double *, const double *,
+                                const double *, const double *, const double *, double *, double *, double *, double *,
+                                void *, size_t, void *)
+{
+    return SMM_ERR_UNSUPPORTED;
+}

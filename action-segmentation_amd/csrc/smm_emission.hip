@@ -1,0 +1,92 @@
+// smm_emission.hip -- diagonal-Gaussian emission scorer for gfx950 (fp64 FMA on the VALU, HBM-streaming).
+//
+// Replaces SemiMarkovModule.emission_log_probs / _emission_log_probs_with_means (reference
+// semimarkov_modules.py:324-381): elp[t][c] = log N(x_t; mu_c, diag(sigma^2)) (+ constraints[t][c], :379-380),
+// evaluated in the expanded form
+//     elp[t][c] = cst[c] + sum_d x[t][d] * w[d][c] - 0.5 * sum_d x[t][d]^2 * inv_var[d]
+// (w = mu/sigma^2, cst = -0.5 sum mu^2/sigma^2 - sum log sigma - D/2 log 2pi; host-side, fp64), which is one
+// v_fma_f64 per (frame, d, state).  In fp64 the expansion costs nothing in accuracy (|terms| ~ 1e3, eps 1e-16).
+//
+// Mapping.  One lane per frame; a wave stages a 64-frame x 64-feature tile of x through LDS with coalesced
+// 256-B row reads (the only HBM traffic: 4*D bytes per frame), then every lane walks its own row.  w[d][.] is the
+// same for all lanes: it is fetched with scalar loads and used as the SGPR operand of the FMA, so the inner
+// loop is FMA-only.  No MFMA: D x C = 200 x 20 per frame in exact fp64 is below the fp64 VALU/HBM balance point.
+#include "smm_launch.h"
+
+template <int CT>
+__global__ void __launch_bounds__(256) smm_emission_kernel(SmmEmArgs a)
+{
+    constexpr int DC = 64;                       // features per LDS stage
+    __shared__ float xs[4][64][DC + 1];
+    const int vid = blockIdx.y;
+    const SmmVideo mv = a.videos[vid];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f0 = (blockIdx.x * 4 + wv) * 64;   // first frame of this wave's tile
+    if (f0 >= mv.T) return;                      // whole wave exits (no block-wide barrier below)
+    const int nfr = min(64, mv.T - f0);
+    const int g = mv.group;
+    const int C = a.n_states[g];
+    const int cm = a.c_max, D = a.d;
+    const float *x = a.x + (size_t)(mv.frame_off + f0) * D;
+    const double *__restrict__ w = a.w + (size_t)g * D * cm;
+    const double *__restrict__ iv = a.inv_var;
+
+    double acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+    double q = 0.0;
+
+    for (int d0 = 0; d0 < D; d0 += DC) {
+        const int nd = min(DC, D - d0);
+        for (int fr = 0; fr < nfr; ++fr)          // coalesced: 64 lanes read 64 consecutive features of one frame
+            xs[wv][fr][lane] = (lane < nd) ? x[(size_t)fr * D + d0 + lane] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's LDS writes have landed
+        for (int dd = 0; dd < nd; ++dd) {
+            const double xv = (double)xs[wv][lane][dd];
+            const double *__restrict__ wr = w + (size_t)(d0 + dd) * cm;   // wave-uniform -> scalar loads
+            q = fma(xv * iv[d0 + dd], xv, q);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = fma(xv, wr[c], acc[c]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < nfr) {
+        const size_t row = (size_t)(mv.frame_off + f0 + lane) * cm;
+        const double *cst = a.cst + (size_t)g * cm;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (c < C) {
+                double v = (cst[c] + acc[c]) - 0.5 * q;
+                if (a.cons) v += (double)a.cons[row + c];
+                if (a.elp64) a.elp64[row + c] = v;
+                if (a.elp32) a.elp32[row + c] = (float)v;
+            }
+        }
+    }
+}
+
+// fp32 -> fp64 widening of a [n] array (smm_viterbi_f32 boundary)
+__global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (double)src[i];
+}
+
+void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, hipStream_t stream)
+{
+    dim3 grid((t_max + 255) / 256, a.b), block(256);
+    if (ct <= 8) hipLaunchKernelGGL(smm_emission_kernel<8>, grid, block, 0, stream, a);
+    else if (ct <= 16) hipLaunchKernelGGL(smm_emission_kernel<16>, grid, block, 0, stream, a);
+    else if (ct <= 24) hipLaunchKernelGGL(smm_emission_kernel<24>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(smm_emission_kernel<32>, grid, block, 0, stream, a);
+}
+
+void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream)
+{
+    if (n == 0) return;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(smm_widen_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
+}

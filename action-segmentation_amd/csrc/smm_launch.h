@@ -1,0 +1,21 @@
+// smm_launch.h -- launch wrappers shared between the kernel translation units and smm_api.hip.
+#pragma once
+#include "smm_device.h"
+
+struct SmmEmArgs {
+    const SmmVideo *videos;
+    const int32_t *n_states;
+    const float *x;          // [total_frames][d]
+    const double *w;         // [g][d][c_max]
+    const double *cst;       // [g][c_max]
+    const double *inv_var;   // [d]
+    const float *cons;       // [total_frames][c_max] or null
+    double *elp64;           // [total_frames][c_max] or null
+    float *elp32;            // [total_frames][c_max] or null
+    int32_t d, c_max, b;
+};
+
+void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, hipStream_t stream);
+void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
+// returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
+int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);

@@ -1,0 +1,147 @@
+"""Tensor-level wrappers of the libsmmdp C ABI (include/smmdp.h).
+
+Every function takes CUDA(=HIP) tensors for bulk data and host sequences for the per-video / per-group
+metadata, enqueues on torch's current stream and returns CUDA tensors.  Nothing here computes on the CPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SmmShape
+
+
+class Batch:
+    """Metadata of one ragged decode batch (host side).
+
+    lengths        frames per video
+    frame_offset   first frame of each video on the packed frame axis (default: padded, i * t_max)
+    group          parameter group per video (default 0)
+    kp             per-video min(K, Tmax of its reference batch) (reference semimarkov_modules.py:450-452)
+    n_states       states per group
+    """
+
+    def __init__(self, lengths, n_states, k_rows, c_max=None, frame_offset=None, group=None, kp=None, d=0,
+                 t_max=None, total_frames=None):
+        self.lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
+        self.b = int(self.lengths.shape[0])
+        self.n_states = np.ascontiguousarray(np.asarray(n_states, dtype=np.int32).reshape(-1))
+        self.n_groups = int(self.n_states.shape[0])
+        self.c_max = int(c_max if c_max is not None else self.n_states.max())
+        self.k_rows = int(k_rows)
+        self.t_max = int(t_max if t_max is not None else self.lengths.max())
+        if frame_offset is None:
+            frame_offset = np.arange(self.b, dtype=np.int64) * self.t_max
+        self.frame_offset = np.ascontiguousarray(np.asarray(frame_offset, dtype=np.int64).reshape(-1))
+        self.group = None if group is None else np.ascontiguousarray(np.asarray(group, dtype=np.int32).reshape(-1))
+        self.kp = None if kp is None else np.ascontiguousarray(np.asarray(kp, dtype=np.int32).reshape(-1))
+        if total_frames is None:
+            total_frames = int((self.frame_offset + self.lengths).max())
+        self.total_frames = int(total_frames)
+        self.d = int(d)
+        self.shape = SmmShape(self.b, self.d, self.n_groups, self.c_max, self.k_rows, self.t_max, self.total_frames)
+
+    def workspace_bytes(self):
+        n = _lib.load().smm_workspace_bytes(ctypes.byref(self.shape), self.lengths.ctypes.data)
+        if n == 0:
+            raise _lib.SmmError("libsmmdp: invalid batch shape")
+        return n
+
+    def host_ptrs(self):
+        return (self.lengths.ctypes.data, self.frame_offset.ctypes.data,
+                None if self.group is None else self.group.ctypes.data,
+                None if self.kp is None else self.kp.ctypes.data, self.n_states.ctypes.data)
+
+
+def _dev(t, dtype, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.SmmError("libsmmdp: %s must be a CUDA/HIP tensor (there is no CPU path)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream).  (Caller-owned from the library's point of view.)"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _outputs(batch, device, want_spans, want_labels):
+    spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
+    labels = torch.full((batch.total_frames,), -1, dtype=torch.int64, device=device) if want_labels else None
+    best = torch.empty(batch.b, dtype=torch.float64, device=device)
+    n_segs = torch.empty(batch.b, dtype=torch.int32, device=device)
+    return spans, labels, best, n_segs
+
+
+def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False):
+    """x fp32 [total_frames, d] -> elp fp64 and/or fp32 [total_frames, c_max].  (smm_emission_f64)"""
+    lib = _lib.load()
+    dev = x.device
+    elp64 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float64, device=dev) if want64 else None
+    elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want32 else None
+    ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, _, ns = batch.host_ptrs()
+    _lib.check(lib.smm_emission_f64(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(ns),
+        _dev(x, torch.float32, 'x'), _dev(w, torch.float64, 'w'), _dev(cst, torch.float64, 'cst'),
+        _dev(inv_var, torch.float64, 'inv_var'), _dev(cons, torch.float32, 'cons'),
+        _dev(elp64, torch.float64, 'elp64'), _dev(elp32, torch.float32, 'elp32'),
+        ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return elp64, elp32
+
+
+def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True):
+    """Viterbi on emission scores.  elp fp64 (smm_viterbi_f64) or fp32 (smm_viterbi_f32, tables fp32 too)."""
+    lib = _lib.load()
+    dev = elp.device
+    dt = elp.dtype
+    fn = lib.smm_viterbi_f64 if dt == torch.float64 else lib.smm_viterbi_f32
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels)
+    ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, kp, ns = batch.host_ptrs()
+    _lib.check(fn(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.c_void_p(ns), _dev(elp, dt, 'elp'), _dev(trans, dt, 'trans'), _dev(init, dt, 'init'),
+        _dev(len_scores, dt, 'len_scores'), _dev(endpen, dt, 'endpen'), _dev(class_map, torch.int64, 'class_map'),
+        _dev(spans, torch.int64, 'spans'), _dev(labels, torch.int64, 'labels'), _dev(best, torch.float64, 'best'),
+        _dev(n_segs, torch.int32, 'n_segs'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs)
+
+
+def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
+           want_spans=True, want_labels=True, want_elp=False):
+    """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream."""
+    lib = _lib.load()
+    dev = x.device
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels)
+    elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want_elp else None
+    ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, kp, ns = batch.host_ptrs()
+    f64 = torch.float64
+    _lib.check(lib.smm_decode_f32(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.c_void_p(ns), _dev(x, torch.float32, 'x'), _dev(w, f64, 'w'), _dev(cst, f64, 'cst'),
+        _dev(inv_var, f64, 'inv_var'), _dev(cons, torch.float32, 'cons'), _dev(trans, f64, 'trans'),
+        _dev(init, f64, 'init'), _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'),
+        _dev(class_map, torch.int64, 'class_map'), _dev(spans, torch.int64, 'spans'),
+        _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
+        _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32)

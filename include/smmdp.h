@@ -1,0 +1,154 @@
+/*
+ * smmdp.h -- C ABI of libsmmdp.so: MI355X (gfx950) semi-Markov decode path.
+ *
+ * This library replaces, for the `--classifier semimarkov` path of dpfried/action-segmentation,
+ * everything between "features are on the device" and "span encoding / frame labels are back":
+ *
+ *   smm_emission_f64        <- SemiMarkovModule.emission_log_probs / _emission_log_probs_with_means
+ *                              (reference src/models/semimarkov/semimarkov_modules.py:324-381)
+ *   smm_viterbi_f64/_f32    <- SemiMarkovModule.log_hsmm (modules:416-523) + torch_struct
+ *                              SemiMarkovCRF(...).argmax + .struct.from_parts (modules:677-679) + class
+ *                              un-mapping (modules:683-691) + semimarkov_utils.spans_to_labels
+ *                              (semimarkov_utils.py:51-63) + SemiMarkovModule.trim (modules:532-543)
+ *   smm_decode_f32          <- SemiMarkovModule.viterbi end to end (modules:660-696)
+ *   smm_logz_f64 / _bwd     <- SemiMarkovCRF(...).partition (modules:657) and its autograd backward
+ *                              (reference src/models/semimarkov/semimarkov.py:286)
+ *
+ * The reference has no FFI: its boundary is the Python call SemiMarkovCRF(scores, lengths) on a dense
+ * b x N x K x C x C tensor.  These entry points take the FACTORS of that tensor instead,
+ * which is what a maintainer's binding passes (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions
+ *   - Plain C, no exceptions; every function returns SMM_OK (0) or a negative smm_status.
+ *   - "dev" pointers are HIP device pointers owned by the caller; "host" pointers are small per-video /
+ *     per-group metadata arrays in ordinary host memory (the library stages them itself; they may be reused
+ *     as soon as the call returns).  The library allocates nothing and keeps no state between calls.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream); no call
+ *     synchronises.  Distinct streams may be used from distinct threads.
+ *   - A "group" is a parameter set (one CrossTask task: its valid classes, transition/init/length tables).
+ *     A reference-style batch (corpus.py:613-644: one task, padded) is n_groups = 1, group = NULL,
+ *     frame_offset[i] = i * t_max.
+ *   - Frames of all videos live on one packed frame axis; video i occupies frames
+ *     [frame_offset[i], frame_offset[i] + lengths[i]).
+ *   - Tables are fp64, padded to c_max columns: trans[g][to][from] (c_max x c_max), init[g][c_max],
+ *     len_scores[g][k_rows][c_max] (row index == segment length, rows 1..k_rows-1 usable; modules:383-398),
+ *     class_map[g][c_max + 1] int64: local state -> global class id, entry n_states[g] = EOS id (n_classes).
+ *   - Per-video kp[i] = min(K, Tmax of the video's reference batch) reproduces modules:450-452 (NULL: min(k_rows, t_max)).
+ *   - endpen[i][c_max] fp64 (dev, nullable): 0 for allowed end states, -1e9 otherwise (modules:462-471).
+ */
+#ifndef SMMDP_H
+#define SMMDP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum smm_status {
+    SMM_OK = 0,
+    SMM_ERR_ARG = -1,          /* null pointer / non-positive size / inconsistent metadata */
+    SMM_ERR_UNSUPPORTED = -2,  /* shape outside the compiled kernels (c_max > 32, k_rows > 4096, ...) */
+    SMM_ERR_WORKSPACE = -3,    /* workspace too small */
+    SMM_ERR_HIP = -4,          /* a HIP runtime call failed (smm_last_hip_error() has the code) */
+    SMM_ERR_NO_DEVICE = -5     /* no gfx950 device visible */
+} smm_status;
+
+#define SMM_MAX_STATES 32
+#define SMM_MAX_K_ROWS 4096
+
+/* Shape of one decode call (plain data; passed by pointer). */
+typedef struct smm_shape {
+    int32_t b;         /* videos */
+    int32_t d;         /* feature dim (emission only) */
+    int32_t n_groups;  /* parameter groups */
+    int32_t c_max;     /* table column stride, >= every n_states[g], <= SMM_MAX_STATES */
+    int32_t k_rows;    /* rows of the length table (= --sm_max_span_length, or 2 for the K==1 HMM table) */
+    int32_t t_max;     /* max lengths[i] */
+    int64_t total_frames; /* extent of the packed frame axis (>= every frame_offset[i] + lengths[i]) */
+} smm_shape;
+
+const char *smm_strerror(int status);
+int smm_last_hip_error(void);
+const char *smm_version(void);
+/* number of visible gfx950 devices (0 when none; never initialises a context on failure) */
+int smm_device_count(void);
+
+/* Bytes of device workspace any entry point below needs for this shape (lengths: host array [b]).
+ * Returns 0 on invalid arguments.  The workspace is scratch: its contents are undefined after a call,
+ * except between smm_logz_f64 and smm_logz_bwd_f64. */
+size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
+
+/*
+ * Emission scorer.  elp[t][c] = cst[g][c] + sum_d x[t][d]*w[g][c][d] - 0.5*sum_d x[t][d]^2*inv_var[d] (+ cons[t][c])
+ * which is the diagonal-Gaussian log density of modules:324-381 with w = mu/sigma^2,
+ * cst = -0.5*sum mu^2/sigma^2 - sum log sigma - D/2 log 2pi.
+ *   x        dev fp32 [total_frames][d]
+ *   w        dev fp64 [n_groups][d][c_max]  (feature-major, so one frame step reads one contiguous row);
+ *   cst      dev fp64 [n_groups][c_max];  inv_var dev fp64 [d]
+ *   cons     dev fp32 [total_frames][c_max] or NULL (narration constraints, modules:379-380)
+ *   elp64    dev fp64 [total_frames][c_max] or NULL   (frame-major, reference layout)
+ *   elp32    dev fp32 [total_frames][c_max] or NULL   (what `return_elp=True` hands back)
+ */
+int smm_emission_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                     const int32_t *group_host, const int32_t *n_states_host,
+                     const float *x, const double *w, const double *cst, const double *inv_var, const float *cons,
+                     double *elp64, float *elp32, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Viterbi decode on emission scores (fp64 path).
+ *   elp       dev fp64 [total_frames][c_max]
+ *   spans     dev int64 [b][t_max + 1]  span encoding of modules:679-691: global class id at each span start,
+ *             -1 continuation, EOS id at position lengths[i], -1 after it           (nullable)
+ *   labels    dev int64 [total_frames]  per-frame global class ids (spans_to_labels + trim)   (nullable)
+ *   best      dev fp64 [b] Viterbi score (nullable);  n_segs dev int32 [b] (nullable)
+ */
+int smm_viterbi_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                    const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                    const double *elp, const double *trans, const double *init, const double *len_scores,
+                    const double *endpen, const int64_t *class_map,
+                    int64_t *spans, int64_t *labels, double *best, int32_t *n_segs,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same with the reference's dtypes at the boundary: fp32 elp [total_frames][c_max] and fp32 tables
+ * (log_hsmm's inputs, modules:416-417); converted to fp64 on load, then the same DP. */
+int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                    const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                    const float *elp, const float *trans, const float *init, const float *len_scores,
+                    const float *endpen, const int64_t *class_map,
+                    int64_t *spans, int64_t *labels, double *best, int32_t *n_segs,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Features -> decode in one call (emission kernel + DP kernel on `stream`); elp32 nullable. */
+int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                   const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                   const float *x, const double *w, const double *cst, const double *inv_var, const float *cons,
+                   const double *trans, const double *init, const double *len_scores,
+                   const double *endpen, const int64_t *class_map,
+                   int64_t *spans, int64_t *labels, double *best, int32_t *n_segs, float *elp32,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Log-partition (LogSemiring forward) and its backward.
+ *   logz   dev fp64 [b]
+ *   bwd:   grad_logz dev fp64 [b] (upstream), outputs g_elp dev fp64 [total_frames][c_max],
+ *          g_trans dev fp64 [n_groups][c_max][c_max], g_init [n_groups][c_max], g_len [n_groups][k_rows][c_max]
+ *          (all overwritten).  The workspace written by smm_logz_f64 must be passed unchanged to smm_logz_bwd_f64.
+ */
+int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                 const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                 const double *elp, const double *trans, const double *init, const double *len_scores,
+                 const double *endpen, double *logz, void *workspace, size_t workspace_bytes, void *stream);
+
+int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                     const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                     const double *elp, const double *trans, const double *init, const double *len_scores,
+                     const double *endpen, const double *logz, const double *grad_logz,
+                     double *g_elp, double *g_trans, double *g_init, double *g_len,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMMDP_H */

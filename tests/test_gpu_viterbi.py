@@ -1,0 +1,198 @@
+"""GPU parity: the HIP Viterbi / emission kernels, called through the C ABI, against the CPU oracle.
+
+Bit-exact bar: spans, frame labels and the best score must equal oracle/smm_oracle.c (same fp64 expressions).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_ref as O
+from oracle import factored as F
+from golden_util import assert_spans_equivalent
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from action_segmentation_amd import ops
+    return ops
+
+
+def make_problem(seed, b, tmax, c, k, c_max=None, ends=False, integer=False, scale=3.0, min_len=1):
+    g = np.random.default_rng(seed)
+    c_max = c_max or c
+    lengths = g.integers(max(min_len, tmax // 2), tmax + 1, size=b)
+    lengths[g.integers(0, b)] = tmax
+    if integer:
+        r = lambda *s: g.integers(-4, 1, size=s).astype(np.float64)
+    else:
+        r = lambda *s: g.standard_normal(s) * scale - 1.0
+    elp = np.zeros((b, tmax, c_max)); elp[:, :, :c] = r(b, tmax, c)
+    trans = np.zeros((c_max, c_max)); trans[:c, :c] = r(c, c)
+    init = np.zeros(c_max); init[:c] = r(c)
+    lens = np.zeros((k, c_max)); lens[:, :c] = r(k, c)
+    endpen = None
+    if ends:
+        endpen = np.full((b, c_max), -1e9)
+        for i in range(b):
+            endpen[i, g.integers(0, c, size=2)] = 0.0
+    return dict(elp=elp, lengths=lengths, trans=trans, init=init, lens=lens, endpen=endpen, c=c, c_max=c_max, k=k)
+
+
+def run_gpu(p, dtype=torch.float64, class_map=None):
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    b, tmax, cm = p['elp'].shape
+    batch = ops.Batch(p['lengths'], [p['c']], p['k'], c_max=cm, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype, device=dev).contiguous()
+    cmap = None if class_map is None else torch.tensor(class_map, dtype=torch.int64, device=dev).view(1, -1)
+    out = ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]),
+                      t(p['lens'][None]), t(p['endpen']), cmap)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def run_oracle(p):
+    c = p['c']
+    ep = None if p['endpen'] is None else p['endpen'][:, :c]
+    return F.viterbi(p['elp'][:, :, :c], p['lengths'], p['trans'][:c, :c], p['init'][:c], p['lens'][:, :c], ep)
+
+
+def check(p, out, spans, v):
+    b, tmax, _ = p['elp'].shape
+    np.testing.assert_array_equal(out['best'], v)
+    np.testing.assert_array_equal(out['spans'], spans)
+    labels = out['labels'].reshape(b, tmax)
+    for i, t in enumerate(p['lengths']):
+        np.testing.assert_array_equal(labels[i, :t], O.spans_to_labels(spans[i:i + 1, :t])[0])
+        assert (labels[i, t:] == -1).all()
+        assert out['n_segs'][i] == (spans[i, :t] != -1).sum()
+
+
+SHAPES = [
+    # b, tmax, c, k
+    (3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64), (3, 200, 7, 65),
+    (2, 300, 17, 130), (2, 600, 20, 300), (1, 1300, 23, 600), (2, 150, 32, 40), (1, 2100, 11, 1024),
+    (2, 64, 4, 2), (3, 65, 1, 5), (2, 1, 3, 4),
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('ends', [False, True])
+def test_viterbi_bit_exact_vs_factored_oracle(shape, ends):
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 1000, b, tmax, c, k, ends=ends)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_viterbi_integer_lattices_tie_order(seed):
+    """Exact ties everywhere: the (k asc, from asc) arg-max order must match the oracle and the dense DP."""
+    p = make_problem(seed, 3, 30 + seed, 4, 3 + seed, integer=True, ends=seed % 2 == 1)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    c = p['c']
+    allowed = None if p['endpen'] is None else [np.nonzero(p['endpen'][i, :c] == 0)[0].tolist() for i in range(3)]
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    scores = O.log_hsmm(tt(p['trans'][:c, :c]), tt(p['elp'][:, :, :c]), tt(p['init'][:c]), tt(p['lens'][:, :c]),
+                        tt(p['lengths']), True, allowed)
+    dv, segs = O.viterbi_backpointers(scores, tt(p['lengths']) + 1)
+    np.testing.assert_array_equal(out['best'], dv.numpy())
+    np.testing.assert_array_equal(out['spans'], O.spans_from_segments(segs, scores.shape[1] + 1).numpy())
+
+
+def test_viterbi_padded_columns_and_class_map():
+    p = make_problem(11, 3, 90, 5, 12, c_max=8)
+    cmap = [10, 11, 14, 15, 19, 99, 0, 0, 0]          # local -> global, entry c = EOS id
+    out = run_gpu(p, class_map=cmap)
+    spans, v = run_oracle(p)
+    table = np.array(cmap + [-1])                      # -1 stays -1
+    np.testing.assert_array_equal(out['spans'], table[spans])
+    np.testing.assert_array_equal(out['best'], v)
+
+
+def test_viterbi_f32_boundary_matches_oracle_on_widened_inputs():
+    p = make_problem(5, 3, 120, 6, 33)
+    for key in ('elp', 'trans', 'init', 'lens'):
+        p[key] = p[key].astype(np.float32).astype(np.float64)
+    out = run_gpu(p, dtype=torch.float32)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+
+
+def test_known_answer_on_gpu():
+    """Inputs of reference src/models/test_semimarkov.py:266-323."""
+    b, c, n, k, step = 10, 4, 100, 5, 4
+    padded = n + 2 * step
+    lengths = np.full(b, n); lengths[0] = padded
+    em = np.full((b, padded, c), -1e9)
+    for t in range(padded):
+        em[:, t, (t // step) % c] = 1
+    init = np.full(c, -1e9); init[0] = 0
+    ls = np.full((k, c), -1e9); ls[step] = 0
+    p = dict(elp=em, lengths=lengths, trans=np.zeros((c, c)), init=init, lens=ls, endpen=None, c=c, c_max=c, k=k)
+    out = run_gpu(p)
+    for s in range(n // step):
+        assert (out['spans'][:, step * s] == s % c).all()
+    assert (out['spans'][np.arange(b), lengths] == c).all()
+    np.testing.assert_array_equal(out['best'], [108.] + [100.] * 9)
+
+
+def test_multi_group_ragged_batch():
+    """Two parameter groups with different state counts, packed (unpadded) frame axis, per-video kp."""
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    pa = make_problem(21, 2, 80, 5, 16, c_max=9)
+    pb = make_problem(22, 3, 50, 9, 16, c_max=9)
+    lengths = np.concatenate([pa['lengths'], pb['lengths']])
+    group = np.array([0, 0, 1, 1, 1], dtype=np.int32)
+    kp = np.array([16, 16, 10, 16, 7], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    elp = np.concatenate([pp['elp'][i, :pp['lengths'][i]] for pp in (pa, pb) for i in range(len(pp['lengths']))])
+    batch = ops.Batch(lengths, [5, 9], 16, c_max=9, frame_offset=offs, group=group, kp=kp)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    out = ops.viterbi(batch, t(elp), t(np.stack([pa['trans'], pb['trans']])), t(np.stack([pa['init'], pb['init']])),
+                      t(np.stack([pa['lens'], pb['lens']])))
+    torch.cuda.synchronize()
+    spans = out['spans'].cpu().numpy(); best = out['best'].cpu().numpy(); labels = out['labels'].cpu().numpy()
+    vi = 0
+    for pp in (pa, pb):
+        c = pp['c']
+        for i in range(len(pp['lengths'])):
+            ti = int(pp['lengths'][i])
+            s, v = F.viterbi(pp['elp'][i:i + 1, :ti, :c], [ti], pp['trans'][:c, :c], pp['init'][:c],
+                             pp['lens'][:kp[vi], :c])
+            np.testing.assert_array_equal(spans[vi, :ti + 1], s[0])
+            assert (spans[vi, ti + 1:] == -1).all()
+            np.testing.assert_array_equal(best[vi], v[0])
+            np.testing.assert_array_equal(labels[offs[vi]:offs[vi] + ti], O.spans_to_labels(s[:, :ti])[0])
+            vi += 1
+
+
+@pytest.mark.parametrize('cfg', [(3, 70, 5, 7), (2, 300, 200, 20), (1, 129, 64, 32), (2, 64, 33, 9)])
+def test_emission_matches_oracle(cfg):
+    ops = _ops()
+    b, tmax, d, c = cfg
+    g = np.random.default_rng(b * 1000 + d)
+    lengths = g.integers(tmax // 2, tmax + 1, size=b); lengths[0] = tmax
+    x = g.standard_normal((b, tmax, d)).astype(np.float32)
+    mu = g.standard_normal((c, d)) * 0.5
+    var = 0.5 + g.random(d)
+    cons = (g.random((b, tmax, c)) < 0.1) * -1e4
+    lognorm = float(-0.5 * d * np.log(2 * np.pi) - 0.5 * np.log(var).sum())
+    ref = F.emission(x, lengths, mu, 1.0 / var, lognorm, cons)
+    dev = torch.device('cuda:0')
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    w = (mu / var).T[None]                                   # [g][d][c]
+    cst = (lognorm - 0.5 * (mu * mu / var).sum(1))[None]
+    batch = ops.Batch(lengths, [c], 4, t_max=tmax, total_frames=b * tmax, d=d)
+    e64, e32 = ops.emission(batch, torch.tensor(x.reshape(b * tmax, d), device=dev), t64(w), t64(cst), t64(1.0 / var),
+                            torch.tensor(cons.reshape(b * tmax, c), dtype=torch.float32, device=dev), True, True)
+    torch.cuda.synchronize()
+    e64 = e64.cpu().numpy().reshape(b, tmax, c); e32 = e32.cpu().numpy().reshape(b, tmax, c)
+    for i, t in enumerate(lengths):
+        np.testing.assert_allclose(e64[i, :t], ref[i, :t], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(e32[i, :t], ref[i, :t], rtol=2e-7, atol=1e-6)

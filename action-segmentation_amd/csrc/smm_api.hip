@@ -46,7 +46,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct SmmPlan {
     size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err
     size_t o_order, o_nstates, o_err;
-    size_t hist_doubles;   // sum over videos of 2*c_max*(T+1)
+    size_t hist_doubles;   // sum over videos of 3*c_max*(T+1): cumE, h (state-major), gamma (frame-major)
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
     size_t total;
@@ -65,7 +65,7 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
     p.meta_bytes = p.o_err + 256;
     size_t h = 0;
-    for (int i = 0; i < s->b; ++i) h += 2 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
+    for (int i = 0; i < s->b; ++i) h += 3 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;
     p.elp_doubles = (size_t)s->total_frames * s->c_max;
     p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
@@ -127,7 +127,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         hv[i].T = (int32_t)t;
         hv[i].group = g;
         hv[i].kp = k;
-        hoff += 2 * (size_t)s->c_max * (size_t)(t + 1);
+        hoff += 3 * (size_t)s->c_max * (size_t)(t + 1);
         kp_max = std::max(kp_max, k);
     }
     std::iota(ho, ho + s->b, 0);
@@ -180,6 +180,10 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = endpen; a.class_map = class_map;
     a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
     a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
+    {
+        const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling aid, see SmmDpArgs::flags
+        a.flags = dbg ? std::atoi(dbg) : 0;
+    }
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());

@@ -27,13 +27,14 @@ struct SmmDpArgs {
     const double *len;         // [g][k_rows][c_max]
     const double *endpen;      // [b][c_max] or null
     const int64_t *class_map;  // [g][c_max+1] or null
-    double *hist;              // per video: cum[c_max][T+1] then h[c_max][T+1]
+    double *hist;              // per video: cum[c_max][T+1], h[c_max][T+1], gamma[T+1][c_max]
     int64_t *spans;            // [b][t_max+1] or null
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
     int32_t *err;              // [1] sticky error flag (NaN in the inputs)
     int32_t c_max, k_rows, t_max, b;
+    int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined)
 };
 
 // ---- 64-bit register helpers -------------------------------------------------------------------
@@ -64,13 +65,44 @@ __device__ __forceinline__ double smm_dpp(double x)
 // lane i <- lane i-1, lane 0 <- lane 63
 __device__ __forceinline__ double smm_wave_ror1(double x) { return smm_dpp<SMM_DPP_WAVE_ROR1>(x); }
 
-// max over lanes 0..31 of x (lanes 32..63 ignored); result is wave-uniform.
-__device__ __forceinline__ double smm_wave_max32(double x)
+// v_max_f64 without the canonicalising self-max hipcc puts in front of fmax() operands it cannot prove quiet
+// (no NaNs ever enter the DP: inputs are finite or -inf and nothing subtracts infinities).
+__device__ __forceinline__ double smm_fmax(double a, double b)
 {
-    x = fmax(x, smm_dpp<SMM_DPP_ROW_SHR(1)>(x));
-    x = fmax(x, smm_dpp<SMM_DPP_ROW_SHR(2)>(x));
-    x = fmax(x, smm_dpp<SMM_DPP_ROW_SHR(4)>(x));
-    x = fmax(x, smm_dpp<SMM_DPP_ROW_SHR(8)>(x));            // lane 15 / 31 hold their row's max
-    x = fmax(x, smm_dpp<SMM_DPP_ROW_BCAST15, 0xA>(x));      // row 1 (and 3) <- lane 15 of the row before
-    return smm_readlane(x, 31);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Max over each DPP row (16 consecutive lanes) of an unsigned; every lane of the row receives it.
+// v_max_u32 with a rotated DPP source, 4 levels.  (2 wait states between a VALU write and a DPP read of
+// the same VGPR: hipcc pads nothing inside asm, so the s_nop's are part of the sequence.)
+__device__ __forceinline__ unsigned smm_row_umax16(unsigned x)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(x));
+    return x;
+}
+
+// Max of a double over each row of 16 lanes (no NaNs); every lane of the row receives it.  fp64 has no DPP
+// form, so the reduction runs on order-preserving 32-bit keys: the high word first, then the low word among
+// the lanes that tie on the high word.
+__device__ __forceinline__ double smm_row_max16(double x)
+{
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    const int sgn = hi >> 31;                                  // all ones for negative values
+    const unsigned khi = (unsigned)(hi ^ (sgn | (int)0x80000000));
+    const unsigned klo = (unsigned)(lo ^ sgn);
+    const unsigned mhi = smm_row_umax16(khi);
+    const unsigned mlo = smm_row_umax16(khi == mhi ? klo : 0u);
+    const int neg = (mhi & 0x80000000u) ? 0 : -1;              // key without the top bit <=> negative value
+    return smm_pack((int)mlo ^ neg, (int)(mhi ^ ((unsigned)neg | 0x80000000u)));
 }

@@ -73,7 +73,7 @@ SHAPES = [
     # b, tmax, c, k
     (3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64), (3, 200, 7, 65),
     (2, 300, 17, 130), (2, 600, 20, 300), (1, 1300, 23, 600), (2, 150, 32, 40), (1, 2100, 11, 1024),
-    (2, 64, 4, 2), (3, 65, 1, 5), (2, 1, 3, 4),
+    (2, 64, 4, 2), (3, 65, 1, 5), (2, 2, 3, 4),
 ]
 
 

@@ -1,0 +1,163 @@
+"""``SemiMarkovModel``: host harness of ``--classifier semimarkov`` (reference ``src/models/semimarkov/semimarkov.py``).
+
+Same class surface as the reference (``add_args`` :17, ``from_args`` :34, ``fit_supervised`` :125,
+``make_additional_allowed_ends`` :135, ``expand_constraints`` :149, ``fit`` :159, ``predict`` :318; attributes
+``.model`` / ``.args``) so ``main.py``'s ``CLASSIFIERS['semimarkov']`` can point here unchanged.  ``predict``
+returns ``{video_name: np.ndarray[int64, T]}`` of global class ids, no EOS id.
+
+What is different is the batching of the decode: the reference calls ``viterbi`` once per single-task batch of
+``--batch_size`` videos; here all those batches are folded into ONE ragged launch (batching.pack_batches), which is
+what lets 256 CUs work on a corpus.  ``predict(test_data, fused=False)`` keeps the reference's call pattern.
+"""
+import numpy as np
+import torch
+
+from . import semimarkov_utils
+from .batching import make_data_loader, make_optimizer, pack_batches
+from .semimarkov_modules import SemiMarkovModule, all_equal
+
+
+class SemiMarkovModel(object):
+    @classmethod
+    def add_args(cls, parser):
+        SemiMarkovModule.add_args(parser)
+        parser.add_argument('--sm_component_model', action='store_true')
+        parser.add_argument('--sm_constrain_transitions', action='store_true')
+        parser.add_argument('--sm_constrain_with_narration', choices=['train', 'test'], nargs='*', default=[])
+        parser.add_argument('--sm_constrain_narration_weight', type=float, default=-1e4)
+        parser.add_argument('--sm_train_discriminatively', action='store_true')
+        parser.add_argument('--sm_hidden_markov', action='store_true',
+                            help='train as hidden markov model (fix K=1) and length distribution')
+        parser.add_argument('--sm_predict_single', action='store_true')
+
+    @classmethod
+    def from_args(cls, args, train_data):
+        n_classes = train_data.corpus.n_classes
+        feature_dim = train_data.feature_dim
+        allow_self_transitions = True
+        assert args.sm_max_span_length is not None
+        if getattr(args, 'sm_component_model', False):
+            raise NotImplementedError("--sm_component_model (compound model) is outside the decode path built here")
+        if args.sm_constrain_transitions:
+            (allowed_starts, allowed_transitions, allowed_ends,
+             ordered_indices_by_task) = train_data.get_allowed_starts_and_transitions()
+            for src in range(n_classes):
+                allowed_transitions.setdefault(src, set()).add(src)
+        else:
+            allowed_starts = allowed_transitions = allowed_ends = ordered_indices_by_task = None
+        merge_classes = None
+        if getattr(args, 'annotate_background_with_previous', False) and not getattr(args, 'no_merge_classes', False):
+            merge_classes = {}
+            bkg = set(train_data.corpus._background_indices)
+            for task, indices in train_data.corpus._indices_by_task.items():
+                background = [ix for ix in indices if ix in bkg]
+                canon = background[0]
+                for ix in indices:
+                    tgt = canon if ix in bkg else ix
+                    assert merge_classes.setdefault(ix, tgt) == tgt
+        model = SemiMarkovModule(args, n_classes, feature_dim, allow_self_transitions=allow_self_transitions,
+                                 allowed_starts=allowed_starts, allowed_transitions=allowed_transitions,
+                                 allowed_ends=allowed_ends, merge_classes=merge_classes)
+        return SemiMarkovModel(args, n_classes, feature_dim, model, ordered_indices_by_task)
+
+    def __init__(self, args, n_classes, feature_dim, model, ordered_indices_by_task=None):
+        self.args = args
+        self.n_classes = n_classes
+        self.feature_dim = feature_dim
+        self.model = model
+        self.ordered_indices_by_task = ordered_indices_by_task
+        if args.cuda:
+            self.model.cuda()
+
+    @property
+    def device(self):
+        return self.model.gaussian_means.device
+
+    # ------------------------------------------------------------------ training
+    def fit_supervised(self, train_data):
+        assert not self.args.sm_constrain_transitions
+        loader = make_data_loader(self.args, train_data, batch_by_task=False, shuffle=False, batch_size=1)
+        features, labels = [], []
+        for batch in loader:
+            features.append(batch['features'].squeeze(0))
+            labels.append(batch['gt_single'].squeeze(0))
+        self.model.fit_supervised(features, labels)
+
+    def fit(self, train_data, use_labels, callback_fn=None):
+        self.model.train()
+        if use_labels:
+            assert not self.args.sm_constrain_transitions
+        if use_labels and self.args.sm_supervised_method == 'closed-form':
+            self.fit_supervised(train_data)   # closed form: no epochs, callback never called (reference :165-171)
+            return
+        raise NotImplementedError("gradient training needs the log-partition kernels (smm_logz_f64): not built yet")
+
+    # ------------------------------------------------------------------ constraints (reference :135-157)
+    def make_additional_allowed_ends(self, tasks, lengths):
+        if self.ordered_indices_by_task is None:
+            return None
+        res = []
+        for task, length in zip(tasks, lengths):
+            order = self.ordered_indices_by_task[task]
+            n = int(length)
+            res.append([order[n - 1]] if n < len(order) else [])
+        return res
+
+    def expand_constraints(self, datasplit, task, task_indices, constraints):
+        task_indices = [int(v) for v in task_indices]
+        step_indices = datasplit.get_ordered_indices_no_background()[task]
+        assert constraints.size(2) == len(step_indices)
+        out = torch.zeros((constraints.size(0), constraints.size(1), len(task_indices)))
+        for index, label in enumerate(step_indices):
+            out[:, :, task_indices.index(label)] = constraints[:, :, index]
+        return out
+
+    def _test_constraints(self, test_data):
+        if 'test' not in self.args.sm_constrain_with_narration:
+            return None
+
+        def fn(batch):
+            tasks = batch['task_name']
+            assert all_equal(tasks)
+            ce = self.expand_constraints(test_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
+            return ce * self.args.sm_constrain_narration_weight
+        return fn
+
+    # ------------------------------------------------------------------ decode (reference :318-410)
+    def prepare(self, test_data):
+        """Everything that happens before the timed decode: collate the reference's batches, move them to the
+        device once, stack the per-task factor tables."""
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size)
+        pc = pack_batches(loader, self.device, self.model.max_k, constraints_fn=self._test_constraints(test_data),
+                          additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
+        return self.model.prepare_packed(pc)
+
+    def predict_packed(self, pc):
+        out = self.model.decode_packed(pc, want_spans=False, want_labels=True)
+        labels = out['labels'].cpu().numpy()
+        preds = {}
+        for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
+            preds[name] = labels[off:off + t]
+            assert self.model.n_classes not in preds[name], "predictions should not contain EOS"
+        return preds
+
+    def predict(self, test_data, fused=True):
+        self.model.eval()
+        if fused:
+            return self.predict_packed(self.prepare(test_data))
+        predictions = {}
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size)
+        cons_fn = self._test_constraints(test_data)
+        for batch in loader:
+            tasks = batch['task_name']
+            assert len(set(tasks)) == 1
+            features, lengths = batch['features'].to(self.device), batch['lengths']
+            cons = cons_fn(batch) if cons_fn else None
+            addl = self.make_additional_allowed_ends(tasks, lengths)
+            pred_spans = self.model.viterbi(features, lengths, batch['task_indices'], add_eos=True, use_mean_z=True,
+                                            additional_allowed_ends_per_instance=addl, constraints=cons)
+            pred_labels = semimarkov_utils.spans_to_labels(pred_spans)
+            for video, seq in zip(batch['video_name'], self.model.trim(pred_labels, lengths, check_eos=True)):
+                predictions[video] = seq.numpy()
+                assert self.model.n_classes not in predictions[video], "predictions should not contain EOS"
+        return predictions

@@ -1,0 +1,451 @@
+"""``SemiMarkovModule``: the reference's HSMM parameter container and decode entry points, MI355X back-end.
+
+Mirrors reference ``src/models/semimarkov/semimarkov_modules.py`` (``SemiMarkovModule`` :52) -- same constructor,
+parameter names (picklable / ``state_dict``-compatible: ``poisson_log_rates, gaussian_means, gaussian_cov,
+transition_logits, init_logits, init_constraints, transition_constraints``), same method names, arguments and
+return conventions -- for the decode path only.  What differs is *how* ``viterbi`` / ``log_likelihood`` compute:
+the reference materialises dense ``b x N x K x C x C`` potentials (``log_hsmm`` :416-523) and hands them to
+pytorch-struct; here the factors (emission scores, transition / initial / length tables) go straight to the HIP
+kernels of ``libsmmdp.so`` (include/smmdp.h) and no dense tensor exists.
+
+There is no CPU path: ``viterbi`` / ``log_likelihood`` need CUDA(HIP) tensors and raise otherwise.
+``log_hsmm`` / ``score_features`` (the dense potentials) are kept as plain torch code for API compatibility and
+small-shape inspection; nothing in this package's decode path calls them.
+"""
+import math
+from typing import Dict, Set
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .semimarkov_utils import semimarkov_sufficient_stats
+
+BIG_NEG = -1e9  # reference semimarkov_modules.py:20
+
+
+def all_equal(xs):
+    xs = list(xs)
+    return all(x == xs[0] for x in xs[1:])
+
+
+def sliding_sum(inputs, k):
+    """out[b,t,c] = sum_{j=t}^{t+k-1} inputs[b,j,c] (terms past the end dropped).  Reference :26-39."""
+    assert k > 0
+    out = inputs.clone()
+    n = inputs.size(1)
+    for j in range(1, min(k, n)):       # direct accumulation: no prefix-sum cancellation in fp32
+        out[:, :n - j] += inputs[:, j:]
+    return out
+
+
+class SemiMarkovModule(nn.Module):
+    @classmethod
+    def add_args(cls, parser):
+        # reference :54-65 (the NICE-flow flags of --sm_feature_projection are accepted but the flow is not built)
+        parser.add_argument('--sm_max_span_length', type=int, default=20)
+        parser.add_argument('--sm_supervised_state_smoothing', type=float, default=1e-2)
+        parser.add_argument('--sm_supervised_length_smoothing', type=float, default=1e-1)
+        parser.add_argument('--sm_supervised_method',
+                            choices=['closed-form', 'gradient-based', 'closed-then-gradient'],
+                            default='closed-form')
+        parser.add_argument('--sm_feature_projection', action='store_true', help='use a flow (not built here)')
+        parser.add_argument('--sm_init_non_projection_parameters_from')
+
+    def __init__(self, args, n_classes, n_dims, allow_self_transitions=False, allowed_starts: Set[int] = None,
+                 allowed_transitions: Dict[int, Set[int]] = None, allowed_ends: Set[int] = None,
+                 merge_classes: Dict[int, int] = None):
+        super().__init__()
+        self.args = args
+        self.n_classes = n_classes
+        self.input_feature_dim = n_dims
+        self.feature_dim = n_dims
+        self.allow_self_transitions = allow_self_transitions
+        self.init_params()
+        if allowed_starts is not None:
+            assert allowed_transitions is not None
+            self.set_transition_constraints(allowed_starts, allowed_transitions, allowed_ends)
+        else:
+            self.remove_transition_constraints()
+        if getattr(args, 'sm_init_non_projection_parameters_from', None) is not None:
+            import pickle
+            with open(args.sm_init_non_projection_parameters_from, 'rb') as f:
+                self.init_nonproject_parameters(pickle.load(f).model)
+        if getattr(args, 'sm_feature_projection', False):
+            raise NotImplementedError("--sm_feature_projection (NICE flow) is outside the decode path built here")
+        self.feature_projector = None
+        self.max_k = args.sm_max_span_length
+        self._merge_classes = merge_classes
+        self.kl = None
+
+    # ------------------------------------------------------------------ parameters (reference :142-193)
+    @property
+    def merge_classes(self):
+        return getattr(self, '_merge_classes', None)
+
+    def init_nonproject_parameters(self, model):
+        inc = self.load_state_dict(model.state_dict(), strict=False)
+        assert not inc.unexpected_keys, inc.unexpected_keys
+
+    def init_params(self):
+        self.poisson_log_rates = nn.Parameter(torch.zeros(self.n_classes), requires_grad=True)
+        self.gaussian_means = nn.Parameter(torch.zeros(self.n_classes, self.feature_dim), requires_grad=True)
+        # shared, tied, diagonal covariance (stored as a dense D x D matrix like the reference)
+        self.gaussian_cov = nn.Parameter(torch.eye(self.feature_dim), requires_grad=False)
+        self.transition_logits = nn.Parameter(torch.zeros(self.n_classes, self.n_classes), requires_grad=True)  # to x from
+        self.init_logits = nn.Parameter(torch.zeros(self.n_classes), requires_grad=True)
+        torch.nn.init.uniform_(self.init_logits, 0, 1)
+
+    def flatten_parameters(self):
+        pass
+
+    def remove_transition_constraints(self):
+        self.transition_constraints = None
+        self.init_constraints = None
+        self.allowed_ends = None
+
+    def set_transition_constraints(self, allowed_starts, allowed_transitions, allowed_ends):
+        init_c = torch.ones(self.n_classes, dtype=torch.bool)           # True = forbidden
+        assert all(x >= 0 for x in allowed_starts)
+        init_c[torch.tensor(sorted(allowed_starts), dtype=torch.long)] = False
+        trans_c = torch.ones(self.n_classes, self.n_classes, dtype=torch.bool)
+        for src, targets in allowed_transitions.items():
+            for tgt in targets:
+                trans_c[tgt, src] = False
+        # parameters so that .cuda() / state_dict carry them (reference :176-187)
+        self.init_constraints = nn.Parameter(init_c, requires_grad=False)
+        self.transition_constraints = nn.Parameter(trans_c, requires_grad=False)
+        self.allowed_ends = allowed_ends
+
+    # ------------------------------------------------------------------ closed-form supervised fit (:195-256)
+    def fit_supervised(self, feature_list, label_list):
+        if self.transition_constraints is not None or self.init_constraints is not None:
+            raise NotImplementedError("fit_supervised closed form with constrained state transitions")
+        a = self.args
+        em, st = semimarkov_sufficient_stats(feature_list, label_list, 'tied_diag', self.n_classes, self.max_k)
+        if self.merge_classes is not None:
+            merged = [torch.as_tensor([self.merge_classes[int(ix)] for ix in labels]) for labels in label_list]
+            em_m, st_m = semimarkov_sufficient_stats(feature_list, merged, 'tied_diag', self.n_classes, self.max_k)
+        else:
+            em_m, st_m = em, st
+        with np.errstate(divide='ignore', invalid='ignore'):
+            init_probs = (st['span_start_counts'] + a.sm_supervised_state_smoothing) / float(
+                st['instance_count'] + a.sm_supervised_state_smoothing * self.n_classes)
+            init_probs[np.isnan(init_probs)] = 0
+            smoothed = st['span_transition_counts'] + a.sm_supervised_state_smoothing
+            trans_probs = smoothed / smoothed.sum(axis=0)[None, :]
+            trans_probs[np.isnan(trans_probs)] = 0
+            mean_lengths = (st_m['span_lengths'] + a.sm_supervised_length_smoothing) / (
+                st_m['span_counts'] + a.sm_supervised_length_smoothing)
+        dev = self.init_logits.device
+        with torch.no_grad():
+            self.init_logits.copy_(torch.from_numpy(init_probs).to(dev).log())
+            self.transition_logits.copy_(torch.from_numpy(trans_probs).to(dev).log())
+            self.poisson_log_rates.copy_(torch.from_numpy(mean_lengths).to(dev).log())
+            self.gaussian_means.copy_(torch.from_numpy(em_m.means_).to(dev).float())
+            self.gaussian_cov.copy_(torch.diag(torch.from_numpy(em_m.covariances_[0]).to(dev).float()))
+
+    def initialize_gaussian_from_feature_list(self, features):
+        feats = torch.cat(features, dim=0)
+        assert feats.dim() == 2 and feats.size(1) == self.feature_dim
+        with torch.no_grad():
+            self.gaussian_means.copy_(feats.mean(dim=0, keepdim=True).expand(self.n_classes, self.feature_dim))
+            self.gaussian_cov.data = torch.diag(feats.var(dim=0))
+
+    def initialize_gaussian(self, data, lengths):
+        self.initialize_gaussian_from_feature_list([data[i, :lengths[i]] for i in range(data.size(0))])
+
+    # ------------------------------------------------------------------ scorers (:284-414); dtype follows the parameters
+    def _merged(self, valid_classes):
+        idx = valid_classes if valid_classes is not None else torch.arange(self.n_classes)
+        if self.merge_classes is not None:
+            idx = torch.as_tensor([self.merge_classes[int(ix)] for ix in idx], dtype=torch.long)
+        return idx
+
+    def initial_log_probs(self, valid_classes, dtype=None):
+        logits = self.init_logits if dtype is None else self.init_logits.to(dtype)
+        if self.init_constraints is not None:
+            logits = logits.masked_fill(self.init_constraints, BIG_NEG)
+        if valid_classes is not None:
+            logits = logits[valid_classes.to(logits.device)]
+        return F.log_softmax(logits, dim=0)
+
+    def transition_log_probs(self, valid_classes, dtype=None):
+        t = self.transition_logits if dtype is None else self.transition_logits.to(dtype)
+        if self.transition_constraints is not None:
+            t = t.masked_fill(self.transition_constraints, BIG_NEG)
+        if valid_classes is not None:
+            vc = valid_classes.to(t.device)
+            t = t[vc][:, vc]
+        if not self.allow_self_transitions:
+            t = t.masked_fill(torch.eye(t.size(0), device=t.device, dtype=torch.bool), BIG_NEG)
+        return F.log_softmax(t, dim=0)   # [to, from]: every column normalised
+
+    def _emission_log_probs_with_means(self, features, class_means):
+        """Plain-torch Gaussian log density (API compatibility; the decode path uses smm_emission_f64)."""
+        var = torch.diagonal(self.gaussian_cov).to(features.dtype)
+        d = features.size(-1)
+        z2 = ((features.unsqueeze(-2) - class_means.to(features.dtype)) ** 2 / var).sum(-1)
+        return -0.5 * (d * math.log(2 * math.pi) + z2) - 0.5 * var.log().sum()
+
+    def emission_log_probs(self, features, valid_classes, constraints):
+        idx = self._merged(valid_classes).to(self.gaussian_means.device)
+        elp = self._emission_log_probs_with_means(features, self.gaussian_means[idx])
+        return elp if constraints is None else elp + constraints
+
+    def _length_log_probs_with_rates(self, log_rates):
+        n_classes = log_rates.size(-1)
+        if self.max_k == 1:   # reference :389-391
+            return torch.tensor([0.0, -1000.0], dtype=log_rates.dtype, device=log_rates.device
+                                ).unsqueeze(-1).expand(2, n_classes)
+        k = torch.arange(self.max_k, device=log_rates.device, dtype=log_rates.dtype).unsqueeze(-1)
+        rate = torch.exp(log_rates)
+        return torch.xlogy(k, rate) - rate - torch.lgamma(k + 1)   # Poisson(rate).log_prob(k); row == length
+
+    def length_log_probs(self, valid_classes, dtype=None):
+        idx = self._merged(valid_classes).to(self.poisson_log_rates.device)
+        rates = self.poisson_log_rates if dtype is None else self.poisson_log_rates.to(dtype)
+        return self._length_log_probs_with_rates(rates[idx])
+
+    # ------------------------------------------------------------------ dense potentials (compat only; :416-523)
+    @staticmethod
+    def log_hsmm(transition, emission_scores, init, length_scores, lengths, add_eos, all_batched=False,
+                 allowed_ends_per_instance=None):
+        """Dense ``scores[b, n, k, c_to, c_from]`` exactly as the reference defines them (memory b*N*K*C*C!)."""
+        assert not all_batched, "per-instance parameter batches (compound model) are not built"
+        b, n1, c1 = emission_scores.shape
+        kk = min(length_scores.shape[0], n1)
+        length_scores = length_scores[:kk]
+        kw = dict(device=emission_scores.device, dtype=emission_scores.dtype)
+        if add_eos:
+            n, c = n1 + 1, c1 + 1
+            trans = torch.full((b, c, c), BIG_NEG, **kw)
+            trans[:, :c1, :c1] = transition
+            if allowed_ends_per_instance is None:
+                trans[:, c1, :] = 0
+            else:
+                for i, ends in enumerate(allowed_ends_per_instance):
+                    assert len(ends) > 0
+                    trans[i, c1, list(ends)] = 0
+            ini = torch.full((b, c), BIG_NEG, **kw)
+            ini[:, :c1] = init
+            ls = torch.full((b, kk, c), BIG_NEG, **kw)
+            ls[:, :, :c1] = length_scores
+            ls[:, 1 if kk > 1 else 0, c1] = 0
+            em = torch.full((b, n, c), BIG_NEG, **kw)
+            for i, t in enumerate(lengths.tolist()):
+                em[i, :t, :c1] = emission_scores[i, :t]
+                em[i, t, c1] = 0
+            lens = lengths + 1
+        else:
+            n, c = n1, c1
+            trans = transition.unsqueeze(0).expand(b, c, c)
+            ini = init.unsqueeze(0).expand(b, c)
+            ls = length_scores.unsqueeze(0).expand(b, kk, c)
+            em, lens = emission_scores, lengths
+        scores = trans.view(b, 1, 1, c, c) + ls.view(b, 1, kk, 1, c) + torch.zeros(b, n - 1, kk, c, c, **kw)
+        scores[:, 0] += ini.view(b, 1, 1, c)
+        summed = None
+        for k in range(1, kk):
+            if summed is None:
+                summed = em.clone()                          # window sums grow by one shifted copy per k
+            elif k - 1 < n:
+                summed[:, :n - (k - 1)] += em[:, k - 1:]
+            for i in range(b):
+                li = int(lens[i])
+                scores[i, :li - 1, k] += summed[i, :li - 1].view(li - 1, 1, c)
+                scores[i, li - 1 - k, k] += em[i, li - 1].view(c, 1)
+        return scores
+
+    def add_eos(self, spans, lengths):
+        b = spans.size(0)
+        aug = torch.cat([spans, torch.full([b, 1], -1, device=spans.device, dtype=torch.long)], dim=1)
+        aug[torch.arange(b), lengths] = self.n_classes
+        return aug
+
+    def trim(self, spans, lengths, check_eos=False):
+        return [spans[i, :lengths[i]] for i in range(spans.size(0))]
+
+    @property
+    def batched_scores(self):
+        return False
+
+    def set_z(self, features, lengths, use_mean=False):
+        self.kl = torch.zeros(features.size(0), device=features.device)
+
+    def _allowed_ends_per_instance(self, valid_classes, additional_allowed_ends_per_instance, b):
+        """Local positions (in valid_classes) of allowed_ends | additional, per instance.  Reference :566-577."""
+        if self.allowed_ends is None:
+            return None
+        vc = list(range(self.n_classes)) if valid_classes is None else [int(v) for v in valid_classes]
+        if additional_allowed_ends_per_instance is None:
+            additional_allowed_ends_per_instance = [set() for _ in range(b)]
+        res = [[i for i, ix in enumerate(vc) if ix in (set(self.allowed_ends) | set(add))]
+               for add in additional_allowed_ends_per_instance]
+        assert all(res), res
+        return res
+
+    def score_features(self, features, lengths, valid_classes, add_eos, use_mean_z,
+                       additional_allowed_ends_per_instance=None, constraints=None, return_elp=False):
+        """Dense potentials like the reference (:553-595).  Compatibility API -- O(b*N*K*C*C) memory."""
+        self.set_z(features, lengths, use_mean=use_mean_z)
+        log_det = torch.zeros(features.size(0), device=features.device)
+        ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, features.size(0))
+        elp = self.emission_log_probs(features, valid_classes, constraints)
+        scores = self.log_hsmm(self.transition_log_probs(valid_classes), elp, self.initial_log_probs(valid_classes),
+                               self.length_log_probs(valid_classes), lengths, add_eos=add_eos,
+                               allowed_ends_per_instance=ends)
+        return (scores, log_det, elp) if return_elp else (scores, log_det)
+
+    # ------------------------------------------------------------------ factor tables for the HIP path
+    def _check_valid_classes(self, valid_classes_per_instance):
+        if valid_classes_per_instance is None:
+            return None
+        assert all_equal(set(int(v) for v in vc) for vc in valid_classes_per_instance), \
+            "must have same valid_classes for all instances in the batch"
+        return valid_classes_per_instance[0].detach().cpu().long()
+
+    def factor_tables(self, valid_classes, device=None):
+        """fp64 factors of the potentials for one class set (no EOS row: the kernels handle EOS in closed form).
+
+        Returns dict(trans C x C [to,from], init C, len K x C, w D x C, cst C, inv_var D, class_map C+1 int64).
+        Built with differentiable torch ops on the parameters' device.
+        """
+        f64 = torch.float64
+        dev = device or self.gaussian_means.device
+        vc = valid_classes
+        idx = self._merged(vc).to(dev)
+        var = torch.diagonal(self.gaussian_cov).to(f64)
+        mu = self.gaussian_means.to(f64)[idx]                                   # C x D
+        d = mu.size(1)
+        w = (mu / var).t().contiguous()                                         # D x C  (feature-major)
+        cst = -0.5 * (mu * mu / var).sum(1) - 0.5 * var.log().sum() - 0.5 * d * math.log(2 * math.pi)
+        ids = list(range(self.n_classes)) if vc is None else [int(v) for v in vc]
+        assert len(set(ids)) == len(ids), "valid_classes must be unique"
+        return dict(
+            trans=self.transition_log_probs(vc, f64).contiguous(), init=self.initial_log_probs(vc, f64).contiguous(),
+            len=self.length_log_probs(vc, f64).contiguous(), w=w, cst=cst.contiguous(),
+            inv_var=(1.0 / var).contiguous(),
+            class_map=torch.tensor(ids + [self.n_classes], dtype=torch.int64, device=dev))
+
+    def _endpen(self, valid_classes, additional_allowed_ends_per_instance, b, c, device):
+        ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
+        if ends is None:
+            return None
+        ep = torch.full((b, c), BIG_NEG, dtype=torch.float64)
+        for i, e in enumerate(ends):
+            ep[i, e] = 0.0
+        return ep.to(device)
+
+    @staticmethod
+    def _require_device(t, what):
+        if not t.is_cuda:
+            raise ops._lib.SmmError("SemiMarkovModule.%s runs on the MI355X only: move the module and the batch to "
+                                    "the device (--cuda); there is no CPU decode path" % what)
+
+    # ------------------------------------------------------------------ decode (:660-696)
+    def viterbi(self, features, lengths, valid_classes_per_instance, add_eos=True, use_mean_z=False,
+                additional_allowed_ends_per_instance=None, constraints=None, predict_single=False, return_elp=False):
+        """Viterbi segmentation of a zero-padded single-task batch.
+
+        features b x Tmax x D (device fp32), lengths b, valid_classes_per_instance list of b identical LongTensors
+        or None.  Returns pred_spans: CPU int64 b x (Tmax+1) -- global class id at every span start, -1 for a
+        continuation, ``n_classes`` (EOS) at position lengths[i], -1 after it [, elp b x Tmax x C fp32 on device].
+        """
+        if not add_eos:
+            raise NotImplementedError("the HIP path decodes with the EOS augmentation only (add_eos=True), "
+                                      "which is what SemiMarkovModel.predict / fit use")
+        self._require_device(features, 'viterbi')
+        valid_classes = self._check_valid_classes(valid_classes_per_instance)
+        self.set_z(features, lengths, use_mean=use_mean_z)
+        out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
+                           want_elp=return_elp, want_labels=False)
+        pred_spans = out['spans'].cpu()
+        if return_elp:
+            b, tmax = features.shape[:2]
+            return pred_spans, out['elp'].view(b, tmax, -1)
+        return pred_spans
+
+    viterbi_decode = viterbi   # name used by BASELINE.json's north star
+
+    def _decode(self, features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
+                want_elp=False, want_labels=True, want_spans=True):
+        b, tmax, d = features.shape
+        dev = features.device
+        lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
+        assert int(lengths_host.max()) == tmax, "one instance must span the padded length (padding_colate)"
+        with torch.no_grad():
+            tab = self.factor_tables(valid_classes, dev)
+        c = tab['init'].numel()
+        k_rows = tab['len'].size(0)
+        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
+        x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
+        cons = None
+        if constraints is not None:
+            cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
+        endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+        return ops.decode(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
+                          tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
+                          tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
+                          class_map=tab['class_map'].view(1, -1), want_spans=want_spans, want_labels=want_labels,
+                          want_elp=want_elp)
+
+    # ------------------------------------------------------------------ packed multi-task decode
+    def prepare_packed(self, pc):
+        """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns."""
+        dev = pc.x.device
+        with torch.no_grad():
+            tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
+        n_states = [int(t['init'].numel()) for t in tabs]
+        cm, d, g = max(n_states), pc.x.size(1), len(tabs)
+        k_rows = tabs[0]['len'].size(0)
+        f64 = dict(dtype=torch.float64, device=dev)
+        st = dict(trans=torch.zeros(g, cm, cm, **f64), init=torch.zeros(g, cm, **f64), len=torch.zeros(g, k_rows, cm, **f64),
+                  w=torch.zeros(g, d, cm, **f64), cst=torch.zeros(g, cm, **f64), inv_var=tabs[0]['inv_var'],
+                  class_map=torch.zeros(g, cm + 1, dtype=torch.int64, device=dev))
+        for i, (t, c) in enumerate(zip(tabs, n_states)):
+            st['trans'][i, :c, :c] = t['trans']
+            st['init'][i, :c] = t['init']
+            st['len'][i, :, :c] = t['len']
+            st['w'][i, :, :c] = t['w']
+            st['cst'][i, :c] = t['cst']
+            st['class_map'][i, :c + 1] = t['class_map']
+        pc.tables, pc.n_states, pc.c_max, pc.k_rows = st, n_states, cm, k_rows
+        pc.kp = [min(k, k_rows) for k in pc.kp]
+        pc.endpen = None
+        if self.allowed_ends is not None:
+            ep = torch.full((pc.n_videos, cm), BIG_NEG, dtype=torch.float64)
+            for i in range(pc.n_videos):
+                vc = pc.groups[pc.group[i]]['valid_classes']
+                add = pc.additional_ends[i]
+                ends = self._allowed_ends_per_instance(vc, None if add is None else [add], 1)[0]
+                ep[i, ends] = 0.0
+            pc.endpen = ep.to(dev)
+        pc.cons = None
+        if getattr(pc, 'cons_list', None) is not None:
+            cons = torch.zeros(pc.x.size(0), cm, dtype=torch.float32, device=dev)
+            for i, cl in enumerate(pc.cons_list):
+                if cl is not None:
+                    o = pc.frame_offset[i]
+                    cons[o:o + pc.lengths[i], :cl.size(1)] = cl.to(device=dev, dtype=torch.float32)
+            pc.cons = cons
+        pc.batch = ops.Batch(pc.lengths, n_states, k_rows, c_max=cm, frame_offset=pc.frame_offset, group=pc.group,
+                             kp=pc.kp, d=d, total_frames=pc.x.size(0))
+        return pc
+
+    def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False):
+        """One emission launch + one DP launch for a whole PackedCorpus.  Returns the dict of ops.decode
+        (``labels``: int64 [total_frames] global class ids; ``spans``: [n_videos, t_max+1])."""
+        self._require_device(pc.x, 'decode_packed')
+        if pc.tables is None:
+            self.prepare_packed(pc)
+        t = pc.tables
+        return ops.decode(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
+                          cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'], want_spans=want_spans,
+                          want_labels=want_labels, want_elp=want_elp)
+
+    def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
+                       additional_allowed_ends_per_instance=None, constraints=None):
+        raise NotImplementedError("log-partition kernels (smm_logz_f64) are not built yet")

@@ -1,0 +1,115 @@
+"""Span/label codecs and closed-form sufficient statistics.
+
+Mirrors reference ``src/models/semimarkov/semimarkov_utils.py`` (same function names and conventions):
+``labels_to_spans`` :6, ``rle_spans`` :26, ``spans_to_labels`` :51, ``semimarkov_sufficient_stats`` :74.
+Vectorised host code (these run once per corpus / are not on the device path; the HIP decode kernel
+emits span encodings and frame labels itself).
+"""
+import numpy as np
+import torch
+
+
+def labels_to_spans(position_labels, max_k):
+    """b x N labels -> span encoding: class id at a span start, -1 for its continuation.  A run of one label is
+    cut every ``max_k - 1`` frames (the DP only knows segment lengths 1..max_k-1).  utils.py:6-23."""
+    lab = position_labels.detach().cpu().numpy() if torch.is_tensor(position_labels) else np.asarray(position_labels)
+    assert not (lab == -1).any(), "position_labels already appear span encoded (have -1)"
+    b, n = lab.shape
+    out = lab.copy()
+    if n > 1:
+        change = np.ones((b, n), dtype=bool)
+        change[:, 1:] = lab[:, 1:] != lab[:, :-1]
+        idx = np.arange(n)[None, :].repeat(b, 0)
+        run_start = np.maximum.accumulate(np.where(change, idx, 0), axis=1)
+        pos_in_run = idx - run_start
+        if max_k is not None:
+            cont = pos_in_run % max(max_k - 1, 1) != 0
+        else:
+            cont = pos_in_run != 0
+        out[cont] = -1
+    if torch.is_tensor(position_labels):
+        return torch.from_numpy(out).to(position_labels.device)
+    return out
+
+
+def spans_to_labels(spans):
+    """Forward-fill -1 with the running label.  utils.py:51-63."""
+    sp = spans.detach().cpu().numpy() if torch.is_tensor(spans) else np.asarray(spans)
+    assert (sp[:, 0] != -1).all()
+    b, n = sp.shape
+    idx = np.where(sp != -1, np.arange(n)[None, :], 0)
+    last = np.maximum.accumulate(idx, axis=1)
+    out = np.take_along_axis(sp, last, axis=1)
+    if torch.is_tensor(spans):
+        return torch.from_numpy(out).to(spans.device)
+    return out
+
+
+def rle_spans(spans, lengths):
+    """[(symbol, run length), ...] per instance.  utils.py:26-48."""
+    sp = spans.detach().cpu().numpy() if torch.is_tensor(spans) else np.asarray(spans)
+    res = []
+    for i in range(sp.shape[0]):
+        row = sp[i, :int(lengths[i])]
+        starts = np.flatnonzero(row != -1)
+        if len(row) and (len(starts) == 0 or starts[0] != 0):
+            starts = np.concatenate([[0], starts])
+        ends = np.concatenate([starts[1:], [len(row)]])
+        rle = [(int(row[s]), int(e - s)) for s, e in zip(starts, ends)]
+        assert sum(c for _, c in rle) == int(lengths[i])
+        res.append(rle)
+    return res
+
+
+def semimarkov_sufficient_stats(feature_list, label_list, covariance_type, n_classes, max_k=None):
+    """Closed-form statistics of reference utils.py:74-126 without the sklearn dependency.
+
+    Returns (emission_stats, span_stats): emission_stats has ``means_`` (n_classes x D, one-hot-responsibility
+    means, nk = count + 10*eps as sklearn's ``_estimate_gaussian_parameters``) and ``covariances_`` (n_classes x D
+    rows of the tied GLOBAL biased per-dim variance + 1e-6 for 'tied_diag').
+    """
+    assert len(feature_list) == len(label_list)
+    assert covariance_type == 'tied_diag', "only the reference's tied diagonal covariance is built"
+    span_counts = np.zeros(n_classes, dtype=np.float32)
+    span_lengths = np.zeros(n_classes, dtype=np.float32)
+    span_start_counts = np.zeros(n_classes, dtype=np.float32)
+    span_transition_counts = np.zeros((n_classes, n_classes), dtype=np.float32)   # to, from
+    d = int(np.asarray(feature_list[0]).shape[1])
+    sum_x = np.zeros((n_classes, d))
+    cnt = np.zeros(n_classes)
+    tot = np.zeros(d)
+    tot2 = np.zeros(d)
+    n_all = 0
+    for x, labels in zip(feature_list, label_list):
+        x = x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+        y = labels.detach().cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+        x = x.astype(np.float64)
+        rle = rle_spans(labels_to_spans(y[None], max_k), [y.shape[0]])[0]
+        syms = np.array([s for s, _ in rle])
+        lens = np.array([c for _, c in rle], dtype=np.float32)
+        span_start_counts[syms[0]] += 1
+        np.add.at(span_counts, syms, 1)
+        np.add.at(span_lengths, syms, lens)
+        np.add.at(span_transition_counts, (syms[1:], syms[:-1]), 1)
+        np.add.at(sum_x, y, x)
+        np.add.at(cnt, y, 1)
+        tot += x.sum(0)
+        tot2 += (x * x).sum(0)
+        n_all += x.shape[0]
+    eps10 = 10 * np.finfo(np.float64).eps
+    means = sum_x / (cnt + eps10)[:, None]
+    gmean = tot / (n_all + eps10)
+    var = tot2 / (n_all + eps10) - gmean ** 2 + 1e-6
+
+    class _Emissions:
+        pass
+    em = _Emissions()
+    em.means_ = means
+    em.covariances_ = np.tile(var[None], (n_classes, 1))
+    return em, {
+        'span_counts': span_counts,
+        'span_lengths': span_lengths,
+        'span_start_counts': span_start_counts,
+        'span_transition_counts': span_transition_counts,
+        'instance_count': len(feature_list),
+    }

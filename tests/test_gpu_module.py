@@ -1,0 +1,91 @@
+"""GPU parity of the product SemiMarkovModule.viterbi (features -> spans) against the oracles."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_ref as O
+from oracle import factored as F
+from golden_util import CASES, case_inputs, assert_spans_equivalent
+from module_util import module_from_golden, make_args
+
+pytestmark = pytest.mark.gpu
+EOS_CASES = [c for c in CASES if CASES[c].get('add_eos', True)]
+
+
+@pytest.mark.parametrize('case', EOS_CASES)
+def test_viterbi_matches_reference_path_on_golden_cases(golden, case):
+    """End to end against the fp64 run of the reference path (dense potentials + restated pytorch-struct DP)."""
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    vc = None if valid is None else [valid for _ in range(feats.shape[0])]
+    spans, elp = m.viterbi(feats.float().to(dev), lengths.to(dev), vc, add_eos=True,
+                           additional_allowed_ends_per_instance=cfg.get('additional'),
+                           constraints=None if cons is None else cons.float().to(dev), return_elp=True)
+    assert spans.device.type == 'cpu' and spans.dtype == torch.int64
+    assert spans.shape == (feats.shape[0], feats.shape[1] + 1)
+    r = O.viterbi_full(p, feats, lengths, valid, True, cfg.get('additional'), cons)
+    for i, t in enumerate(lengths.tolist()):
+        np.testing.assert_allclose(elp[i, :t].cpu().numpy(), r['elp'][i, :t].numpy(), rtol=3e-7, atol=1e-5)
+    # same frame labels / EOS placement as the reference path; boundaries inside one-class runs certified by re-scoring
+    assert_spans_equivalent(spans.numpy(), r['spans'].numpy(), lengths, p.n_classes)
+    local = O.map_spans_to_local(spans, valid, p.n_classes)
+    np.testing.assert_allclose(O.rescore(r['scores'], local, r['pos_lengths']).numpy(), r['v'].numpy(),
+                               rtol=1e-9, atol=1e-7)
+    # and identical to what the reference's own host code produced with the restated DP (fixture)
+    assert_spans_equivalent(spans.numpy(), golden[case + '/f64/ref_spans'], lengths, p.n_classes)
+
+
+@pytest.mark.parametrize('case', EOS_CASES)
+def test_viterbi_bit_exact_vs_factored_oracle_on_module_tables(golden, case):
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    b = feats.shape[0]
+    vc = None if valid is None else [valid for _ in range(b)]
+    spans = m.viterbi(feats.float().to(dev), lengths.to(dev), vc,
+                      additional_allowed_ends_per_instance=cfg.get('additional'),
+                      constraints=None if cons is None else cons.float().to(dev))
+    with torch.no_grad():
+        tab = {k: v.cpu().numpy() for k, v in m.factor_tables(valid).items()}
+    c = tab['init'].shape[0]
+    w = tab['w']                                   # D x C
+    x = feats.float().numpy().astype(np.float64)
+    elp = tab['cst'] + x @ w - 0.5 * (x * x) @ tab['inv_var'][:, None]
+    if cons is not None:
+        elp = elp + cons.float().numpy().astype(np.float64)
+    ends = O.allowed_ends_for_batch(p, valid, cfg.get('additional'), b)
+    fs, fv = F.viterbi(elp, lengths.numpy(), tab['trans'], tab['init'], tab['len'],
+                       F.endpen_from_allowed_ends(ends, b, c))
+    table = np.concatenate([tab['class_map'], [-1]])
+    # emission sums differ in association (GPU: running FMA; here: matmul), so equality is up to exact ties only
+    assert_spans_equivalent(spans.numpy(), table[fs], lengths, p.n_classes)
+
+
+def test_viterbi_decode_alias_and_larger_random_batch():
+    from action_segmentation_amd.semimarkov_modules import SemiMarkovModule
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    n_classes, d, k, b, tmax = 12, 40, 50, 6, 700
+    m = SemiMarkovModule(make_args(k), n_classes, d, allow_self_transitions=True)
+    with torch.no_grad():
+        m.poisson_log_rates.copy_(torch.rand(n_classes, generator=g) * 2 + 1.5)
+        m.gaussian_means.copy_(torch.randn(n_classes, d, generator=g) * 0.5)
+        m.gaussian_cov.copy_(torch.diag(0.5 + torch.rand(d, generator=g)))
+        m.transition_logits.copy_(torch.randn(n_classes, n_classes, generator=g))
+    m = m.to(dev)
+    lengths = torch.randint(300, tmax + 1, (b,), generator=g); lengths[2] = tmax
+    labels = torch.randint(0, n_classes, (b, tmax // 25 + 1), generator=g).repeat_interleave(25, dim=1)[:, :tmax]
+    feats = m.gaussian_means.detach().cpu()[labels] + torch.randn(b, tmax, d, generator=g)
+    for i, t in enumerate(lengths.tolist()):
+        feats[i, t:] = 0
+    valid = torch.tensor([0, 2, 3, 5, 6, 7, 9, 11])
+    spans = m.viterbi_decode(feats.to(dev), lengths.to(dev), [valid] * b)
+    p = O.RefParams(n_classes, m.poisson_log_rates.detach().cpu(), m.gaussian_means.detach().cpu(),
+                    torch.diagonal(m.gaussian_cov.detach().cpu()).clone(), m.transition_logits.detach().cpu(),
+                    m.init_logits.detach().cpu(), k, True).to(torch.float64)
+    trans, init, lens, merged = O.factor_tables(p, valid)
+    elp = O.emission_log_probs(feats.double(), p.gaussian_means[merged], p.gaussian_cov_diag)
+    fs, fv = F.viterbi(elp.numpy(), lengths.numpy(), trans.numpy(), init.numpy(), lens.numpy())
+    table = np.array(valid.tolist() + [n_classes, -1])
+    assert_spans_equivalent(spans.numpy(), table[fs], lengths, n_classes)

@@ -1,0 +1,96 @@
+"""Host-side logic of the product SemiMarkovModule against the reference's golden vectors (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, case_inputs
+from module_util import module_from_golden, make_args
+
+
+@pytest.mark.parametrize('case', list(CASES))
+def test_scorers_and_dense_potentials_match_reference_fp32(golden, case):
+    m = module_from_golden(golden, case)
+    _, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float32)
+    pre = case + '/f32/'
+    tol = dict(rtol=2e-5, atol=2e-4)
+    with torch.no_grad():
+        np.testing.assert_allclose(m.initial_log_probs(valid).numpy(), golden[pre + 'init'], **tol)
+        np.testing.assert_allclose(m.transition_log_probs(valid).numpy(), golden[pre + 'trans'], **tol)
+        np.testing.assert_allclose(m.length_log_probs(valid).numpy(), golden[pre + 'len'], **tol)
+        scores, log_det, elp = m.score_features(feats, lengths, valid, add_eos=cfg.get('add_eos', True),
+                                                use_mean_z=True,
+                                                additional_allowed_ends_per_instance=cfg.get('additional'),
+                                                constraints=cons, return_elp=True)
+    np.testing.assert_allclose(elp.numpy(), golden[pre + 'elp'], **tol)
+    ref = golden[pre + 'scores']
+    assert scores.shape == ref.shape
+    b = scores.shape[0]
+    for i in range(b):   # cells no path reads (reference's wrapped negative index, padded tail) are not compared
+        li = int(lengths[i]) + (1 if cfg.get('add_eos', True) else 0)
+        np.testing.assert_allclose(scores[i, :li - 1].numpy(), ref[i, :li - 1], **tol)
+    assert float(log_det.abs().sum()) == 0.0 and m.kl.shape == (b,)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'subset_merge', 'constrained', 'hmm_k1'])
+def test_fp64_factor_tables_match_oracle(golden, case):
+    from oracle import dense_ref as O
+    m = module_from_golden(golden, case)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    trans, init, lens, merged = O.factor_tables(p, valid)
+    with torch.no_grad():
+        tab = m.factor_tables(valid)
+    np.testing.assert_allclose(tab['trans'].numpy(), trans.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(tab['init'].numpy(), init.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(tab['len'].numpy(), lens.numpy(), rtol=1e-12, atol=1e-12)
+    # emission factors reproduce the density: cst + x.w - 0.5 x^2.inv_var
+    elp = O.emission_log_probs(feats, p.gaussian_means[merged], p.gaussian_cov_diag)
+    mine = tab['cst'] + feats @ tab['w'] - 0.5 * (feats * feats) @ tab['inv_var'][:, None]
+    np.testing.assert_allclose(mine.numpy(), elp.numpy(), rtol=1e-10, atol=1e-9)
+    ids = list(range(p.n_classes)) if valid is None else valid.tolist()
+    assert tab['class_map'].tolist() == ids + [p.n_classes]
+
+
+def test_fit_supervised_matches_reference(golden):
+    from action_segmentation_amd.semimarkov_modules import SemiMarkovModule
+    n_classes, k = int(golden['fit/n_classes']), int(golden['fit/max_k'])
+    feats = [torch.from_numpy(golden['fit/features%d' % i]) for i in range(5)]
+    labels = [torch.from_numpy(golden['fit/labels%d' % i]) for i in range(5)]
+    m = SemiMarkovModule(make_args(k), n_classes, feats[0].shape[1], allow_self_transitions=True)
+    m.fit_supervised(feats, labels)
+    for name, prm in m.state_dict().items():
+        np.testing.assert_allclose(prm.numpy(), golden['fit/param/' + name], rtol=2e-6, atol=1e-6, err_msg=name)
+
+
+def test_no_cpu_decode_path(golden):
+    from action_segmentation_amd._lib import SmmError
+    m = module_from_golden(golden, 'tiny')
+    _, feats, lengths, valid, cons, cfg = case_inputs(golden, 'tiny', torch.float32)
+    with pytest.raises(SmmError):
+        m.viterbi(feats, lengths, None)
+    with pytest.raises(NotImplementedError):
+        m.viterbi(feats, lengths, None, add_eos=False)
+
+
+def test_module_is_picklable_and_keeps_reference_parameter_names(golden):
+    import pickle
+    m = module_from_golden(golden, 'constrained')
+    m2 = pickle.loads(pickle.dumps(m))
+    assert set(m2.state_dict()) == {'poisson_log_rates', 'gaussian_means', 'gaussian_cov', 'transition_logits',
+                                    'init_logits', 'init_constraints', 'transition_constraints'}
+    assert m2.allowed_ends == {4, 6} and m2.max_k == 6
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports everything include/smmdp.h declares."""
+    import os, re
+    from action_segmentation_amd import _build, _lib
+    _build.build()
+    lib = _lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'smmdp.h')).read()
+    declared = set(re.findall(r'\b(smm_[a-z0-9_]+)\s*\(', header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_lib.SYMBOLS) == declared
+    assert lib.smm_strerror(0) == b'ok' and b'workspace' in lib.smm_strerror(-3)

@@ -95,7 +95,7 @@ def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False):
     """x fp32 [total_frames, d] -> elp fp64 and/or fp32 [total_frames, c_max].  (smm_emission_f64)"""
     lib = _lib.load()
     dev = x.device
-    elp64 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float64, device=dev) if want64 else None
+    elp64 = torch.empty((batch.total_frames, batch.c_max), dtype=torch.float64, device=dev) if want64 else None
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want32 else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, _, ns = batch.host_ptrs()

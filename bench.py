@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Benchmark of the semi-Markov decode path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|cfg4] [--scale S]
+
+One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + D->H copy of the
+labels) over this rank's synthetic corpus, features already resident in HBM.  Default workload: cfg3, the shape
+BASELINE.json's metric is quoted on (CrossTask-shaped: 18 tasks x 20 videos, T ~ 6k (500..14k), 11..23 states per
+task, max span L = K-1 = 1023, D = 200).  With N > 1 (torchrun, one rank per GPU) every rank decodes its own
+corpus of that size (weak scaling; videos are independent, so there is no data-path collective); RCCL carries the
+MAX of the step time and the SUM of the metric counters.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (the DP kernel), timed live with HIP events
+on the stream it is launched on; ``cpu_baseline`` is the oracle's dense reference-path restatement on a bounded
+sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9   # fp64 lane-ops/s: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4'])
+    p.add_argument('--scale', type=float, default=1.0, help='videos per task multiplier')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    return p.parse_args()
+
+
+def dist_setup(n):
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if n > 1 or world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    return rank, world, local
+
+
+def cpu_baseline(data, model, pc):
+    """Dense reference-path restatement (oracle/dense_ref.py: log_hsmm potentials + sequential max-DP with
+    back-pointers, fp32 like the reference) on a bounded sample: the first frames of the first video."""
+    from oracle import dense_ref as O
+    m = model.model
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    p = O.RefParams(m.n_classes, sd['poisson_log_rates'], sd['gaussian_means'], torch.diagonal(sd['gaussian_cov']).clone(),
+                    sd['transition_logits'], sd['init_logits'], m.max_k, True)
+    (task, name) = sorted(data._videos)[0]
+    smp = data._videos[(task, name)]
+    c = len(smp['task_indices'])
+    k_all = min(m.max_k, 4096)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))     # small per-step tensors: more threads only add overhead
+    feats_all = smp['features'].cpu().float()
+
+    def run(t):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.viterbi(p, feats_all[:t].unsqueeze(0), torch.tensor([t]), smp['task_indices'])
+        return time.perf_counter() - t0
+
+    # bounded sample: cost ~ t * min(K, t) * C^2; calibrate on 192 frames, then aim at ~15 s and <= 2 GB of potentials
+    t_cal = min(192, feats_all.shape[0])
+    dt_cal = run(t_cal)
+    per_cell = dt_cal / (t_cal * min(k_all, t_cal))
+    t = int(min(feats_all.shape[0], 2.0e9 / (4.0 * k_all * (c + 1) ** 2), max(k_all + 64, 15.0 / (per_cell * k_all))))
+    while t > 64 and per_cell * t * min(k_all, t) > 40.0:
+        t //= 2
+    dt = run(t)
+    feats = feats_all[:t].unsqueeze(0)
+    return {"value": t / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "first %d frames of video %s (C=%d, K=%d, D=%d): dense b x N x K x C x C fp32 potentials + "
+                      "sequential max-DP with back-pointers (oracle/dense_ref.py), %.1f s" % (t, name, c, m.max_k,
+                                                                                            feats.shape[-1], dt)}
+
+
+def cpu_factored(pc, model, max_videos=8):
+    """The plain-C factored oracle (OpenMP over videos) on a few videos: the 'fair' CPU number."""
+    from oracle import factored as F
+    t = pc.tables
+    n = min(max_videos, pc.n_videos)
+    frames, dt = 0, 0.0
+    for i in range(n):
+        g = pc.group[i]
+        c = pc.n_states[g]
+        off, ln = pc.frame_offset[i], pc.lengths[i]
+        x = pc.x[off:off + ln].cpu().numpy()
+        t0 = time.perf_counter()
+        w = t['w'][g, :, :c].cpu().numpy()
+        xd = x.astype(np.float64)
+        elp = t['cst'][g, :c].cpu().numpy() + xd @ w - 0.5 * (xd * xd) @ t['inv_var'].cpu().numpy()[:, None]
+        F.viterbi(elp[None], [ln], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
+                  t['len'][g, :pc.kp[i], :c].cpu().numpy())
+        dt += time.perf_counter() - t0
+        frames += ln
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d videos, oracle/smm_oracle.c factored fp64 DP, one video at a time" % n}
+
+
+def main():
+    a = parse()
+    rank, world, local = dist_setup(a.gpus)
+    dev = torch.device('cuda', local if world > 1 else 0)
+    from action_segmentation_amd import ops, synth
+    from action_segmentation_amd.semimarkov import SemiMarkovModel
+
+    cfg = synth.CONFIGS[a.workload]
+    data = synth.SynthDatasplit(a.workload, seed=1000 + rank, device=dev, scale=a.scale)
+    fit_args = synth.make_args(cfg['max_k'], cuda=False, batch_size=cfg['batch_size'])
+    fitted = SemiMarkovModel.from_args(fit_args, data)
+    fitted.fit(data.subset(2), use_labels=True)       # closed-form fit on 2 videos per task: "trained" parameters
+    args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'],
+                           sm_constrain_transitions=bool(cfg.get('narration')),
+                           sm_constrain_with_narration=['test'] if cfg.get('narration') else [])
+    model = SemiMarkovModel.from_args(args, data)
+    model.model.load_state_dict(fitted.model.state_dict(), strict=False)
+    model.model.to(dev)
+    pc = model.prepare(data)                                         # inputs resident in HBM from here on
+    frames = pc.n_frames
+    t = pc.tables
+    stream = torch.cuda.current_stream()
+
+    def step(events=None):
+        """emission -> DP -> labels on the host.  (Same two launches as smm_decode_f32; split only so that HIP
+        events can bracket the DP kernel on the stream it runs on.)"""
+        elp64, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
+        if events:
+            events[0].record(stream)
+        out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
+                          class_map=t['class_map'], want_spans=False, want_labels=True)
+        if events:
+            events[1].record(stream)
+        return out['labels'].cpu()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(a.warmup):
+        labels = step()
+    sync()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        labels = step(evs[i])
+    sync()
+    dt = time.perf_counter() - t0
+    dp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+    # metric counters: frame accuracy (MoF) numerator / denominator, summed over ranks with one RCCL all-reduce
+    lab = labels.numpy()
+    correct = sum(int((lab[o:o + n] == data._videos[(tk, nm)]['gt_single'].numpy()).sum())
+                  for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths))
+    counters = torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(counters, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    total_frames = float(counters[2])
+    dt = float(tmax[0])
+
+    if rank == 0:
+        c_avg = float(np.mean([pc.n_states[g] for g in pc.group]))
+        cells = sum(ln * ((min(kp, ln + 1) - 1) * pc.n_states[g] + pc.n_states[g] ** 2)
+                    for ln, kp, g in zip(pc.lengths, pc.kp, pc.group))
+        # algorithmic HBM bytes of the DP kernel per frame: elp in 8C, history out 24C, label out 8
+        dp_bytes = sum(ln * (32 * pc.n_states[g] + 8) for ln, g in zip(pc.lengths, pc.group))
+        achieved = dp_bytes / (dp_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(a.workload, {}).get('smm_viterbi_kernel_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "frames/sec semi-Markov decode, CrossTask T~10k K~20 L=1024, 1/2/4/8 GPUs",
+            "value": total_frames * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
+                                   "task (mean %.1f), max span length %d, D=%d; closed-form-fitted HSMM parameters"
+                       % (a.workload, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
+                          max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg, cfg['max_k'] - 1, cfg['d']),
+                       "parallelism": "videos sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "smm_viterbi_kernel", "kernel_ms": dp_ms,
+                         "algorithmic_bytes_per_launch": dp_bytes,
+                         "note": "the DP is fp64-VALU-bound, not HBM-bound: %.3g lattice cells/launch = %.2f T cell/s "
+                                 "= %.3f of the 2-op-per-cell fp64 VALU peak" % (
+                                     cells, cells / (dp_ms * 1e-3) / 1e12,
+                                     2 * cells / (dp_ms * 1e-3) / FP64_VALU_PEAK)},
+            "mof": float(counters[0] / counters[1]),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(data, model, pc)
+            try:
+                res["cpu_factored"] = cpu_factored(pc, model)
+            except Exception as e:                              # the C oracle needs gcc on the box; report, don't fail
+                res["cpu_factored"] = {"error": str(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

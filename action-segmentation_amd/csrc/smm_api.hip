@@ -63,7 +63,7 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
     p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
-    p.meta_bytes = p.o_err + 256;
+    p.meta_bytes = p.o_err + 512;   // error word + diagnostic counters
     size_t h = 0;
     for (int i = 0; i < s->b; ++i) h += 3 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;

@@ -6,30 +6,36 @@
 // order and the arg-max order are specified in oracle/smm_oracle.c (the CPU twin); they are repeated here
 // only where the mapping to the hardware needs them.
 //
-// Mapping.  One workgroup per video, NW waves; wave w owns states c = j*NW + w (j < SPW): "one wavefront
-// per (video, state) row".  The DP is run in PUSH form so that nothing has to be reduced across lanes in
-// the O(K) part:
-//   * ring slot p = n mod RING (RING = 64*R >= kp) holds the accumulator A[n][c] = max_k (h[n-k][c] + len[k][c])
-//     for a future position n; slot p lives in lane p/R, register p%R of the state's wave -- all 64*R
-//     accumulators of a state stay in VGPRs for the whole video;
-//   * when h[s][c] is final it is a wave-uniform scalar; every slot does A = max(A, h[s] + len[k]) with its own
-//     k = n - s.  k shrinks by one per step for every slot, so the length table is kept in registers too and
-//     ROTATED by one slot per step: one register is renamed (the loop is unrolled R times so the renaming is
-//     static) and one crosses to the next lane with a single DPP wave_ror:1 -- no LDS or memory traffic for
-//     the K*C work at all;
-//   * per frame the only cross-wave step is the C x C transition: gamma[n][c] goes through 8 bytes of LDS per
-//     state, one barrier, and a 32-lane DPP max.
-// The forward pass keeps VALUES only (2 fp64 VALU ops per lattice cell: v_add_f64 + v_max_f64).  The arg-max
-// is recovered afterwards along the optimal path only (one K*C scan per SEGMENT instead of per frame) from
-// the h / cumE history, re-evaluating exactly the expressions of the forward pass, so it is bit-identical
-// to tracking back-pointers.
+// Mapping.  One workgroup per video with two kinds of waves:
 //
-// HBM traffic per frame (c = states of the video): read elp 8c, write history 16c, write span 8 + label 8;
-// back-trace reads 16 B per (k, state) candidate of each segment.
+//   PUSHER waves (waves 1..NW-1), each owning SPW states ("one wavefront per (video, state) row").  The DP runs in
+//   PUSH form so that nothing K-proportional is ever reduced across lanes or leaves the register file:
+//     * ring slot p = n mod RING (RING = 64*R >= kp) holds the accumulator A[n][c] = max_k (h[n-k][c] + len[k][c])
+//       of a future position n, in lane p/R, register p%R of the state's wave;
+//     * when h[s][c] is final it is a wave-uniform scalar; every slot does A = max(A, h[s] + len[k]), k = n - s:
+//       2 fp64 VALU ops per lattice cell (v_add_f64, v_max_f64), nothing else;
+//     * k shrinks by one per step for every slot, so the length table lives in registers too and is ROTATED one slot
+//       per step: R-1 registers are renamed (the loop is unrolled R times, so statically) and one crosses to the next
+//       lane with a single DPP wave_ror:1.
+//
+//   one CHAIN wave (wave 0) that owns the serial part for ALL states, one lane per state: cumE += elp, gamma = cumE + A,
+//   the C x C transition, h = beta - cumE, and the history.  The transition is lane = target state: gamma[.] is
+//   broadcast through LDS and every lane folds its own row of the transition table (registers) over it; the two
+//   halves of the wave take half of the source states each and are merged with one v_permlane32_swap.
+//
+// Per frame: pushers do the ONE push the next position depends on, the owner lane hands A[n+1][c] to LDS, barrier 1,
+// then the pushers issue the other R-1 pushes of that frame WHILE the chain wave turns A[n+1][.] into h[n+1][.];
+// barrier 2; pushers read h[n+1][c].  The K-proportional work and the latency-bound serial chain overlap.
+//
+// The forward pass keeps VALUES only.  The arg-max is recovered afterwards along the optimal path only (one row
+// scan per SEGMENT instead of arg-max tracking per cell) from the history, re-evaluating exactly the expressions of
+// the forward pass, so it is bit-identical to tracking back-pointers.
+//
+// HBM traffic per frame (c states): read elp 8c, write history 24c (cumE, h, gamma; frame-major), label 8 B.
 #include "smm_device.h"
 
-// Diagnostic build only (-DSMM_PROFILE, never shipped): s_memtime stamps around the phases of a frame step,
-// summed per workgroup-0/wave-0 and written to the workspace's error block (+64 bytes).
+// Diagnostic build only (-DSMM_PROFILE, never shipped or timed): s_memtime stamps around the phases of a frame,
+// summed for workgroup 0 and written behind the workspace's error word (chain wave: +64 B, pusher wave 1: +192 B).
 #ifdef SMM_PROFILE
 #define SMM_STAMP(var)                                                            \
     do {                                                                          \
@@ -37,16 +43,25 @@
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
         __builtin_amdgcn_sched_barrier(0);                                        \
     } while (0)
-#define SMM_ACC(slot, t_from, t_to) prof_acc[slot] += (t_to) - (t_from)
+#define SMM_PROF_DECL unsigned long long pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0
+#define SMM_ACC(slot, t_from, t_to) pa[slot] += (t_to) - (t_from)
+#define SMM_PROF_OUT(off)                                                         \
+    if (blockIdx.x == 0 && lane == 0) {                                           \
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + (off); \
+        for (int q = 0; q < 8; ++q) pp[q] = pa[q];                                \
+    }
+#define SMM_PROF_WAVE(wv)                                                         \
+    if (blockIdx.x == 0 && lane == 0) {                                           \
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + 40 + (wv); \
+        pp[0] = pa[4];                                                            \
+    }
 #else
+#define SMM_PROF_WAVE(wv) do { } while (0)
 #define SMM_STAMP(var) do { } while (0)
+#define SMM_PROF_DECL do { } while (0)
 #define SMM_ACC(slot, a, b) do { } while (0)
+#define SMM_PROF_OUT(off) do { } while (0)
 #endif
-
-template <int R>
-struct SmmRing {
-    static constexpr int RING = 64 * R;
-};
 
 // wave-level lexicographic arg-max: larger val first, then smaller k, then smaller c
 __device__ __forceinline__ void smm_best3(double &v, int &k, int &c, double v2, int k2, int c2)
@@ -66,12 +81,23 @@ __device__ __forceinline__ void smm_wave_best3(double &v, int &k, int &c)
     }
 }
 
-template <int R, int SPW, int NW>
+// max(x[lane], x[lane ^ 32]) in every lane: one v_permlane32_swap per 32-bit half
+__device__ __forceinline__ double smm_max_halves(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
+}
+
+// R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
+// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
+template <int R, int SPW, int NW, int HF>
 __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
 {
     constexpr int RING = 64 * R;
-    constexpr int NP = (SPW + 3) / 4;                 // transition passes: 4 target states (DPP rows) per pass
-    const int vid = a.order[blockIdx.x];
+    constexpr int NP = NW - 1;
+        const int vid = a.order[blockIdx.x];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
     const int g = mv.group;
@@ -80,11 +106,6 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
     const int kp = mv.kp;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: scalar branches
     const int lane = threadIdx.x & 63;
-    const int row = lane >> 4, col = lane & 15;
-    // wave w owns states w, w+NW, w+2NW, ... (interleaved: waves w and w+4 share a SIMD, so SIMDs stay balanced)
-    const int nv_all = (C - w + NW - 1) / NW;
-    const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
-#define SMM_STATE(j) ((j) * NW + w)
 
     const double *trans = a.trans + (size_t)g * cm * cm;
     const double *init = a.init + (size_t)g * cm;
@@ -92,161 +113,192 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
     const double *elp = a.elp + (size_t)mv.frame_off * cm;
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
     const int64_t *cmap = a.class_map ? a.class_map + (size_t)g * (cm + 1) : nullptr;
-    double *hcum = a.hist + mv.hist_off;                  // [c][T+1]
-    double *hh = hcum + (size_t)cm * (T + 1);             // [c][T+1]
-    double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c], frame-major
+    double *hcum = a.hist + mv.hist_off;                  // [T+1][cm]  cumE[n][c]
+    double *hh = hcum + (size_t)cm * (T + 1);             // [T+1][cm]  h[n][c]
+    double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c]
     int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
     int64_t *labels = a.labels ? a.labels + mv.frame_off : nullptr;
 
-    __shared__ __attribute__((aligned(16))) double gam2[2][16][2];   // gamma[f + 16*half] at [parity][f][half]
-    __shared__ int sh_c;
+    __shared__ __attribute__((aligned(16))) double sh_apart[2][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
+    __shared__ __attribute__((aligned(16))) double sh_h[2][SMM_MAX_STATES_DEV];       // h[n][c]    chain -> pushers
+    __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];        // gamma[n][.] chain-private broadcast
+    __shared__ __attribute__((aligned(16))) double sh_elp[2][64 * SMM_MAX_STATES_DEV];  // elp rows of 64 frames, x2
     __shared__ unsigned sh_kmin[3];
+    __shared__ int sh_c;
 
     if (T <= 0) return;
-
-    // -------------------------------------------------------------------------------- set-up
     if (spans)
         for (int i = threadIdx.x; i <= a.t_max; i += blockDim.x) spans[i] = -1;
-    if (threadIdx.x < 64) (&gam2[0][0][0])[threadIdx.x] = 0.0;
-
-    double A[SPW][R], L[SPW][R];
-    double cum[SPW], hs[SPW], ecur[SPW], enxt[SPW], hb_h[SPW], hb_c[SPW];
-    double t0[NP], t1[NP];
-#pragma unroll
-    for (int j = 0; j < SPW; ++j) {
-        const int c = SMM_STATE(j);
-        const bool ok = j < nv;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int p = lane * R + r;
-            A[j][r] = SMM_NEG_INF;
-            L[j][r] = (ok && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + c] : SMM_NEG_INF;
-        }
-        cum[j] = 0.0;
-        hs[j] = ok ? init[c] : 0.0;
-        ecur[j] = 0.0;
-        enxt[j] = (ok && lane < T) ? elp[(size_t)lane * cm + c] : 0.0;
-        hb_h[j] = 0.0;
-        hb_c[j] = 0.0;
+    if (threadIdx.x < SMM_MAX_STATES_DEV) {
+        const int c = threadIdx.x;
+        sh_h[0][c] = (c < C) ? init[c] : 0.0;
+        sh_h[1][c] = 0.0;
+        sh_apart[0][c] = SMM_NEG_INF;
+        sh_apart[1][c] = SMM_NEG_INF;
+        sh_gam[c] = SMM_NEG_INF;
+        if (c < C) { hcum[c] = 0.0; hh[c] = init[c]; }                             // history of n = 0
     }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int jt = 4 * p + row;                                        // target state handled by this DPP row
-        const bool ok = jt < nv;
-        t0[p] = (ok && col < C) ? trans[(size_t)SMM_STATE(jt) * cm + col] : SMM_NEG_INF;
-        t1[p] = (ok && col + 16 < C) ? trans[(size_t)SMM_STATE(jt) * cm + col + 16] : SMM_NEG_INF;
+    // elp reaches the chain wave through LDS: the pusher waves copy 64-frame chunks (64*cm contiguous doubles) one
+    // chunk ahead, so the chain wave itself never waits on a vector-memory counter (its history stores stay in flight).
+    {
+        const int nel = ((T < 64) ? T : 64) * cm;
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) sh_elp[0][i] = elp[i];
     }
     __syncthreads();
 
-    // -------------------------------------------------------------------------------- forward (values only)
-    // Source step n (0 <= n < T) knows h[n] and cumE[n]; it pushes h[n] into the ring and finalises position n+1.
-    // Program order inside a step puts the one push position n+1 depends on first, hands gamma[n+1] to LDS, and
-    // only then issues the other R-1 pushes, so the K-proportional work sits in the shadow of the LDS round trip
-    // and of the barrier.  Global memory is touched once per 64 frames (elp chunk in, history chunk out).
-#ifdef SMM_PROFILE
-    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
-#endif
-    for (int base = 0; base < T; base += 64) {
-        // elp of this wave's states: lane <-> frame base+lane; the next chunk is fetched one chunk ahead
+    // One barrier per frame.  During frame n (between barrier n and barrier n+1):
+    //   pushers  read h[n] (LDS, parity n), clear ring slot n, push h[n] into every slot, then hand
+    //            A'[n+2][c] = max over sources <= n  (slot n+2, owner lane) to LDS (parity n+2 = n);
+    //   chain    reads A'[n+1][.] (handed over during frame n-1: sources <= n-1), adds the k = 1 term itself
+    //            (h[n] + len[1], both in its registers), and turns it into gamma[n+1], beta[n+1], h[n+1] (LDS, parity n+1).
+    // So the K-proportional pushes of frame n and the latency-bound serial chain of frame n+1 run side by side.
+    if (w == 0) {
+        // ============================================================================ chain wave
+        // The serial chain is the critical path of every frame; its SIMD partner is a pusher wave with an endless
+        // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
+        __builtin_amdgcn_s_setprio(3);
+        const int to = lane & 31, half = lane >> 5;
+        const bool live = to < C;
+        double tr[HF];                                    // trans[to][half*HF + i]
+#pragma unroll
+        for (int i = 0; i < HF; ++i) {
+            const int f = half * HF + i;
+            tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
+        }
+        const double len1 = (live && kp >= 2) ? len[(size_t)cm + to] : SMM_NEG_INF;   // len[1][to]
+        double cum = 0.0;
+        double hcur = live ? init[to] : 0.0;              // h[n][to]
+        double enext = live ? sh_elp[0][to] : 0.0;          // elp[n][to], read one frame ahead
+        SMM_PROF_DECL;
+        for (int n = 0; n < T; ++n) {
+            {
+                const double ecurv = enext;
+                const int n1 = n + 1;
+                enext = (live && n1 < T) ? sh_elp[(n1 >> 6) & 1][(n1 & 63) * cm + to] : 0.0;
+                const int nn = n + 1;
+                SMM_STAMP(q0);
+                const double acc = smm_fmax(sh_apart[nn & 1][to], hcur + len1);      // A[nn][to]
+                cum = cum + ecurv;
+                const double gm = cum + acc;
+                if (half == 0 && live) {
+                    sh_gam[to] = gm;
+                    hgam[(size_t)nn * cm + to] = gm;
+                    hcum[(size_t)nn * cm + to] = cum;
+                }
+                SMM_STAMP(q1);
+                if (nn < T) {
+                    // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
+                    const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
+                    double b0 = SMM_NEG_INF, b1 = SMM_NEG_INF;
+#pragma unroll
+                    for (int q = 0; q < HF / 2; ++q) {
+                        const double2 gv = gp[q];
+                        b0 = smm_fmax(b0, gv.x + tr[2 * q]);
+                        b1 = smm_fmax(b1, gv.y + tr[2 * q + 1]);
+                    }
+                    const double beta = smm_max_halves(smm_fmax(b0, b1));
+                    hcur = beta - cum;
+                    if (half == 0 && live) {
+                        sh_h[nn & 1][to] = hcur;
+                        hh[(size_t)nn * cm + to] = hcur;
+                    }
+                }
+                SMM_STAMP(q2);
+                __syncthreads();                                           // barrier n+1
+                SMM_STAMP(q3);
+                SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); if (q4) SMM_ACC(4, q4, q2); SMM_ACC(7, 0, 1); q4 = q3;
+            }
+        }
+        SMM_PROF_OUT(8);
+        SMM_PROF_WAVE(0);
+    } else {
+        // ============================================================================ pusher waves
+        // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
+        // owns the fewest states
+        int rank = w - 1;
+        if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+        const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
+        const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
+        double A[SPW][R], L[SPW][R], hs[SPW];
 #pragma unroll
         for (int j = 0; j < SPW; ++j) {
-            ecur[j] = enxt[j];
-            const int f = base + 64 + lane;
-            enxt[j] = (j < nv && f < T) ? elp[(size_t)f * cm + SMM_STATE(j)] : 0.0;
+            const int c = j * NP + rank;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = lane * R + r;
+                A[j][r] = SMM_NEG_INF;
+                L[j][r] = (j < nv && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + c] : SMM_NEG_INF;
+            }
+            hs[j] = 0.0;
         }
-        const int stop = (T - base < 64) ? T - base : 64;
-        for (int i0 = 0; i0 < stop; i0 += R) {
+        constexpr int QMAX = (SMM_MAX_STATES_DEV + NP - 1) / NP;   // chunk elements per pusher thread
+        double pre[QMAX];
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) pre[q] = 0.0;
+        const int pidx = (w - 1) * 64 + lane;
+        SMM_PROF_DECL;
+        for (int n0 = 0; n0 < T; n0 += R) {
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int i = i0 + u;
-                if (i >= stop) break;
-                const int n = base + i;                      // n % R == u (64 % R == 0)
-                const int nn = n + 1;
-                const int rn = (u + 1) % R;                  // register of ring slot nn (static after unrolling)
-                const int owner = (nn & (RING - 1)) / R;     // lane of ring slot nn
-                const bool is_owner = lane == owner;
-                const bool is_hist = lane == i;
-                SMM_STAMP(ts0);
+                const int n = n0 + u;                            // source step; n % R == u
+                if (n >= T) break;
+                const int r2 = (u + 2) % R;                      // register of ring slot n+2 (static after unrolling)
+                const bool clear = lane == (n & (RING - 1)) / R;           // lane of ring slot n (register u)
+                const bool hand = lane == ((n + 2) & (RING - 1)) / R;      // lane of ring slot n+2
+                if (u == 0 && (n & 31) == 0) {
+                    // next 64-frame chunk of elp: global -> registers at the start of a chunk, -> LDS half a chunk later
+                    const int nbase = (n & ~63) + 64;
+                    const int nel = (T - nbase < 64 ? T - nbase : 64) * cm;        // <= 0 when there is no next chunk
+                    if ((n & 63) == 0) {
 #pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    if (j >= nv) break;
-                    const int c = SMM_STATE(j);
-                    const double e = smm_readlane(ecur[j], i);
-                    if (is_hist) { hb_h[j] = hs[j]; hb_c[j] = cum[j]; }             // history of step n
-                    A[j][rn] = smm_fmax(A[j][rn], hs[j] + L[j][(rn - u + R) % R]);
-                    cum[j] = cum[j] + e;
-                    const double gm = cum[j] + A[j][rn];                            // meaningful in the owner lane
-                    if (is_owner) {
-                        gam2[nn & 1][c & 15][c >> 4] = gm;
-                        A[j][rn] = SMM_NEG_INF;                                     // slot now accumulates nn + RING
+                        for (int q = 0; q < QMAX; ++q) {
+                            const int e = pidx + q * NP * 64;
+                            if (e < nel) pre[q] = elp[(size_t)nbase * cm + e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < QMAX; ++q) {
+                            const int e = pidx + q * NP * 64;
+                            if (e < nel) sh_elp[(nbase >> 6) & 1][e] = pre[q];
+                        }
                     }
                 }
-                SMM_STAMP(ts1);
+                SMM_STAMP(q0);
 #pragma unroll
                 for (int j = 0; j < SPW; ++j) {
                     if (j >= nv) break;
+                    hs[j] = sh_h[n & 1][j * NP + rank];          // h[n][c]  (LDS broadcast read)
+                }
+                SMM_STAMP(q1);
+#pragma unroll
+                for (int j = 0; j < SPW; ++j) {
+                    if (j >= nv) break;
+                    if (clear) A[j][u] = SMM_NEG_INF;            // slot n now accumulates position n + RING
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (r != rn) A[j][r] = smm_fmax(A[j][r], hs[j] + L[j][(r - u + R) % R]);
+                        A[j][r] = smm_fmax(A[j][r], hs[j] + L[j][(r - u + R) % R]);
+                    if (hand) sh_apart[n & 1][j * NP + rank] = A[j][r2];   // sources <= n of position n+2
                     L[j][(R - 1 - u + R) % R] = smm_wave_ror1(L[j][(R - 1 - u + R) % R]);
                 }
-                SMM_STAMP(ts2);
-                __syncthreads();
-                SMM_STAMP(ts3);
-                const double2 gv = *reinterpret_cast<const double2 *>(&gam2[nn & 1][col][0]);
-                if (w == (nn & (NW - 1)) && row == 0) {            // gamma[nn][.] -> history (128 B per store)
-                    if (col < C) hgam[(size_t)nn * cm + col] = gv.x;
-                    if (col + 16 < C) hgam[(size_t)nn * cm + col + 16] = gv.y;
-                }
-                if (nn < T) {
-                    SMM_STAMP(ts4);
-                    double beta[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        beta[p] = smm_row_max16(smm_fmax(gv.x + t0[p], gv.y + t1[p]));
-#pragma unroll
-                    for (int j = 0; j < SPW; ++j) {
-                        if (j >= nv) break;
-                        hs[j] = smm_readlane(beta[j / 4], 16 * (j % 4)) - cum[j];
-                    }
-                    SMM_STAMP(ts5);
-                    SMM_ACC(0, ts0, ts1); SMM_ACC(1, ts1, ts2); SMM_ACC(2, ts2, ts3); SMM_ACC(3, ts3, ts4);
-                    SMM_ACC(4, ts4, ts5); SMM_ACC(5, ts0, ts5);
-                }
+                SMM_STAMP(q2);
+                __syncthreads();                                 // barrier n+1
+                SMM_STAMP(q3);
+                SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); if (q4) SMM_ACC(4, q4, q2); SMM_ACC(7, 0, 1); q4 = q3;
             }
         }
-        // history chunk out: h[n], cumE[n] for n in [base, base + stop)
-        if (lane < stop) {
-#pragma unroll
-            for (int j = 0; j < SPW; ++j) {
-                if (j >= nv) break;
-                const size_t o = (size_t)SMM_STATE(j) * (T + 1) + base + lane;
-                hcum[o] = hb_c[j];
-                hh[o] = hb_h[j];
-            }
-        }
-    }
-#ifdef SMM_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + 8;
-        for (int q = 0; q < 6; ++q) pp[q] = prof_acc[q];
-        pp[6] = (unsigned long long)T;
-    }
-#endif
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < SPW; ++j)
-            if (j < nv) hcum[(size_t)SMM_STATE(j) * (T + 1) + T] = cum[j];
+        if (w == 1) { SMM_PROF_OUT(24); }
+        SMM_PROF_WAVE(w);
     }
 
     // -------------------------------------------------------------------------------- last position
-    // gam[T&1][.] holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
+    // sh_gam holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
+    __syncthreads();
     if (w == 0) {
         double f = SMM_NEG_INF;
         if (lane <= C) {
             for (int c = 0; c < C; ++c) {
                 const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c];
-                f = fmax(f, gam2[T & 1][c & 15][c >> 4] + wgt);
+                f = fmax(f, sh_gam[c] + wgt);
             }
             if (lane < C) f = f + SMM_BIG_NEG;
         }
@@ -286,14 +338,14 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
         while (fmask) {
             const int f = __builtin_amdgcn_readfirstlane(__ffsll(fmask) - 1);
             fmask &= fmask - 1;
-            const double cn = hcum[(size_t)f * (T + 1) + n];
+            const double cn = hcum[(size_t)n * cm + f];
             const double wf = smm_readlane(wgt, f);
-            const double *hrow = hh + (size_t)f * (T + 1);
+            const double *hcol = hh + f;
             const int lim = (kmax < k - 1) ? kmax : k - 1;      // an equal k with a larger state loses
             for (int kb = 0; kb < lim; kb += NW * 64) {
                 const int kk = kb + w * 64 + lane + 1;
                 bool hit = false;
-                if (kk <= lim) hit = ((cn + (hrow[n - kk] + len[(size_t)kk * cm + f])) + wf) == best;
+                if (kk <= lim) hit = ((cn + (hcol[(size_t)(n - kk) * cm] + len[(size_t)kk * cm + f])) + wf) == best;
                 const unsigned long long m = __ballot(hit);
                 const int slot = round % 3;
                 if (lane == 0 && m) atomicMin(&sh_kmin[slot], (unsigned)(kb + w * 64 + __ffsll(m)));
@@ -324,58 +376,53 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-// (SPW, NW) per state count; VGPR budget = 512/(NW/4) per lane and the kernel needs ~4*R*SPW + 40.
 #include <cstdlib>
 #include "../../include/smmdp.h"
 #include "smm_launch.h"
 
+// Configuration: 1 chain wave + NP pusher waves x SPW states, NP * SPW >= states.  VALU code can only address the
+// 256 architected VGPRs (the other half of the unified file are AGPRs) and a pusher needs ~4*R*SPW + 40 of them, so
+// R*SPW <= 52.  Fewer, fatter pushers are preferred (fewer waves per barrier), but at least one pusher per SIMD.
 template <int R, int SPW, int NW>
-static void launch_cfg(const SmmDpArgs &a, hipStream_t stream)
+static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_t stream)
 {
-    hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW>), dim3(a.b), dim3(NW * 64), 0, stream, a);
-}
-
-// Configuration: NW waves x SPW states per wave, NW * SPW >= states.  VALU code can only address the 256
-// architected VGPRs (the other 256 of the unified file are AGPRs), and a wave needs ~4*R*SPW + 56 of them,
-// so R*SPW <= 50; the smallest NW that fits is used (fewer waves = fewer copies of the per-frame transition).
-template <int R, int SPW, int NW>
-static int launch_if(const SmmDpArgs &a, int spw, int nw, hipStream_t stream)
-{
-    if (spw == SPW && nw == NW) { launch_cfg<R, SPW, NW>(a, stream); return 1; }
-    return 0;
+    if (spw != SPW || nw != NW) return 0;
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    return 1;
 }
 
 template <int R>
 static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
-    constexpr int SPW_MAX = (50 / R) > 8 ? 8 : (50 / R);
-    int nw = 4;
+    constexpr int SPW_MAX = (52 / R) > 8 ? 8 : (52 / R);
+    int nw = 8;
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
-    if (nw != 4 && nw != 8 && nw != 16) nw = 4;
-    while (nw <= 16 && (c_need + nw - 1) / nw > SPW_MAX) nw *= 2;
+    if (nw != 4 && nw != 8 && nw != 16) nw = 8;
+    while (nw <= 16 && (c_need + nw - 2) / (nw - 1) > SPW_MAX) nw *= 2;
     if (nw > 16) return SMM_ERR_UNSUPPORTED;
-    const int spw = (c_need + nw - 1) / nw;
+    const int spw = (c_need + nw - 2) / (nw - 1);
     int hit = 0;
     if constexpr (R <= 4) {
-        hit = launch_if<R, 1, 4>(a, spw, nw, stream) || launch_if<R, 2, 4>(a, spw, nw, stream) ||
-              launch_if<R, 3, 4>(a, spw, nw, stream) || launch_if<R, 4, 4>(a, spw, nw, stream) ||
-              launch_if<R, 5, 4>(a, spw, nw, stream) || launch_if<R, 6, 4>(a, spw, nw, stream) ||
-              launch_if<R, 7, 4>(a, spw, nw, stream) || launch_if<R, 8, 4>(a, spw, nw, stream) ||
-              launch_if<R, 1, 8>(a, spw, nw, stream) || launch_if<R, 2, 8>(a, spw, nw, stream) ||
-              launch_if<R, 3, 8>(a, spw, nw, stream) || launch_if<R, 4, 8>(a, spw, nw, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, stream) || launch_if<R, 2, 16>(a, spw, nw, stream);
+        hit = launch_if<R, 1, 4>(a, spw, nw, c_need, stream) || launch_if<R, 2, 4>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 4>(a, spw, nw, c_need, stream) || launch_if<R, 4, 4>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 6, 4>(a, spw, nw, c_need, stream) || launch_if<R, 8, 4>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 5, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
     } else if constexpr (R == 8) {
-        hit = launch_if<R, 1, 4>(a, spw, nw, stream) || launch_if<R, 2, 4>(a, spw, nw, stream) ||
-              launch_if<R, 3, 4>(a, spw, nw, stream) || launch_if<R, 4, 4>(a, spw, nw, stream) ||
-              launch_if<R, 5, 4>(a, spw, nw, stream) || launch_if<R, 6, 4>(a, spw, nw, stream) ||
-              launch_if<R, 1, 8>(a, spw, nw, stream) || launch_if<R, 2, 8>(a, spw, nw, stream) ||
-              launch_if<R, 3, 8>(a, spw, nw, stream) || launch_if<R, 4, 8>(a, spw, nw, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, stream) || launch_if<R, 2, 16>(a, spw, nw, stream);
+        hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 5, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
     } else if constexpr (R == 16) {
-        hit = launch_if<R, 1, 4>(a, spw, nw, stream) || launch_if<R, 2, 4>(a, spw, nw, stream) ||
-              launch_if<R, 3, 4>(a, spw, nw, stream) || launch_if<R, 2, 8>(a, spw, nw, stream) ||
-              launch_if<R, 3, 8>(a, spw, nw, stream) || launch_if<R, 1, 8>(a, spw, nw, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, stream) || launch_if<R, 2, 16>(a, spw, nw, stream);
+        hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
+              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
 }

@@ -21,12 +21,14 @@ def run(b, T, C, K):
     # error block offset: mirrors make_plan() in smm_api.hip
     al = lambda x: (x + 255) // 256 * 256
     o_err = al(32 * b) + al(4 * b) + al(4)
-    prof = ws[o_err + 64: o_err + 64 + 56].cpu().numpy().view(np.uint64)
-    n = float(prof[6]) - 1
-    names = ['finalize', 'pushes', 'barrier', 'gam read', 'transition', 'total']
-    print(f"b={b} T={T} C={C} K={K}: " + "  ".join(f"{nm}={prof[i]/n:.0f}" for i, nm in enumerate(names)), flush=True)
+    ch = ws[o_err + 64: o_err + 128].cpu().numpy().view(np.uint64).astype(np.float64)
+    pu = ws[o_err + 192: o_err + 256].cpu().numpy().view(np.uint64).astype(np.float64)
+    print(f"b={b} T={T} C={C} K={K}")
+    print("  chain : gamma=%4.0f transition=%4.0f barrier=%4.0f total=%4.0f" % tuple(ch[:4] / ch[7]))
+    print("  pusher: read_h=%4.0f pushes=%4.0f barrier=%4.0f total=%4.0f" % tuple(pu[:4] / pu[7]), flush=True)
+    wv = ws[o_err + 320: o_err + 320 + 64].cpu().numpy().view(np.uint64).astype(np.float64)
+    print("  busy cycles per frame by wave (release -> arrival):", " ".join("%4.0f" % (v / pu[7]) for v in wv))
 
 if __name__ == '__main__':
     run(64, 2048, 16, 20)
-    run(64, 2048, 16, 256)
     run(64, 4096, 20, 1024)

@@ -50,6 +50,12 @@
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + (off); \
         for (int q = 0; q < 8; ++q) pp[q] = pa[q];                                \
     }
+#define SMM_PROF_FRAME                                                            \
+    do {                                                                          \
+        SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); \
+        if (q4) SMM_ACC(4, q4, q2);                                               \
+        SMM_ACC(7, 0, 1); q4 = q3;                                                \
+    } while (0)
 #define SMM_PROF_WAVE(wv)                                                         \
     if (blockIdx.x == 0 && lane == 0) {                                           \
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + 40 + (wv); \
@@ -57,6 +63,7 @@
     }
 #else
 #define SMM_PROF_WAVE(wv) do { } while (0)
+#define SMM_PROF_FRAME do { } while (0)
 #define SMM_STAMP(var) do { } while (0)
 #define SMM_PROF_DECL do { } while (0)
 #define SMM_ACC(slot, a, b) do { } while (0)
@@ -206,7 +213,7 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
                 SMM_STAMP(q2);
                 __syncthreads();                                           // barrier n+1
                 SMM_STAMP(q3);
-                SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); if (q4) SMM_ACC(4, q4, q2); SMM_ACC(7, 0, 1); q4 = q3;
+                SMM_PROF_FRAME;
             }
         }
         SMM_PROF_OUT(8);
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
                 SMM_STAMP(q2);
                 __syncthreads();                                 // barrier n+1
                 SMM_STAMP(q3);
-                SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); if (q4) SMM_ACC(4, q4, q2); SMM_ACC(7, 0, 1); q4 = q3;
+                SMM_PROF_FRAME;
             }
         }
         if (w == 1) { SMM_PROF_OUT(24); }

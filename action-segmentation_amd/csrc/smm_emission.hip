@@ -13,23 +13,28 @@
 // loop is FMA-only.  No MFMA: D x C = 200 x 20 per frame in exact fp64 is below the fp64 VALU/HBM balance point.
 #include "smm_launch.h"
 
+// Pointer arguments are passed one by one (not in a struct) with __restrict__: only then can hipcc prove that the
+// wave-uniform reads of w / cst / inv_var are not clobbered by the elp stores and turn them into scalar loads.
 template <int CT>
-__global__ void __launch_bounds__(256) smm_emission_kernel(SmmEmArgs a)
+__global__ void __launch_bounds__(256)
+smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ n_states,
+                    const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
+                    const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
+                    float *__restrict__ elp32, int D, int cm)
 {
-    constexpr int DC = 64;                       // features per LDS stage
+    constexpr int DC = 32;                       // features per LDS stage
     __shared__ float xs[4][64][DC + 1];
     const int vid = blockIdx.y;
-    const SmmVideo mv = a.videos[vid];
+    const SmmVideo mv = videos[vid];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f0 = (blockIdx.x * 4 + wv) * 64;   // first frame of this wave's tile
     if (f0 >= mv.T) return;                      // whole wave exits (no block-wide barrier below)
     const int nfr = min(64, mv.T - f0);
     const int g = mv.group;
-    const int C = a.n_states[g];
-    const int cm = a.c_max, D = a.d;
-    const float *x = a.x + (size_t)(mv.frame_off + f0) * D;
-    const double *__restrict__ w = a.w + (size_t)g * D * cm;
-    const double *__restrict__ iv = a.inv_var;
+    const int C = n_states[g];
+    const float *__restrict__ x = xall + (size_t)(mv.frame_off + f0) * D;
+    const double *__restrict__ w = wall + (size_t)g * D * cm;
+    const int sub = lane >> 5, col = lane & 31;  // staging: two frames per instruction, 32 features each
 
     double acc[CT];
 #pragma unroll
@@ -38,10 +43,12 @@ __global__ void __launch_bounds__(256) smm_emission_kernel(SmmEmArgs a)
 
     for (int d0 = 0; d0 < D; d0 += DC) {
         const int nd = min(DC, D - d0);
-        for (int fr = 0; fr < nfr; ++fr)          // coalesced: 64 lanes read 64 consecutive features of one frame
-            xs[wv][fr][lane] = (lane < nd) ? x[(size_t)fr * D + d0 + lane] : 0.f;
+        for (int fr = 0; fr < nfr; fr += 2) {     // coalesced: 2 x 128-B row pieces per wave instruction
+            const int f = fr + sub;
+            xs[wv][f][col] = (f < nfr && col < nd) ? x[(size_t)f * D + d0 + col] : 0.f;
+        }
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's LDS writes have landed
+#pragma unroll 2
         for (int dd = 0; dd < nd; ++dd) {
             const double xv = (double)xs[wv][lane][dd];
             const double *__restrict__ wr = w + (size_t)(d0 + dd) * cm;   // wave-uniform -> scalar loads
@@ -53,14 +60,14 @@ __global__ void __launch_bounds__(256) smm_emission_kernel(SmmEmArgs a)
     }
     if (lane < nfr) {
         const size_t row = (size_t)(mv.frame_off + f0 + lane) * cm;
-        const double *cst = a.cst + (size_t)g * cm;
+        const double *__restrict__ cst = cstall + (size_t)g * cm;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (c < C) {
                 double v = (cst[c] + acc[c]) - 0.5 * q;
-                if (a.cons) v += (double)a.cons[row + c];
-                if (a.elp64) a.elp64[row + c] = v;
-                if (a.elp32) a.elp32[row + c] = (float)v;
+                if (cons) v += (double)cons[row + c];
+                if (elp64) elp64[row + c] = v;
+                if (elp32) elp32[row + c] = (float)v;
             }
         }
     }
@@ -77,10 +84,14 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
 void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, hipStream_t stream)
 {
     dim3 grid((t_max + 255) / 256, a.b), block(256);
-    if (ct <= 8) hipLaunchKernelGGL(smm_emission_kernel<8>, grid, block, 0, stream, a);
-    else if (ct <= 16) hipLaunchKernelGGL(smm_emission_kernel<16>, grid, block, 0, stream, a);
-    else if (ct <= 24) hipLaunchKernelGGL(smm_emission_kernel<24>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(smm_emission_kernel<32>, grid, block, 0, stream, a);
+#define SMM_EM_LAUNCH(CT)                                                                                          \
+    hipLaunchKernelGGL(smm_emission_kernel<CT>, grid, block, 0, stream, a.videos, a.n_states, a.x, a.w, a.cst,     \
+                       a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max)
+    if (ct <= 8) SMM_EM_LAUNCH(8);
+    else if (ct <= 16) SMM_EM_LAUNCH(16);
+    else if (ct <= 24) SMM_EM_LAUNCH(24);
+    else SMM_EM_LAUNCH(32);
+#undef SMM_EM_LAUNCH
 }
 
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream)

@@ -9,7 +9,9 @@ LIB = os.path.join(HERE, "libsmmdp.so")
 SOURCES = ["smm_api.hip", "smm_emission.hip", "smm_viterbi.hip"]
 HEADERS = ["smm_device.h", "smm_launch.h", os.path.join("..", "..", "include", "smmdp.h")]
 # -ffp-contract=off: every a+b in the DP must be ONE IEEE add (bit-exact twin of oracle/smm_oracle.c)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# unroll thresholds: the frame loops must unroll completely, or the register-resident rings become scratch arrays
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-mllvm", "-pragma-unroll-threshold=1048576", "-mllvm", "-unroll-threshold=1048576"]
 
 
 def stale():

@@ -7,10 +7,10 @@
 // (w = mu/sigma^2, cst = -0.5 sum mu^2/sigma^2 - sum log sigma - D/2 log 2pi; host-side, fp64), which is one
 // v_fma_f64 per (frame, d, state).  In fp64 the expansion costs nothing in accuracy (|terms| ~ 1e3, eps 1e-16).
 //
-// Mapping.  One lane per frame; a wave stages a 64-frame x 64-feature tile of x through LDS with coalesced
-// 256-B row reads (the only HBM traffic: 4*D bytes per frame), then every lane walks its own row.  w[d][.] is the
-// same for all lanes: it is fetched with scalar loads and used as the SGPR operand of the FMA, so the inner
-// loop is FMA-only.  No MFMA: D x C = 200 x 20 per frame in exact fp64 is below the fp64 VALU/HBM balance point.
+// Mapping.  One lane per frame; every lane walks its own feature row with 16-B loads issued one load ahead
+// (HBM traffic: 4*D bytes per frame, each 64-B sector fetched once and finished from L1/L2).  w[d][.] is the same
+// for all lanes: it is fetched with scalar loads and used as the SGPR operand of the FMA, so the inner loop is
+// FMA-only.  No MFMA: D x C = 200 x 20 per frame in exact fp64 is below the fp64 VALU/HBM balance point.
 #include "smm_launch.h"
 
 // Pointer arguments are passed one by one (not in a struct) with __restrict__: only then can hipcc prove that the
@@ -22,44 +22,50 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
                     float *__restrict__ elp32, int D, int cm)
 {
-    constexpr int DC = 32;                       // features per LDS stage
-    __shared__ float xs[4][64][DC + 1];
     const int vid = blockIdx.y;
     const SmmVideo mv = videos[vid];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int f0 = (blockIdx.x * 4 + wv) * 64;   // first frame of this wave's tile
-    if (f0 >= mv.T) return;                      // whole wave exits (no block-wide barrier below)
-    const int nfr = min(64, mv.T - f0);
+    const int f = blockIdx.x * 256 + threadIdx.x;   // one lane per frame
+    if ((int)(blockIdx.x * 256 + (threadIdx.x & ~63)) >= mv.T) return;   // whole wave past the end
+    const bool livef = f < mv.T;
     const int g = mv.group;
     const int C = n_states[g];
-    const float *__restrict__ x = xall + (size_t)(mv.frame_off + f0) * D;
+    // every lane walks its own feature row with 16-B loads, one load ahead of the FMAs (rows are 4*D bytes apart, so a
+    // wave instruction touches 64 lines; the other 3/4 of each 64-B sector are used by the next three loads from L1/L2)
+    const float *__restrict__ x = xall + (size_t)(mv.frame_off + (livef ? f : 0)) * D;
     const double *__restrict__ w = wall + (size_t)g * D * cm;
-    const int sub = lane >> 5, col = lane & 31;  // staging: two frames per instruction, 32 features each
 
     double acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.0;
     double q = 0.0;
 
-    for (int d0 = 0; d0 < D; d0 += DC) {
-        const int nd = min(DC, D - d0);
-        for (int fr = 0; fr < nfr; fr += 2) {     // coalesced: 2 x 128-B row pieces per wave instruction
-            const int f = fr + sub;
-            xs[wv][f][col] = (f < nfr && col < nd) ? x[(size_t)f * D + d0 + col] : 0.f;
+    if ((D & 3) == 0) {
+        const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+        float4 nxt = x4[0];
+        for (int d = 0; d < D; d += 4) {
+            const float4 cur = nxt;
+            if (d + 4 < D) nxt = x4[(d >> 2) + 1];
+            const float xs[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double xv = (double)xs[k];
+                const double *__restrict__ wr = w + (size_t)(d + k) * cm;   // wave-uniform -> scalar loads
+                q = fma(xv * iv[d + k], xv, q);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = fma(xv, wr[c], acc[c]);
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-        for (int dd = 0; dd < nd; ++dd) {
-            const double xv = (double)xs[wv][lane][dd];
-            const double *__restrict__ wr = w + (size_t)(d0 + dd) * cm;   // wave-uniform -> scalar loads
-            q = fma(xv * iv[d0 + dd], xv, q);
+    } else {
+        for (int d = 0; d < D; ++d) {
+            const double xv = (double)x[d];
+            const double *__restrict__ wr = w + (size_t)d * cm;
+            q = fma(xv * iv[d], xv, q);
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = fma(xv, wr[c], acc[c]);
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    if (lane < nfr) {
-        const size_t row = (size_t)(mv.frame_off + f0 + lane) * cm;
+    if (livef) {
+        const size_t row = (size_t)(mv.frame_off + f) * cm;
         const double *__restrict__ cst = cstall + (size_t)g * cm;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {

@@ -99,8 +99,11 @@ __device__ __forceinline__ double smm_max_halves(double x)
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
+// One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
+// architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
 template <int R, int SPW, int NW, int HF>
-__global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, NW / 4)))
+smm_viterbi_kernel(SmmDpArgs a)
 {
     constexpr int RING = 64 * R;
     constexpr int NP = NW - 1;
@@ -154,8 +157,9 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
     __syncthreads();
 
     // One barrier per frame.  During frame n (between barrier n and barrier n+1):
-    //   pushers  read h[n] (LDS, parity n), clear ring slot n, push h[n] into every slot, then hand
-    //            A'[n+2][c] = max over sources <= n  (slot n+2, owner lane) to LDS (parity n+2 = n);
+    //   pushers  start the LDS read of h[n] (parity n), finish the pushes of h[n-1] meanwhile, clear ring slot n, do the
+    //            one push of h[n] that slot n+2 needs and hand A'[n+2][c] = max over sources <= n (slot n+2, owner
+    //            lane) to LDS (parity n+2 = n); the other R-1 pushes of h[n] follow after the barrier;
     //   chain    reads A'[n+1][.] (handed over during frame n-1: sources <= n-1), adds the k = 1 term itself
     //            (h[n] + len[1], both in its registers), and turns it into gamma[n+1], beta[n+1], h[n+1] (LDS, parity n+1).
     // So the K-proportional pushes of frame n and the latency-bound serial chain of frame n+1 run side by side.
@@ -271,21 +275,32 @@ __global__ void __launch_bounds__(NW * 64) smm_viterbi_kernel(SmmDpArgs a)
                     }
                 }
                 SMM_STAMP(q0);
+                double hn[SPW];
 #pragma unroll
                 for (int j = 0; j < SPW; ++j) {
                     if (j >= nv) break;
-                    hs[j] = sh_h[n & 1][j * NP + rank];          // h[n][c]  (LDS broadcast read)
+                    hn[j] = sh_h[n & 1][j * NP + rank];          // h[n][c]  (LDS broadcast read, consumed below)
+                }
+                // While that read is in flight: the R-1 pushes of source n-1 that position n+1 did not depend on
+                // (everything but register (u+1)%R, pushed before the hand-over of the previous frame).
+                if (n >= 1) {
+#pragma unroll
+                    for (int j = 0; j < SPW; ++j) {
+                        if (j >= nv) break;
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (r != (u + 1) % R) A[j][r] = smm_fmax(A[j][r], hs[j] + L[j][(r - u + 1 + R) % R]);
+                        L[j][(R - u) % R] = smm_wave_ror1(L[j][(R - u) % R]);
+                    }
                 }
                 SMM_STAMP(q1);
 #pragma unroll
                 for (int j = 0; j < SPW; ++j) {
                     if (j >= nv) break;
+                    hs[j] = hn[j];
                     if (clear) A[j][u] = SMM_NEG_INF;            // slot n now accumulates position n + RING
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        A[j][r] = smm_fmax(A[j][r], hs[j] + L[j][(r - u + R) % R]);
-                    if (hand) sh_apart[n & 1][j * NP + rank] = A[j][r2];   // sources <= n of position n+2
-                    L[j][(R - 1 - u + R) % R] = smm_wave_ror1(L[j][(R - 1 - u + R) % R]);
+                    A[j][r2] = smm_fmax(A[j][r2], hs[j] + L[j][(r2 - u + R) % R]);   // the push slot n+2 waits for
+                    if (hand) sh_apart[n & 1][j * NP + rank] = A[j][r2];             // sources <= n of position n+2
                 }
                 SMM_STAMP(q2);
                 __syncthreads();                                 // barrier n+1
@@ -402,12 +417,16 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
 template <int R>
 static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
-    constexpr int SPW_MAX = (52 / R) > 8 ? 8 : (52 / R);
+    // 8 waves: 256 VGPRs per wave -> R*SPW <= 52;  16 waves: 128 VGPRs per wave -> R*SPW <= 22.
+    // K > 512 with more than 21 states fits neither (the rings of 22+ states x 1024 slots x fp64 (A, len) exceed the
+    // CU's register file); that shape still runs -- 16 waves x 2 states, spilling to scratch -- but slowly.
+    constexpr int SPW8 = (52 / R) > 5 ? 5 : (52 / R);
+    constexpr int SPW16 = (22 / R) > 3 ? 3 : ((22 / R) < 1 ? 1 : (22 / R));
     int nw = 8;
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
-    while (nw <= 16 && (c_need + nw - 2) / (nw - 1) > SPW_MAX) nw *= 2;
-    if (nw > 16) return SMM_ERR_UNSUPPORTED;
+    if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
+    (void)SPW16;
     const int spw = (c_need + nw - 2) / (nw - 1);
     int hit = 0;
     if constexpr (R <= 4) {

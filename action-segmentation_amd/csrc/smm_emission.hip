@@ -15,7 +15,7 @@
 
 // Pointer arguments are passed one by one (not in a struct) with __restrict__: only then can hipcc prove that the
 // wave-uniform reads of w / cst / inv_var are not clobbered by the elp stores and turn them into scalar loads.
-template <int CT>
+template <int CT, int FPL>   // FPL frames per lane: the scalar weight row of a feature is reused FPL times
 __global__ void __launch_bounds__(256)
 smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
@@ -24,53 +24,78 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
 {
     const int vid = blockIdx.y;
     const SmmVideo mv = videos[vid];
-    const int f = blockIdx.x * 256 + threadIdx.x;   // one lane per frame
-    if ((int)(blockIdx.x * 256 + (threadIdx.x & ~63)) >= mv.T) return;   // whole wave past the end
-    const bool livef = f < mv.T;
+    const int wave0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * FPL;   // first frame of this wave
+    if (wave0 >= mv.T) return;                                           // whole wave past the end
+    const int lane = threadIdx.x & 63;
+    int f[FPL];
+    bool livef[FPL];
+    const float4 *x4[FPL];
+#pragma unroll
+    for (int p = 0; p < FPL; ++p) {
+        f[p] = wave0 + p * 64 + lane;                                    // lane-consecutive frames: coalesced stores
+        livef[p] = f[p] < mv.T;
+        x4[p] = reinterpret_cast<const float4 *>(xall + (size_t)(mv.frame_off + (livef[p] ? f[p] : 0)) * D);
+    }
     const int g = mv.group;
     const int C = n_states[g];
-    // every lane walks its own feature row with 16-B loads, one load ahead of the FMAs (rows are 4*D bytes apart, so a
+    // every lane walks its own feature rows with 16-B loads, one load ahead of the FMAs (rows are 4*D bytes apart, so a
     // wave instruction touches 64 lines; the other 3/4 of each 64-B sector are used by the next three loads from L1/L2)
-    const float *__restrict__ x = xall + (size_t)(mv.frame_off + (livef ? f : 0)) * D;
     const double *__restrict__ w = wall + (size_t)g * D * cm;
 
-    double acc[CT];
+    double acc[FPL][CT], q[FPL];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) acc[c] = 0.0;
-    double q = 0.0;
+    for (int p = 0; p < FPL; ++p) {
+        q[p] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = 0.0;
+    }
 
     if ((D & 3) == 0) {
-        const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
-        float4 nxt = x4[0];
+        float4 nxt[FPL];
+#pragma unroll
+        for (int p = 0; p < FPL; ++p) nxt[p] = x4[p][0];
         for (int d = 0; d < D; d += 4) {
-            const float4 cur = nxt;
-            if (d + 4 < D) nxt = x4[(d >> 2) + 1];
-            const float xs[4] = {cur.x, cur.y, cur.z, cur.w};
+            float xs[FPL][4];
+#pragma unroll
+            for (int p = 0; p < FPL; ++p) {
+                xs[p][0] = nxt[p].x; xs[p][1] = nxt[p].y; xs[p][2] = nxt[p].z; xs[p][3] = nxt[p].w;
+                if (d + 4 < D) nxt[p] = x4[p][(d >> 2) + 1];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double xv = (double)xs[k];
                 const double *__restrict__ wr = w + (size_t)(d + k) * cm;   // wave-uniform -> scalar loads
-                q = fma(xv * iv[d + k], xv, q);
+                const double ivd = iv[d + k];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[c] = fma(xv, wr[c], acc[c]);
+                for (int p = 0; p < FPL; ++p) {
+                    const double xv = (double)xs[p][k];
+                    q[p] = fma(xv * ivd, xv, q[p]);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[p][c] = fma(xv, wr[c], acc[p][c]);
+                }
             }
         }
     } else {
         for (int d = 0; d < D; ++d) {
-            const double xv = (double)x[d];
             const double *__restrict__ wr = w + (size_t)d * cm;
-            q = fma(xv * iv[d], xv, q);
+            const double ivd = iv[d];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = fma(xv, wr[c], acc[c]);
+            for (int p = 0; p < FPL; ++p) {
+                const double xv = (double)reinterpret_cast<const float *>(x4[p])[d];
+                q[p] = fma(xv * ivd, xv, q[p]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[p][c] = fma(xv, wr[c], acc[p][c]);
+            }
         }
     }
-    if (livef) {
-        const size_t row = (size_t)(mv.frame_off + f) * cm;
-        const double *__restrict__ cst = cstall + (size_t)g * cm;
+    const double *__restrict__ cst = cstall + (size_t)g * cm;
+#pragma unroll
+    for (int p = 0; p < FPL; ++p) {
+        if (!livef[p]) continue;
+        const size_t row = (size_t)(mv.frame_off + f[p]) * cm;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             if (c < C) {
-                double v = (cst[c] + acc[c]) - 0.5 * q;
+                double v = (cst[c] + acc[p][c]) - 0.5 * q[p];
                 if (cons) v += (double)cons[row + c];
                 if (elp64) elp64[row + c] = v;
                 if (elp32) elp32[row + c] = (float)v;
@@ -89,14 +114,15 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
 
 void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, hipStream_t stream)
 {
-    dim3 grid((t_max + 255) / 256, a.b), block(256);
-#define SMM_EM_LAUNCH(CT)                                                                                          \
-    hipLaunchKernelGGL(smm_emission_kernel<CT>, grid, block, 0, stream, a.videos, a.n_states, a.x, a.w, a.cst,     \
-                       a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max)
-    if (ct <= 8) SMM_EM_LAUNCH(8);
-    else if (ct <= 16) SMM_EM_LAUNCH(16);
-    else if (ct <= 24) SMM_EM_LAUNCH(24);
-    else SMM_EM_LAUNCH(32);
+    dim3 block(256);
+#define SMM_EM_LAUNCH(CT, FPL)                                                                                     \
+    hipLaunchKernelGGL((smm_emission_kernel<CT, FPL>), dim3((t_max + 256 * FPL - 1) / (256 * FPL), a.b), block, 0,  \
+                       stream, a.videos, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons, a.elp64, a.elp32, a.d,     \
+                       a.c_max)
+    if (ct <= 8) SMM_EM_LAUNCH(8, 4);
+    else if (ct <= 16) SMM_EM_LAUNCH(16, 2);
+    else if (ct <= 24) SMM_EM_LAUNCH(24, 2);
+    else SMM_EM_LAUNCH(32, 2);
 #undef SMM_EM_LAUNCH
 }
 

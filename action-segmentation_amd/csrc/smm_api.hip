@@ -258,11 +258,26 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     return run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
 }
 
-extern "C" int smm_logz_f64(const smm_shape *, const int64_t *, const int64_t *, const int32_t *, const int32_t *,
-                            const int32_t *, const double *, const double *, const double *, const double *, const double *,
-                            double *, void *, size_t, void *)
+extern "C" int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                            const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                            const double *elp, const double *trans, const double *init, const double *len_scores,
+                            const double *endpen, double *logz, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return SMM_ERR_UNSUPPORTED;   // LogSemiring forward kernel: not built yet
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    if (!elp || !trans || !init || !len_scores || !logz) return SMM_ERR_ARG;
+    SmmDpArgs a{};
+    a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
+    a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = endpen;
+    a.hist = st.hist; a.err = st.err;
+    a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
+    rc = smm_launch_logz(a, logz, ring_regs(st.kp_max), st.c_need, hs);
+    if (rc != SMM_OK) return rc;
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
 }
 
 extern "C" int smm_logz_bwd_f64(const smm_shape *, const int64_t *, const int64_t *, const int32_t *, const int32_t *,

@@ -19,3 +19,5 @@ void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, hipStream_t 
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
+// LogSemiring forward: logz[b]; same arguments as the Viterbi launch
+int smm_launch_logz(const SmmDpArgs &a, double *logz, int r, int c_need, hipStream_t stream);

@@ -88,15 +88,6 @@ __device__ __forceinline__ void smm_wave_best3(double &v, int &k, int &c)
     }
 }
 
-// max(x[lane], x[lane ^ 32]) in every lane: one v_permlane32_swap per 32-bit half
-__device__ __forceinline__ double smm_max_halves(double x)
-{
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
-}
-
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole

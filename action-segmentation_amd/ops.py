@@ -145,3 +145,19 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32)
+
+
+def logz(batch, elp, trans, init, len_scores, endpen=None):
+    """Log-partition per video (smm_logz_f64).  elp fp64 [total_frames, c_max] -> logZ fp64 [b]."""
+    lib = _lib.load()
+    dev = elp.device
+    f64 = torch.float64
+    out = torch.empty(batch.b, dtype=f64, device=dev)
+    ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, kp, ns = batch.host_ptrs()
+    _lib.check(lib.smm_logz_f64(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.c_void_p(ns), _dev(elp, f64, 'elp'), _dev(trans, f64, 'trans'), _dev(init, f64, 'init'),
+        _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'), _dev(out, f64, 'logz'),
+        ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return out

@@ -446,6 +446,85 @@ class SemiMarkovModule(nn.Module):
                           cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'], want_spans=want_spans,
                           want_labels=want_labels, want_elp=want_elp)
 
+    # ------------------------------------------------------------------ likelihoods (reference :597-658)
+    def gold_score(self, features, lengths, valid_classes, spans, additional_allowed_ends_per_instance=None,
+                   constraints=None):
+        """Joint score of given span encodings = sum(potentials * to_parts(spans)) of the reference (:641-655),
+        evaluated on the factors (differentiable torch ops, O(T*C); no dense tensor).  spans: b x Tmax global ids."""
+        tab = self.factor_tables(valid_classes, features.device)
+        f64 = torch.float64
+        x = features.to(f64)
+        elp = tab['cst'] + x @ tab['w'] - 0.5 * (x * x) @ tab['inv_var'].unsqueeze(1)
+        if constraints is not None:
+            elp = elp + constraints.to(elp)
+        b, tmax, c = elp.shape
+        cum = torch.cat([elp.new_zeros(b, 1, c), elp.cumsum(1)], dim=1)
+        ids = list(range(self.n_classes)) if valid_classes is None else [int(v) for v in valid_classes]
+        local = {g: i for i, g in enumerate(ids)}
+        ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
+        k_rows = tab['len'].size(0)
+        kp = min(k_rows, tmax)
+        out = []
+        sp = spans.detach().cpu()
+        for i in range(b):
+            t = int(lengths[i])
+            row = sp[i, :t]
+            starts = torch.nonzero(row != -1).flatten().tolist()
+            assert starts and starts[0] == 0, "a span encoding starts with a label"
+            bounds = starts + [t]
+            labs = [local[int(row[s])] for s in starts]
+            total = tab['init'][labs[0]]
+            for j, (s0, s1) in enumerate(zip(bounds[:-1], bounds[1:])):
+                kk = s1 - s0
+                assert 1 <= kk <= kp - 1, "span longer than the model's max span length"
+                total = total + tab['len'][kk, labs[j]] + (cum[i, s1, labs[j]] - cum[i, s0, labs[j]])
+                if j + 1 < len(labs):
+                    total = total + tab['trans'][labs[j + 1], labs[j]]
+            if ends is not None and labs[-1] not in ends[i]:
+                total = total + BIG_NEG
+            out.append(total)
+        return torch.stack(out)
+
+    def log_partition(self, features, lengths, valid_classes, additional_allowed_ends_per_instance=None,
+                      constraints=None):
+        """log Z per instance on the device (smm_emission_f64 + smm_logz_f64).  Value only: the backward kernels are
+        not built yet, so no gradient flows through it."""
+        self._require_device(features, 'log_partition')
+        b, tmax, d = features.shape
+        dev = features.device
+        lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
+        assert int(lengths_host.max()) == tmax
+        with torch.no_grad():
+            tab = self.factor_tables(valid_classes, dev)
+            c = tab['init'].numel()
+            batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
+            x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
+            cons = None
+            if constraints is not None:
+                cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
+            elp64, _ = ops.emission(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
+                                    tab['inv_var'], cons=cons)
+            endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+            return ops.logz(batch, elp64, tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
+                            tab['len'].unsqueeze(0).contiguous(), endpen=endpen)
+
     def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None):
-        raise NotImplementedError("log-partition kernels (smm_logz_f64) are not built yet")
+        """(mean log-likelihood, mean log_det) like the reference (:597-658).
+
+        spans given: joint score p(x, y) (differentiable), or with --sm_train_discriminatively the conditional
+        score - log Z.  spans=None: the log-partition (marginal likelihood), computed by the HIP forward kernel.
+        """
+        if not add_eos:
+            raise NotImplementedError("the HIP path works with the EOS augmentation only (add_eos=True)")
+        valid_classes = self._check_valid_classes(valid_classes_per_instance)
+        self.set_z(features, lengths, use_mean=use_mean_z)
+        log_det = torch.zeros(features.size(0), device=features.device)
+        if spans is not None:
+            ll = self.gold_score(features, lengths, valid_classes, spans, additional_allowed_ends_per_instance, constraints)
+            if getattr(self.args, 'sm_train_discriminatively', False):
+                ll = ll - self.log_partition(features, lengths, valid_classes, additional_allowed_ends_per_instance,
+                                             constraints)
+        else:
+            ll = self.log_partition(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints)
+        return ll.mean(), log_det.mean()

@@ -89,3 +89,24 @@ def test_viterbi_decode_alias_and_larger_random_batch():
     fs, fv = F.viterbi(elp.numpy(), lengths.numpy(), trans.numpy(), init.numpy(), lens.numpy())
     table = np.array(valid.tolist() + [n_classes, -1])
     assert_spans_equivalent(spans.numpy(), table[fs], lengths, n_classes)
+
+
+@pytest.mark.parametrize('case', EOS_CASES)
+def test_log_likelihood_matches_reference_path(golden, case):
+    """log Z (HIP forward) and the gold-span joint score against the dense reference path (fp64)."""
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    b = feats.shape[0]
+    vc = None if valid is None else [valid for _ in range(b)]
+    kw = dict(additional_allowed_ends_per_instance=cfg.get('additional'),
+              constraints=None if cons is None else cons.float().to(dev))
+    ll, log_det = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=None, **kw)
+    ref = float(golden[case + '/f64/ref_mean_logz'])
+    assert abs(ll.item() - ref) <= 1e-6 * abs(ref) + 1e-4 and log_det.item() == 0.0
+    # gold-span score: score the Viterbi path -> must equal the Viterbi value, and be <= log Z
+    r = O.viterbi_full(p, feats, lengths, valid, True, cfg.get('additional'), cons)
+    gold = r['spans'][:, :feats.shape[1]].clone()
+    js, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=gold.to(dev), **kw)
+    np.testing.assert_allclose(js.item(), r['v'].mean().item(), rtol=1e-9, atol=1e-6)
+    assert js.item() <= ll.item() + 1e-6

@@ -196,3 +196,24 @@ def test_emission_matches_oracle(cfg):
     for i, t in enumerate(lengths):
         np.testing.assert_allclose(e64[i, :t], ref[i, :t], rtol=1e-12, atol=1e-9)
         np.testing.assert_allclose(e32[i, :t], ref[i, :t], rtol=2e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64),
+                                   (3, 200, 7, 65), (2, 300, 17, 130), (2, 600, 14, 300), (1, 1300, 12, 1024),
+                                   (2, 150, 32, 40), (2, 64, 4, 2)])
+@pytest.mark.parametrize('ends', [False, True])
+def test_log_partition_matches_oracle(shape, ends):
+    """LogSemiring forward kernel vs the fp64 CPU twin; tolerance of the path is 1e-4 relative."""
+    ops = _ops()
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 1000 + 7, b, tmax, c, k, ends=ends)
+    dev = torch.device('cuda:0')
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    z = ops.logz(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]),
+                 t(p['endpen']))
+    torch.cuda.synchronize()
+    ref = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'])
+    np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=1e-6, atol=1e-4)
+    _, v = run_oracle(p)
+    assert (z.cpu().numpy() >= v - 1e-6).all()

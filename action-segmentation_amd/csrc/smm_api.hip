@@ -46,7 +46,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct SmmPlan {
     size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err
     size_t o_order, o_nstates, o_err;
-    size_t hist_doubles;   // sum over videos of 3*c_max*(T+1): cumE, h (state-major), gamma (frame-major)
+    size_t hist_doubles;   // sum over videos of 8*c_max*(T+1): forward cumE/h/gamma, backward cumE/h/gamma, 2 transposes
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
     size_t total;
@@ -65,7 +65,7 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
     p.meta_bytes = p.o_err + 512;   // error word + diagnostic counters
     size_t h = 0;
-    for (int i = 0; i < s->b; ++i) h += 3 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
+    for (int i = 0; i < s->b; ++i) h += 8 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;
     p.elp_doubles = (size_t)s->total_frames * s->c_max;
     p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
@@ -127,7 +127,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         hv[i].T = (int32_t)t;
         hv[i].group = g;
         hv[i].kp = k;
-        hoff += 3 * (size_t)s->c_max * (size_t)(t + 1);
+        hoff += 8 * (size_t)s->c_max * (size_t)(t + 1);
         kp_max = std::max(kp_max, k);
     }
     std::iota(ho, ho + s->b, 0);
@@ -280,10 +280,38 @@ extern "C" int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host,
     return SMM_OK;
 }
 
-extern "C" int smm_logz_bwd_f64(const smm_shape *, const int64_t *, const int64_t *, const int32_t *, const int32_t *,
-                                const int32_t *, const double *, const double *, const double *, const double *,
-                                const double *, const double *, const double *, double *, double *, double *, double *,
-                                void *, size_t, void *)
+extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                                const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
+                                const double *elp, const double *trans, const double *init, const double *len_scores,
+                                const double *endpen, const double *logz, const double *grad_logz, double *g_elp,
+                                double *g_trans, double *g_init, double *g_len, void *workspace, size_t workspace_bytes,
+                                void *stream)
 {
-    return SMM_ERR_UNSUPPORTED;
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
+                   hs, &st);
+    if (rc != SMM_OK) return rc;
+    if (!elp || !trans || !init || !len_scores || !logz || !g_elp || !g_trans || !g_init || !g_len) return SMM_ERR_ARG;
+    const size_t g = shape->n_groups, cm = shape->c_max;
+    double *trans_t = st.tabs;                 // [g][cm][cm] transposed
+    double *logz_b = trans_t + g * cm * cm;    // [b] log Z as closed by the backward recursion (consistency value)
+    smm_launch_transpose(trans, trans_t, (int)g, (int)cm, hs);
+    SmmDpArgs a{};
+    a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
+    a.elp = elp; a.trans = trans_t; a.init = init; a.len = len_scores; a.endpen = endpen;
+    a.hist = st.hist; a.err = st.err;
+    a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
+    a.flags = 2;                               // time-reversed run -> backward messages in the second history half
+    rc = smm_launch_logz(a, logz_b, ring_regs(st.kp_max), st.c_need, hs);
+    if (rc != SMM_OK) return rc;
+    SMM_HIP(hipMemsetAsync(g_trans, 0, sizeof(double) * g * cm * cm, hs));
+    SMM_HIP(hipMemsetAsync(g_init, 0, sizeof(double) * g * cm, hs));
+    SMM_HIP(hipMemsetAsync(g_len, 0, sizeof(double) * g * shape->k_rows * cm, hs));
+    SMM_HIP(hipMemsetAsync(g_elp, 0, sizeof(double) * (size_t)shape->total_frames * cm, hs));
+    SmmBwdArgs m{st.videos, st.n_states, trans, len_scores, st.hist, logz, grad_logz, g_elp, g_trans, g_init, g_len,
+                 shape->c_max, shape->k_rows, shape->b};
+    smm_launch_marginals(m, shape->t_max, st.kp_max, hs);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
 }

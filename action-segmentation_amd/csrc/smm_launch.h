@@ -21,3 +21,20 @@ void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t strea
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
 // LogSemiring forward: logz[b]; same arguments as the Viterbi launch
 int smm_launch_logz(const SmmDpArgs &a, double *logz, int r, int c_need, hipStream_t stream);
+
+struct SmmBwdArgs {
+    const SmmVideo *videos;
+    const int32_t *n_states;
+    const double *trans;       // forward tables [g][c_max][c_max], [g][k_rows][c_max]
+    const double *len;
+    const double *hist;        // per video: F_cum, F_h, F_g, B_cum, B_h, B_g, (scratch) hT0, hT1; each [T+1][c_max]
+    const double *logz;        // [b]
+    const double *grad_logz;   // [b] or null (= 1)
+    double *g_elp;             // [total_frames][c_max]
+    double *g_trans;           // [g][c_max][c_max]
+    double *g_init;            // [g][c_max]
+    double *g_len;             // [g][k_rows][c_max]
+    int32_t c_max, k_rows, b;
+};
+void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStream_t stream);
+void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream);

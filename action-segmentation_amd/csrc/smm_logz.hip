@@ -73,7 +73,10 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     const double *len = a.len + (size_t)g * a.k_rows * cm;
     const double *elp = a.elp + (size_t)mv.frame_off * cm;
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
-    double *hcum = a.hist + mv.hist_off;                  // [T+1][cm]  cumE[n][c]
+    // bwd (a.flags bit 1): the same recursion on the time-reversed video with the transposed transition table gives
+    // the backward messages (see smm_logz_bwd.hip); its history goes to the second half of the video's block.
+    const bool bwd = (a.flags & 2) != 0;
+    double *hcum = a.hist + mv.hist_off + (bwd ? (size_t)3 * cm * (T + 1) : 0);   // [T+1][cm]  cumE[n][c]
     double *hh = hcum + (size_t)cm * (T + 1);             // [T+1][cm]  h[n][c]   (log-weight of "a span of c starts at n" - cumE)
     double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c] (log-weight of "a span of c ends at n")
 
@@ -86,16 +89,31 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     if (T <= 0) return;
     if (threadIdx.x < SMM_MAX_STATES_DEV) {
         const int c = threadIdx.x;
-        sh_h[0][c] = (c < C) ? init[c] : 0.0;
+        // start weights: forward = init; backward = weight of "the video ends after a span of c":
+        // LSE(endpen[c], LSE_to(trans[to][c]) - 1e9)  (a.trans is the transposed table in that mode: row c)
+        double h0 = 0.0;
+        if (c < C) {
+            if (!bwd) {
+                h0 = init[c];
+            } else {
+                double alt = SMM_NEG_INF;
+                for (int t2 = 0; t2 < C; ++t2) alt = smm_lse2(alt, trans[(size_t)c * cm + t2]);
+                h0 = smm_lse2(endpen ? endpen[c] : 0.0, alt + SMM_BIG_NEG);
+            }
+        }
+        sh_h[0][c] = h0;
         sh_h[1][c] = 0.0;
         sh_am[0][c] = SMM_NEG_INF; sh_am[1][c] = SMM_NEG_INF;
         sh_as[0][c] = 0.f; sh_as[1][c] = 0.f;
         sh_gam[c] = SMM_NEG_INF;
-        if (c < C) { hcum[c] = 0.0; hh[c] = init[c]; }
+        if (c < C) { hcum[c] = 0.0; hh[c] = h0; }
     }
     {
-        const int nel = ((T < 64) ? T : 64) * cm;
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) sh_elp[0][i] = elp[i];
+        const int nfr = (T < 64) ? T : 64;
+        for (int i = threadIdx.x; i < nfr * cm; i += blockDim.x) {
+            const int j = i / cm, c = i - j * cm;
+            sh_elp[0][i] = elp[(size_t)(bwd ? T - 1 - j : j) * cm + c];
+        }
     }
     __syncthreads();
 
@@ -112,7 +130,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
         }
         const double len1 = (live && kp >= 2) ? len[(size_t)cm + to] : SMM_NEG_INF;
         double cum = 0.0;
-        double hcur = live ? init[to] : SMM_NEG_INF;
+        double hcur = live ? sh_h[0][to] : SMM_NEG_INF;
         double enext = live ? sh_elp[0][to] : 0.0;
         for (int n = 0; n < T; ++n) {
             const double ecurv = enext;
@@ -159,11 +177,15 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
         }
         // last position: LSE over fin[to], to = 0..C  (sh_gam holds gamma[T][.])
         double f = SMM_NEG_INF;
-        if (lane <= C) {
-            for (int c = 0; c < C; ++c) {
-                const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c] + SMM_BIG_NEG;
-                f = smm_lse2(f, sh_gam[c] + wgt);
+        if (!bwd) {
+            if (lane <= C) {
+                for (int c = 0; c < C; ++c) {
+                    const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c] + SMM_BIG_NEG;
+                    f = smm_lse2(f, sh_gam[c] + wgt);
+                }
             }
+        } else if (lane < C) {
+            f = sh_gam[lane] + init[lane];               // closes the recursion: must reproduce log Z
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) f = smm_lse2(f, __shfl_xor(f, off));
@@ -208,7 +230,10 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
                         for (int q = 0; q < QMAX; ++q) {
                             const int e = pidx + q * NP * 64;
-                            if (e < nel) pre[q] = elp[(size_t)nbase * cm + e];
+                            if (e < nel) {
+                                const int j = e / cm, c = e - j * cm;
+                                pre[q] = elp[(size_t)(bwd ? T - 1 - (nbase + j) : nbase + j) * cm + c];
+                            }
                         }
                     } else {
 #pragma unroll

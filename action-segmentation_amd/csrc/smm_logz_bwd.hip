@@ -1,0 +1,142 @@
+// smm_logz_bwd.hip -- gradient of the log-partition (posterior marginals) of the factored semi-Markov model.
+//
+// Replaces the autograd backward through torch_struct's LogSemiring DP and log_hsmm (reference
+// src/models/semimarkov/semimarkov.py:286 `loss.backward()` through semimarkov_modules.py:416-523, 657).
+// CPU statement: oracle/smm_oracle.c: smm_oracle_logz (want_grad branch).
+//
+// Inputs are the two histories left in the workspace:
+//   forward  (smm_logz_kernel)            F_cum[n][c] = cumE,  F_h[s][c] = start[s][c] - cumE[s][c],  F_g[n][c] = gamma
+//   backward (same kernel, time reversed,  B_cum[j][c] = cumE' (reversed prefix), B_h[j][c] = bend[T-j][c] - cumE'[j][c],
+//             transposed transitions)      B_g[j][c]  = bstart[T-j][c]
+// With them every marginal is local:
+//   P(a span of c starts at s) = exp(F_h[s][c] + F_cum[s][c] + B_g[T-s][c] - logZ)
+//   P(a span of c ends at n)   = exp(F_g[n][c] + B_h[T-n][c] + B_cum[T-n][c] - logZ)
+//   d logZ / d elp[t][c]       = #spans of c covering t = sum_{s<=t} Pstart - sum_{n<=t} Pend          O(T C)
+//   d logZ / d trans[to][from] = sum_n exp(F_g[n][from] + trans[to][from] + B_g[T-n][to] - logZ)         O(T C^2)
+//   d logZ / d init[c]         = Pstart(0, c)
+//   d logZ / d len[k][c]       = sum_s exp(F_h[s][c] + len[k][c] + B_h[T-s-k][c] + cumE[T][c] - logZ)    O(T K C)
+// Only the last one is K-proportional; it has no serial dependence at all: lane = k (length scores and
+// accumulators in registers), loop over s with one coalesced sliding-window load per cell, no reduction.
+#include "smm_device.h"
+#include "smm_launch.h"
+#include "../../include/smmdp.h"
+
+#define SMM_LOG2E_F 1.4426950408889634f
+
+__device__ __forceinline__ double smm_expd(double x)     // exp of a non-positive (up to rounding) log-probability
+{
+    return (double)__builtin_amdgcn_exp2f((float)x * SMM_LOG2E_F);
+}
+
+__global__ void smm_transpose2d_kernel(const double *src, double *dst, int g, int cm)
+{
+    const int n = g * cm * cm;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int gi = i / (cm * cm), r = (i / cm) % cm, c = i % cm;
+        dst[(size_t)gi * cm * cm + (size_t)c * cm + r] = src[i];
+    }
+}
+
+__global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
+{
+    const int vid = blockIdx.x;
+    const SmmVideo mv = a.videos[vid];
+    const int T = mv.T, g = mv.group, cm = a.c_max;
+    const int C = a.n_states[g];
+    const size_t blk = (size_t)cm * (T + 1);
+    const double *F_cum = a.hist + mv.hist_off, *F_h = F_cum + blk, *F_g = F_h + blk;
+    const double *B_cum = F_g + blk, *B_h = B_cum + blk, *B_g = B_h + blk;
+    double *hT0 = const_cast<double *>(B_g + blk), *hT1 = hT0 + blk;          // state-major copies for the length pass
+    const double lz = a.logz[vid];
+    const double up = a.grad_logz ? a.grad_logz[vid] : 1.0;
+    const double *trans = a.trans + (size_t)g * cm * cm;
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    // (a) state-major copies: hT0[c][s] = F_h[s][c], hT1[c][j] = B_h[j][c]
+    for (size_t i = tid; i < blk; i += nth) {
+        const int n = (int)(i / cm), c = (int)(i - (size_t)n * cm);
+        hT0[(size_t)c * (T + 1) + n] = F_h[i];
+        hT1[(size_t)c * (T + 1) + n] = B_h[i];
+    }
+
+    // (b) d/d elp: running (#starts - #ends) per state; threads = (state, chunk of frames), two passes
+    __shared__ double part[32][33];
+    const int c = tid & 31, j = tid >> 5, nj = nth >> 5;
+    const int cs = (T + nj - 1) / nj;
+    const int t0 = j * cs, t1 = (t0 + cs < T) ? t0 + cs : T;
+    auto delta = [&](int t) -> double {      // O(T C) terms: full fp64 exp
+        const double ps = exp(F_h[(size_t)t * cm + c] + F_cum[(size_t)t * cm + c] + B_g[(size_t)(T - t) * cm + c] - lz);
+        if (t == 0) return ps;
+        return ps - exp(F_g[(size_t)t * cm + c] + B_h[(size_t)(T - t) * cm + c] + B_cum[(size_t)(T - t) * cm + c] - lz);
+    };
+    double sum = 0.0;
+    if (c < C)
+        for (int t = t0; t < t1; ++t) sum += delta(t);
+    if (j < 32) part[c][j] = sum;
+    __syncthreads();
+    if (c < C) {
+        double run = 0.0;
+        for (int q = 0; q < j && q < 32; ++q) run += part[c][q];
+        for (int t = t0; t < t1; ++t) {
+            run += delta(t);
+            a.g_elp[(size_t)(mv.frame_off + t) * cm + c] = up * run;
+        }
+    }
+    // (c) d/d init
+    if (tid < C)
+        atomicAdd(&a.g_init[(size_t)g * cm + tid],
+                  up * exp(F_h[tid] + F_cum[tid] + B_g[(size_t)T * cm + tid] - lz));
+    // (d) d/d trans: threads = (pair, slice of n)
+    const int P = C * C;
+    const int ng = nth / P;
+    if (ng >= 1 && tid < ng * P) {
+        const int pair = tid % P, sl = tid / P;
+        const int to = pair / C, from = pair - to * C;
+        const double tw = trans[(size_t)to * cm + from] - lz;
+        double acc = 0.0;
+        for (int n = 1 + sl; n < T; n += ng)
+            acc += smm_expd(F_g[(size_t)n * cm + from] + tw + B_g[(size_t)(T - n) * cm + to]);
+        atomicAdd(&a.g_trans[(size_t)g * cm * cm + (size_t)to * cm + from], up * acc);
+    }
+}
+
+// d/d len[k][c]: grid (k tiles of 256, s tiles of SCH, b * c_max); lane = k
+#define SMM_GLEN_SCH 2048
+__global__ void __launch_bounds__(256) smm_glen_kernel(SmmBwdArgs a)
+{
+    const int cm = a.c_max;
+    const int vid = blockIdx.z / cm, c = blockIdx.z - vid * cm;
+    const SmmVideo mv = a.videos[vid];
+    const int T = mv.T, g = mv.group;
+    if (c >= a.n_states[g]) return;
+    const int k = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int s0 = blockIdx.y * SMM_GLEN_SCH;
+    if (s0 >= T) return;
+    const int kmax = (mv.kp - 1 < T) ? mv.kp - 1 : T;
+    const size_t blk = (size_t)cm * (T + 1);
+    const double *F_cum = a.hist + mv.hist_off;
+    const double *hT0 = F_cum + 6 * blk + (size_t)c * (T + 1);      // F_h[s][c] over s
+    const double *hT1 = hT0 + blk;                                  // B_h[j][c] over j
+    const double base = F_cum[(size_t)T * cm + c] - a.logz[vid];    // cumE[T][c] - logZ
+    if (k > kmax) return;
+    const double lk = a.len[((size_t)g * a.k_rows + k) * cm + c] + base;
+    const int s1 = (s0 + SMM_GLEN_SCH < T - k + 1) ? s0 + SMM_GLEN_SCH : T - k + 1;   // s + k <= T
+    double acc = 0.0;
+    for (int s = s0; s < s1; ++s) acc += smm_expd(hT0[s] + lk + hT1[T - s - k]);
+    if (acc != 0.0) {
+        const double up = a.grad_logz ? a.grad_logz[vid] : 1.0;
+        atomicAdd(&a.g_len[((size_t)g * a.k_rows + k) * cm + c], up * acc);
+    }
+}
+
+void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smm_transpose2d_kernel, dim3(8), dim3(256), 0, stream, src, dst, g, cm);
+}
+
+void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smm_marginals_kernel, dim3(a.b), dim3(1024), 0, stream, a);
+    dim3 grid((kp_max - 1 + 255) / 256, (t_max + SMM_GLEN_SCH - 1) / SMM_GLEN_SCH, a.b * a.c_max);
+    if (kp_max >= 2) hipLaunchKernelGGL(smm_glen_kernel, grid, dim3(256), 0, stream, a);
+}

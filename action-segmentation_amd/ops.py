@@ -161,3 +161,23 @@ def logz(batch, elp, trans, init, len_scores, endpen=None):
         _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'), _dev(out, f64, 'logz'),
         ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     return out
+
+
+def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endpen=None):
+    """Gradient of sum_i grad_logz[i] * logZ_i (smm_logz_bwd_f64).  Must follow ``logz`` for the same batch with the
+    same workspace (same device + stream).  -> dict(elp [total_frames, c_max], trans, init, len) fp64."""
+    lib = _lib.load()
+    dev = elp.device
+    f64 = torch.float64
+    g = dict(elp=torch.empty_like(elp), trans=torch.empty_like(trans), init=torch.empty_like(init),
+             len=torch.empty_like(len_scores))
+    ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, kp, ns = batch.host_ptrs()
+    _lib.check(lib.smm_logz_bwd_f64(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.c_void_p(ns), _dev(elp, f64, 'elp'), _dev(trans, f64, 'trans'), _dev(init, f64, 'init'),
+        _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'), _dev(logz_val, f64, 'logz'),
+        _dev(grad_logz, f64, 'grad_logz'), _dev(g['elp'], f64, 'g_elp'), _dev(g['trans'], f64, 'g_trans'),
+        _dev(g['init'], f64, 'g_init'), _dev(g['len'], f64, 'g_len'),
+        ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return g

@@ -132,7 +132,7 @@ int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_host, const in
 /*
  * Log-partition (LogSemiring forward) and its backward.
  *   logz   dev fp64 [b]
- *   bwd:   grad_logz dev fp64 [b] (upstream), outputs g_elp dev fp64 [total_frames][c_max],
+ *   bwd:   grad_logz dev fp64 [b] (upstream, NULL = ones), outputs g_elp dev fp64 [total_frames][c_max],
  *          g_trans dev fp64 [n_groups][c_max][c_max], g_init [n_groups][c_max], g_len [n_groups][k_rows][c_max]
  *          (all overwritten).  The workspace written by smm_logz_f64 must be passed unchanged to smm_logz_bwd_f64.
  */

@@ -217,3 +217,31 @@ def test_log_partition_matches_oracle(shape, ends):
     np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=1e-6, atol=1e-4)
     _, v = run_oracle(p)
     assert (z.cpu().numpy() >= v - 1e-6).all()
+
+
+@pytest.mark.parametrize('shape', [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64),
+                                   (3, 200, 7, 65), (2, 300, 17, 130), (2, 150, 32, 40), (1, 700, 12, 520)])
+@pytest.mark.parametrize('ends', [False, True])
+def test_log_partition_gradients_match_oracle(shape, ends):
+    """Posterior marginals (d logZ / d elp, trans, init, len) vs the exact fp64 forward-backward of the CPU twin."""
+    ops = _ops()
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 1000 + 11, b, tmax, c, k, ends=ends, scale=1.5)
+    dev = torch.device('cuda:0')
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    args = (t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    up = np.linspace(0.5, 1.5, b)
+    z = ops.logz(batch, *args, endpen=t(p['endpen']))
+    g = ops.logz_bwd(batch, *args, z, grad_logz=t(up), endpen=t(p['endpen']))
+    torch.cuda.synchronize()
+    ref_z, ref = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'], grad=True, upstream=up)
+    ge = g['elp'].cpu().numpy().reshape(b, tmax, c)
+    for i, ti in enumerate(p['lengths']):
+        np.testing.assert_allclose(ge[i, :ti], ref['elp'][i, :ti], rtol=2e-5, atol=2e-5)
+        assert np.all(ge[i, ti:] == 0)
+        np.testing.assert_allclose(ge[i, :ti].sum(1), up[i], rtol=1e-4)   # exactly one state per frame
+    kp = min(k, tmax)
+    np.testing.assert_allclose(g['trans'].cpu().numpy()[0], ref['trans'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g['init'].cpu().numpy()[0], ref['init'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g['len'].cpu().numpy()[0, :kp], ref['len'], rtol=2e-5, atol=2e-5)

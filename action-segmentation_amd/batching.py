@@ -53,7 +53,10 @@ def padding_colate(samples):
     batch['lengths'] = torch.LongTensor([s['features'].size(0) for s in samples])
     for k in PAD_KEYS:
         if k in keys:
-            batch[k] = torch.nn.utils.rnn.pad_sequence([s[k] for s in samples], batch_first=True, padding_value=0)
+            seqs = [s[k] for s in samples]
+            if k == 'constraints' and len({tuple(q.shape[1:]) for q in seqs}) > 1:
+                continue          # mixed-task batch: per-task step counts differ, narration constraints do not apply
+            batch[k] = torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True, padding_value=0)
     return batch
 
 

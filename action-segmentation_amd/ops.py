@@ -147,13 +147,15 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
     return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32)
 
 
-def logz(batch, elp, trans, init, len_scores, endpen=None):
-    """Log-partition per video (smm_logz_f64).  elp fp64 [total_frames, c_max] -> logZ fp64 [b]."""
+def logz(batch, elp, trans, init, len_scores, endpen=None, ws=None):
+    """Log-partition per video (smm_logz_f64).  elp fp64 [total_frames, c_max] -> logZ fp64 [b].
+    ``ws``: a private uint8 workspace tensor (keep it for ``logz_bwd``); default: the shared per-stream one."""
     lib = _lib.load()
     dev = elp.device
     f64 = torch.float64
     out = torch.empty(batch.b, dtype=f64, device=dev)
-    ws = workspace(batch.workspace_bytes(), dev)
+    if ws is None:
+        ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(lib.smm_logz_f64(
         ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
@@ -163,7 +165,7 @@ def logz(batch, elp, trans, init, len_scores, endpen=None):
     return out
 
 
-def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endpen=None):
+def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endpen=None, ws=None):
     """Gradient of sum_i grad_logz[i] * logZ_i (smm_logz_bwd_f64).  Must follow ``logz`` for the same batch with the
     same workspace (same device + stream).  -> dict(elp [total_frames, c_max], trans, init, len) fp64."""
     lib = _lib.load()
@@ -171,7 +173,8 @@ def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endp
     f64 = torch.float64
     g = dict(elp=torch.empty_like(elp), trans=torch.empty_like(trans), init=torch.empty_like(init),
              len=torch.empty_like(len_scores))
-    ws = workspace(batch.workspace_bytes(), dev)
+    if ws is None:
+        ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(lib.smm_logz_bwd_f64(
         ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),

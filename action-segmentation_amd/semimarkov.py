@@ -84,13 +84,71 @@ class SemiMarkovModel(object):
         self.model.fit_supervised(features, labels)
 
     def fit(self, train_data, use_labels, callback_fn=None):
+        """reference semimarkov.py:159-316: closed form for supervised data, otherwise Adam on -log-likelihood
+        (marginal likelihood log Z for unlabelled data; joint or conditional span score for labelled data)."""
+        import time
+        args = self.args
         self.model.train()
         if use_labels:
-            assert not self.args.sm_constrain_transitions
-        if use_labels and self.args.sm_supervised_method == 'closed-form':
-            self.fit_supervised(train_data)   # closed form: no epochs, callback never called (reference :165-171)
-            return
-        raise NotImplementedError("gradient training needs the log-partition kernels (smm_logz_f64): not built yet")
+            assert not args.sm_constrain_transitions
+        initialize = True
+        if use_labels and args.sm_supervised_method in ('closed-form', 'closed-then-gradient'):
+            self.fit_supervised(train_data)
+            if args.sm_supervised_method == 'closed-then-gradient':
+                initialize = False
+                if callback_fn:
+                    callback_fn(-1, {})
+            else:
+                return   # closed form: no epochs, callback never called (reference :165-171)
+        optimizer, scheduler = make_optimizer(args, [p for p in self.model.parameters() if p.requires_grad])
+        if initialize:
+            big = next(iter(make_data_loader(args, train_data, batch_by_task=False, shuffle=True, batch_size=100)))
+            self.model.initialize_gaussian(big['features'].to(self.device), big['lengths'])
+        loader = make_data_loader(args, train_data, batch_by_task=True, shuffle=True, batch_size=args.batch_size)
+        k = args.sm_max_span_length
+        for epoch in range(args.epochs):
+            start_time = time.time()
+            self.model.train()
+            losses, pending = [], []
+            train_nll = num_frames = num_videos = 0
+            for batch_ix, batch in enumerate(loader):
+                if args.train_limit and batch_ix >= args.train_limit:
+                    break
+                tasks, lengths = batch['task_name'], batch['lengths']
+                cons = None
+                if 'train' in args.sm_constrain_with_narration:
+                    assert all_equal(tasks)
+                    cons = self.expand_constraints(train_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
+                    cons = cons * args.sm_constrain_narration_weight
+                num_frames += int(lengths.sum())
+                num_videos += len(lengths)
+                features = batch['features'].to(self.device)
+                spans = semimarkov_utils.labels_to_spans(batch['gt_single'], max_k=k) if use_labels else None
+                addl = self.make_additional_allowed_ends(tasks, lengths)
+                ll, log_det = self.model.log_likelihood(features, lengths, valid_classes_per_instance=batch['task_indices'],
+                                                        spans=spans, add_eos=True, use_mean_z=use_labels,
+                                                        additional_allowed_ends_per_instance=addl, constraints=cons)
+                loss = -ll - log_det
+                pending.append(loss)
+                losses.append(loss.item())
+                train_nll += -ll.item() * len(lengths)
+                if len(pending) >= args.batch_accumulation:
+                    (sum(pending) / len(pending)).backward()
+                    pending = []
+                    if args.print_every and batch_ix % args.print_every == 0:
+                        print('Epoch: %02d, Batch: %03d/%03d, loss: %.4f, recon: %.4f, Throughput: %.2f vid / sec' % (
+                            epoch, batch_ix, len(loader), train_nll / num_videos, train_nll / num_frames,
+                            num_videos / (time.time() - start_time)))
+                    if args.max_grad_norm is not None:
+                        torch.nn.utils.clip_grad_norm_(self.model.parameters(), args.max_grad_norm)
+                    optimizer.step()
+                    self.model.zero_grad()
+            train_loss = float(np.mean(losses))
+            if scheduler is not None:
+                scheduler.step(train_loss)
+            if callback_fn:
+                callback_fn(epoch, {'train_loss': train_loss, 'train_nll_frame_avg': train_nll / max(num_frames, 1),
+                                    'train_kl_vid_avg': 0.0, 'train_recon_bound': train_nll / max(num_frames, 1)})
 
     # ------------------------------------------------------------------ constraints (reference :135-157)
     def make_additional_allowed_ends(self, tasks, lengths):

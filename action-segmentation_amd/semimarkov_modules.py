@@ -41,6 +41,33 @@ def sliding_sum(inputs, k):
     return out
 
 
+class _LogPartition(torch.autograd.Function):
+    """log Z of one batch as a differentiable function of the fp64 factor tables (emission factors w, cst; transition,
+    initial and length tables).  Forward: smm_emission_f64 + smm_logz_f64; backward: smm_logz_bwd_f64 (posterior
+    marginals) + the chain rule through elp = cst + x.w - 0.5 x^2.inv_var as two small torch GEMMs."""
+
+    @staticmethod
+    def forward(ctx, batch, x, cons, endpen, w, cst, inv_var, trans, init, len_scores):
+        ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=x.device)   # private: survives until backward
+        elp64, _ = ops.emission(batch, x, w, cst, inv_var, cons=cons)
+        z = ops.logz(batch, elp64, trans, init, len_scores, endpen=endpen, ws=ws)
+        ctx.batch, ctx.endpen, ctx.ws = batch, endpen, ws
+        ctx.save_for_backward(x, elp64, trans, init, len_scores, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, elp64, trans, init, len_scores, z = ctx.saved_tensors
+        g = ops.logz_bwd(ctx.batch, elp64, trans, init, len_scores, z, grad_logz=gz.to(torch.float64).contiguous(),
+                         endpen=ctx.endpen, ws=ctx.ws)
+        ge = g['elp']                                   # [frames, C]: posterior state occupancy x upstream
+        xd = x.to(torch.float64)
+        g_w = (xd.t() @ ge).unsqueeze(0)                # [1, D, C]
+        g_cst = ge.sum(0, keepdim=True)                 # [1, C]
+        g_iv = -0.5 * ((xd * xd) * ge.sum(1, keepdim=True)).sum(0)
+        return None, None, None, None, g_w, g_cst, g_iv, g['trans'], g['init'], g['len']
+
+
 class SemiMarkovModule(nn.Module):
     @classmethod
     def add_args(cls, parser):
@@ -487,33 +514,33 @@ class SemiMarkovModule(nn.Module):
 
     def log_partition(self, features, lengths, valid_classes, additional_allowed_ends_per_instance=None,
                       constraints=None):
-        """log Z per instance on the device (smm_emission_f64 + smm_logz_f64).  Value only: the backward kernels are
-        not built yet, so no gradient flows through it."""
+        """log Z per instance on the device, differentiable w.r.t. the module's parameters
+        (smm_emission_f64 + smm_logz_f64 forward, smm_logz_bwd_f64 backward)."""
         self._require_device(features, 'log_partition')
         b, tmax, d = features.shape
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
         assert int(lengths_host.max()) == tmax
-        with torch.no_grad():
-            tab = self.factor_tables(valid_classes, dev)
-            c = tab['init'].numel()
-            batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
-            x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
-            cons = None
-            if constraints is not None:
-                cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
-            elp64, _ = ops.emission(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
-                                    tab['inv_var'], cons=cons)
-            endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
-            return ops.logz(batch, elp64, tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
-                            tab['len'].unsqueeze(0).contiguous(), endpen=endpen)
+        tab = self.factor_tables(valid_classes, dev)
+        c = tab['init'].numel()
+        batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
+        x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
+        cons = None
+        if constraints is not None:
+            cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
+        endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+        return _LogPartition.apply(batch, x, cons, endpen, tab['w'].unsqueeze(0).contiguous(),
+                                   tab['cst'].unsqueeze(0).contiguous(), tab['inv_var'].contiguous(),
+                                   tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
+                                   tab['len'].unsqueeze(0).contiguous())
 
     def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None):
         """(mean log-likelihood, mean log_det) like the reference (:597-658).
 
         spans given: joint score p(x, y) (differentiable), or with --sm_train_discriminatively the conditional
-        score - log Z.  spans=None: the log-partition (marginal likelihood), computed by the HIP forward kernel.
+        score - log Z.  spans=None: the log-partition (marginal likelihood) from the HIP forward kernel; its gradient
+        (posterior marginals chained into the parameters) comes from the HIP backward kernels.
         """
         if not add_eos:
             raise NotImplementedError("the HIP path works with the EOS augmentation only (add_eos=True)")

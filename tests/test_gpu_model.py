@@ -57,3 +57,16 @@ def test_predict_matches_reference_path(constrain, narration):
         np.testing.assert_array_equal(unfused[name], ref[name], err_msg=name)
     acc = np.mean([np.mean(fused[n] == data._videos[(t, n)]['gt_single'].numpy()) for (t, n) in data._videos])
     assert acc > 0.5                                          # it also segments the synthetic videos sensibly
+
+
+def test_unsupervised_fit_improves_marginal_likelihood():
+    """A few epochs of the reference's unsupervised objective (-log Z, Adam) through the HIP forward/backward kernels."""
+    data = synth.SynthDatasplit('tiny', seed=9)
+    args = synth.make_args(data.max_k, cuda=True, batch_size=2, epochs=6, lr=5e-2, print_every=0)
+    model = SemiMarkovModel.from_args(args, data)
+    log = []
+    model.fit(data, use_labels=False, callback_fn=lambda ep, st: log.append(st['train_loss']))
+    assert len(log) == 6 and all(np.isfinite(log))
+    assert log[-1] < log[0] - 1.0, log
+    preds = model.predict(data)
+    assert set(preds) == {n for (_, n) in data._videos}

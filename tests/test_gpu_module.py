@@ -110,3 +110,33 @@ def test_log_likelihood_matches_reference_path(golden, case):
     js, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=gold.to(dev), **kw)
     np.testing.assert_allclose(js.item(), r['v'].mean().item(), rtol=1e-9, atol=1e-6)
     assert js.item() <= ll.item() + 1e-6
+
+
+@pytest.mark.parametrize('case', ['tiny', 'subset_merge', 'constrained'])
+def test_log_likelihood_gradients_match_dense_autograd(golden, case):
+    """d mean(logZ) / d parameters through the HIP forward/backward kernels vs autograd through the dense reference
+    path (fp64 log_hsmm potentials + LogSemiring DP)."""
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    b = feats.shape[0]
+    vc = None if valid is None else [valid for _ in range(b)]
+    m.zero_grad()
+    ll, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=None,
+                             additional_allowed_ends_per_instance=cfg.get('additional'),
+                             constraints=None if cons is None else cons.float().to(dev))
+    ll.backward()
+    # dense reference in fp64 with autograd on CPU
+    names = ['poisson_log_rates', 'gaussian_means', 'transition_logits', 'init_logits']
+    q = p.to(torch.float64)
+    leaves = {n: getattr(q, n).clone().requires_grad_(True) for n in names}
+    for n, v in leaves.items():
+        setattr(q, n, v)
+    scores, _ = O.score_features(q, feats, lengths, valid, True, cfg.get('additional'), cons)
+    z, _ = O.semimarkov_dp(scores, lengths + 1, O.LogSemiring)
+    z.mean().backward()
+    assert abs(ll.item() - z.mean().item()) <= 1e-6 * abs(z.mean().item()) + 1e-4
+    for n in names:
+        got = getattr(m, n).grad.detach().cpu().double().numpy()
+        ref = leaves[n].grad.numpy()
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()), err_msg=n)

@@ -42,19 +42,34 @@ def parse():
 
 
 def dist_setup(n):
+    """One process per GPU (torchrun env).  Collectives run over RCCL (backend "nccl" on ROCm); if RCCL cannot come up
+    on this box the tiny metric reductions fall back to gloo on host tensors rather than losing the measurement."""
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    backend = None
     if n > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        try:
+            dist.init_process_group('nccl', rank=rank, world_size=world)
+            probe = torch.ones(1, device='cuda')
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world
+            backend = 'nccl'
+        except Exception as e:                                    # pragma: no cover (needs a broken RCCL setup)
+            sys.stderr.write('bench.py: RCCL unavailable (%s); metric reductions fall back to gloo\n' % e)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            backend = 'gloo'
     else:
         torch.cuda.set_device(0)
-    return rank, world, local
+    return rank, world, local, backend
 
 
 def cpu_baseline(data, model, pc):
@@ -118,8 +133,9 @@ def cpu_factored(pc, model, max_videos=8):
 
 def main():
     a = parse()
-    rank, world, local = dist_setup(a.gpus)
-    dev = torch.device('cuda', local if world > 1 else 0)
+    rank, world, local, backend = dist_setup(a.gpus)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    red_dev = dev if backend != 'gloo' else torch.device('cpu')
     from action_segmentation_amd import ops, synth
     from action_segmentation_amd.semimarkov import SemiMarkovModel
 
@@ -171,8 +187,8 @@ def main():
     lab = labels.numpy()
     correct = sum(int((lab[o:o + n] == data._videos[(tk, nm)]['gt_single'].numpy()).sum())
                   for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths))
-    counters = torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    counters = torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         torch.distributed.all_reduce(counters, op=torch.distributed.ReduceOp.SUM)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -202,7 +218,8 @@ def main():
                                    "task (mean %.1f), max span length %d, D=%d; closed-form-fitted HSMM parameters"
                        % (a.workload, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
                           max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg, cfg['max_k'] - 1, cfg['d']),
-                       "parallelism": "videos sharded across %d GPU(s), no data-path collective" % world},
+                       "parallelism": "videos sharded across %d GPU(s), no data-path collective; metric counters all-reduced over %s"
+                                      % (world, {None: "nothing (1 rank)", "nccl": "RCCL", "gloo": "gloo (RCCL unavailable)"}[backend])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "smm_viterbi_kernel", "kernel_ms": dp_ms,

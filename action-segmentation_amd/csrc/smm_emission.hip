@@ -7,98 +7,110 @@
 // (w = mu/sigma^2, cst = -0.5 sum mu^2/sigma^2 - sum log sigma - D/2 log 2pi; host-side, fp64), which is one
 // v_fma_f64 per (frame, d, state).  In fp64 the expansion costs nothing in accuracy (|terms| ~ 1e3, eps 1e-16).
 //
-// Mapping.  One lane per frame; every lane walks its own feature row with 16-B loads issued one load ahead
-// (HBM traffic: 4*D bytes per frame, each 64-B sector fetched once and finished from L1/L2).  w[d][.] is the same
-// for all lanes: it is fetched with scalar loads and used as the SGPR operand of the FMA, so the inner loop is
-// FMA-only.  No MFMA: D x C = 200 x 20 per frame in exact fp64 is below the fp64 VALU/HBM balance point.
+// Mapping: see the comment above smm_emission_kernel (fp64 MFMA tiles, weights in LDS, 64-B row pieces of x).
 #include "smm_launch.h"
 
-// Pointer arguments are passed one by one (not in a struct) with __restrict__: only then can hipcc prove that the
-// wave-uniform reads of w / cst / inv_var are not clobbered by the elp stores and turn them into scalar loads.
-template <int CT, int FPL>   // FPL frames per lane: the scalar weight row of a feature is reused FPL times
+// ---------------------------------------------------------------------------------------------------------------
+// elp = x . w is a [frames x D] x [D x C] product: it runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: a
+// 16-frame x 16-state tile per instruction, 4 features deep).  fp64 MFMA has the fp64 VALU's FLOP rate on gfx950, but
+// one instruction replaces 1024 FMAs, needs no scalar operand stream, and leaves the VALU free for the x^2 term.
+//   A operand (lane l): x[frame f0 + (l & 15)][feature]  -- each lane loads 16 B = 4 consecutive features of its frame,
+//       so a wave reads 16 rows x 64 contiguous bytes per macro-step of 16 features (whole 64-B sectors, once);
+//       the 4 features of a lane feed 4 MFMAs (k index = l >> 4), i.e. MFMA j of a macro-step contracts features
+//       {d0 + 4k + j}.  Any feature <-> (j, k) assignment is valid as long as B uses the same one.
+//   B operand (lane l): w[d0 + 4 (l >> 4) + j][s0 + (l & 15)]  from an LDS copy of the group's weight table.
+//   C/D (lane l, reg i): frame f0 + (l >> 4) + 4 i, state s0 + (l & 15)  -> 128-B contiguous row pieces on store.
+// One workgroup = 4 waves on one video; every wave walks 16-frame tiles with a grid stride.
+typedef double smm_d4 __attribute__((ext_vector_type(4)));
+
+template <int NT>   // state tiles of 16 (1: C <= 16, 2: C <= 32)
 __global__ void __launch_bounds__(256)
 smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
                     float *__restrict__ elp32, int D, int cm)
 {
+    extern __shared__ __attribute__((aligned(16))) double wl[];      // [D16][16*NT + 1]: this group's weights (zero padded) | inv_var
     const int vid = blockIdx.y;
     const SmmVideo mv = videos[vid];
-    const int wave0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) * FPL;   // first frame of this wave
-    if (wave0 >= mv.T) return;                                           // whole wave past the end
-    const int lane = threadIdx.x & 63;
-    int f[FPL];
-    bool livef[FPL];
-    const float4 *x4[FPL];
-#pragma unroll
-    for (int p = 0; p < FPL; ++p) {
-        f[p] = wave0 + p * 64 + lane;                                    // lane-consecutive frames: coalesced stores
-        livef[p] = f[p] < mv.T;
-        x4[p] = reinterpret_cast<const float4 *>(xall + (size_t)(mv.frame_off + (livef[p] ? f[p] : 0)) * D);
-    }
-    const int g = mv.group;
+    const int T = mv.T, g = mv.group;
     const int C = n_states[g];
-    // every lane walks its own feature rows with 16-B loads, one load ahead of the FMAs (rows are 4*D bytes apart, so a
-    // wave instruction touches 64 lines; the other 3/4 of each 64-B sector are used by the next three loads from L1/L2)
-    const double *__restrict__ w = wall + (size_t)g * D * cm;
-
-    double acc[FPL][CT], q[FPL];
-#pragma unroll
-    for (int p = 0; p < FPL; ++p) {
-        q[p] = 0.0;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[p][c] = 0.0;
-    }
-
-    if ((D & 3) == 0) {
-        float4 nxt[FPL];
-#pragma unroll
-        for (int p = 0; p < FPL; ++p) nxt[p] = x4[p][0];
-        for (int d = 0; d < D; d += 4) {
-            float xs[FPL][4];
-#pragma unroll
-            for (int p = 0; p < FPL; ++p) {
-                xs[p][0] = nxt[p].x; xs[p][1] = nxt[p].y; xs[p][2] = nxt[p].z; xs[p][3] = nxt[p].w;
-                if (d + 4 < D) nxt[p] = x4[p][(d >> 2) + 1];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double *__restrict__ wr = w + (size_t)(d + k) * cm;   // wave-uniform -> scalar loads
-                const double ivd = iv[d + k];
-#pragma unroll
-                for (int p = 0; p < FPL; ++p) {
-                    const double xv = (double)xs[p][k];
-                    q[p] = fma(xv * ivd, xv, q[p]);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) acc[p][c] = fma(xv, wr[c], acc[p][c]);
-                }
-            }
-        }
-    } else {
-        for (int d = 0; d < D; ++d) {
-            const double *__restrict__ wr = w + (size_t)d * cm;
-            const double ivd = iv[d];
-#pragma unroll
-            for (int p = 0; p < FPL; ++p) {
-                const double xv = (double)reinterpret_cast<const float *>(x4[p])[d];
-                q[p] = fma(xv * ivd, xv, q[p]);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) acc[p][c] = fma(xv, wr[c], acc[p][c]);
-            }
+    const int ntiles = (T + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)(blockIdx.x * 4) >= ntiles) return;                     // whole block has nothing to do
+    const int D16 = (D + 15) & ~15;
+    constexpr int WS = 16 * NT + 1;                                  // LDS row stride (doubles): weights + inv_var
+    const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // state tiles this video really needs
+    {
+        const double *__restrict__ w = wall + (size_t)g * D * cm;
+        for (int i = threadIdx.x; i < D16 * WS; i += 256) {
+            const int d = i / WS, c = i - d * WS;
+            wl[i] = (d >= D) ? 0.0 : ((c == 16 * NT) ? iv[d] : ((c < C) ? w[(size_t)d * cm + c] : 0.0));
         }
     }
+    __syncthreads();
+    const int fr = lane & 15, kq = lane >> 4;
+    const float *__restrict__ xv = xall + (size_t)mv.frame_off * D;
     const double *__restrict__ cst = cstall + (size_t)g * cm;
+
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int f0 = tile << 4;
+        const int f = (f0 + fr < T) ? f0 + fr : T - 1;               // clamp: rows past the end are computed, not stored
+        const float *__restrict__ xrow = xv + (size_t)f * D;
+        smm_d4 acc[NT];
 #pragma unroll
-    for (int p = 0; p < FPL; ++p) {
-        if (!livef[p]) continue;
-        const size_t row = (size_t)(mv.frame_off + f[p]) * cm;
+        for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+        double q = 0.0;
+        auto load4 = [&](int d0) -> float4 {
+            const int db = d0 + 4 * kq;                              // this lane's 4 features of the macro-step
+            float4 r;
+            if (db + 3 < D && (D & 3) == 0) {
+                r = *reinterpret_cast<const float4 *>(xrow + db);
+            } else {
+                r.x = (db + 0 < D) ? xrow[db + 0] : 0.f;
+                r.y = (db + 1 < D) ? xrow[db + 1] : 0.f;
+                r.z = (db + 2 < D) ? xrow[db + 2] : 0.f;
+                r.w = (db + 3 < D) ? xrow[db + 3] : 0.f;
+            }
+            return r;
+        };
+        float4 xn1 = load4(0), xn2 = load4(16);                      // two macro-steps of x in flight ahead of the MFMAs
+        for (int d0 = 0; d0 < D16; d0 += 16) {
+            const int db = d0 + 4 * kq;
+            const float4 x4 = xn1;
+            xn1 = xn2;
+            xn2 = load4(d0 + 32);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            if (c < C) {
-                double v = (cst[c] + acc[p][c]) - 0.5 * q[p];
-                if (cons) v += (double)cons[row + c];
-                if (elp64) elp64[row + c] = v;
-                if (elp32) elp32[row + c] = (float)v;
+            for (int j = 0; j < 4; ++j) {
+                const double a = (double)xs[j];
+                const int d = db + j;
+                q = fma(a * wl[(size_t)d * WS + 16 * NT], a, q);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
+                if (NT == 2 && nt == 2)
+                    acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + 16 + fr], acc[NT - 1], 0, 0, 0);
+            }
+        }
+        // q: this lane summed the features with k index kq of frame fr; add the four k groups (lanes fr + 16 k)
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = kq + 4 * i;                              // frame of accumulator register i
+            const double qr = __shfl(q, row);
+            const int ff = f0 + row;
+            if (ff < T) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = 16 * t + fr;
+                    if (c < C) {
+                        const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
+                        double v = (cst[c] + acc[t][i]) - 0.5 * qr;
+                        if (cons) v += (double)cons[o];
+                        if (elp64) elp64[o] = v;
+                        if (elp32) elp32[o] = (float)v;
+                    }
+                }
             }
         }
     }
@@ -114,16 +126,25 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
 
 void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, hipStream_t stream)
 {
-    dim3 block(256);
-#define SMM_EM_LAUNCH(CT, FPL)                                                                                     \
-    hipLaunchKernelGGL((smm_emission_kernel<CT, FPL>), dim3((t_max + 256 * FPL - 1) / (256 * FPL), a.b), block, 0,  \
-                       stream, a.videos, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons, a.elp64, a.elp32, a.d,     \
-                       a.c_max)
-    if (ct <= 8) SMM_EM_LAUNCH(8, 4);
-    else if (ct <= 16) SMM_EM_LAUNCH(16, 2);
-    else if (ct <= 24) SMM_EM_LAUNCH(24, 2);
-    else SMM_EM_LAUNCH(32, 2);
-#undef SMM_EM_LAUNCH
+    const int d16 = (a.d + 15) & ~15;
+    const int tiles = (t_max + 15) / 16;
+    int bx = (tiles + 4 * 8 - 1) / (4 * 8);                 // ~8 tiles per wave: amortises the LDS fill of the weights
+    if (bx < 1) bx = 1;
+    dim3 grid(bx, a.b), block(256);
+    const size_t lds = sizeof(double) * d16 * (ct <= 16 ? 17 : 33);          // <= 160 KiB checked by the caller
+    if (ct <= 16) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_emission_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(smm_emission_kernel<1>, grid, block, lds, stream, a.videos, a.n_states, a.x, a.w, a.cst,
+                           a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_emission_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(smm_emission_kernel<2>, grid, block, lds, stream, a.videos, a.n_states, a.x, a.w, a.cst,
+                           a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max);
+    }
 }
 
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream)

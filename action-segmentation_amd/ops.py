@@ -184,3 +184,20 @@ def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endp
         _dev(g['init'], f64, 'g_init'), _dev(g['len'], f64, 'g_len'),
         ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     return g
+
+
+_pinned = {}
+
+
+def to_host(t):
+    """Device -> host copy through a cached pinned staging buffer (pageable copies are staged by the runtime and
+    run at a fraction of the PCIe rate).  Returns a CPU tensor that is valid until the next call for the same dtype."""
+    key = (t.dtype, t.device.index)
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < t.numel():
+        buf = torch.empty(int(t.numel() * 1.25) + 16, dtype=t.dtype, pin_memory=True)
+        _pinned[key] = buf
+    out = buf[:t.numel()].view(t.shape)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return out

@@ -192,7 +192,8 @@ class SemiMarkovModel(object):
 
     def predict_packed(self, pc):
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True)
-        labels = out['labels'].cpu().numpy()
+        from . import ops
+        labels = ops.to_host(out['labels']).numpy().copy()
         preds = {}
         for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
             preds[name] = labels[off:off + t]

@@ -165,7 +165,7 @@ def main():
                           class_map=t['class_map'], want_spans=False, want_labels=True)
         if events:
             events[1].record(stream)
-        return out['labels'].cpu()
+        return ops.to_host(out['labels'])
 
     def sync():
         torch.cuda.synchronize()

@@ -245,3 +245,40 @@ def test_log_partition_gradients_match_oracle(shape, ends):
     np.testing.assert_allclose(g['trans'].cpu().numpy()[0], ref['trans'], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(g['init'].cpu().numpy()[0], ref['init'], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(g['len'].cpu().numpy()[0, :kp], ref['len'], rtol=2e-5, atol=2e-5)
+
+
+EDGE_SHAPES = [
+    # b, tmax, c, k : chunk boundaries of the 64-frame elp staging, ring wrap-around, degenerate state / length counts
+    (2, 2, 1, 2), (3, 63, 2, 5), (3, 64, 2, 5), (3, 65, 3, 5), (2, 127, 3, 70), (2, 128, 3, 70), (2, 129, 3, 70),
+    (2, 193, 1, 9), (1, 4100, 2, 3), (1, 3000, 5, 64), (2, 700, 9, 65), (40, 90, 3, 7), (300, 50, 4, 6),
+]
+
+
+@pytest.mark.parametrize('shape', EDGE_SHAPES)
+def test_viterbi_and_logz_edge_shapes(shape):
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 997, b, tmax, c, k, ends=(c > 1), min_len=2)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    z = ops.logz(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]),
+                 t(p['endpen']))
+    ref = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'])
+    np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=1e-6, atol=1e-4)
+
+
+def test_unsupported_shapes_fail_loudly():
+    from action_segmentation_amd._lib import SmmError
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=dev)
+    with pytest.raises(SmmError):                       # more than 32 states
+        ops.viterbi(ops.Batch([10], [33], 4), z(10, 33), z(1, 33, 33), z(1, 33), z(1, 4, 33))
+    with pytest.raises(SmmError):                       # length table beyond the compiled rings
+        ops.viterbi(ops.Batch([3000], [3], 2000), z(3000, 3), z(1, 3, 3), z(1, 3), z(1, 2000, 3))
+    with pytest.raises(SmmError):                       # log-partition at K > 512 with more than 14 states
+        ops.logz(ops.Batch([1500], [20], 1024), z(1500, 20), z(1, 20, 20), z(1, 20), z(1, 1024, 20))

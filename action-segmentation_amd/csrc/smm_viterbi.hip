@@ -191,14 +191,14 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if (nn < T) {
                     // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                     const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
-                    double b0 = SMM_NEG_INF, b1 = SMM_NEG_INF;
+                    double bq[4] = {SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF};   // 4 independent max chains
 #pragma unroll
                     for (int q = 0; q < HF / 2; ++q) {
                         const double2 gv = gp[q];
-                        b0 = smm_fmax(b0, gv.x + tr[2 * q]);
-                        b1 = smm_fmax(b1, gv.y + tr[2 * q + 1]);
+                        bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
+                        bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
                     }
-                    const double beta = smm_max_halves(smm_fmax(b0, b1));
+                    const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
                     hcur = beta - cum;
                     if (half == 0 && live) {
                         sh_h[nn & 1][to] = hcur;

@@ -131,6 +131,35 @@ def cpu_factored(pc, model, max_videos=8):
             "sample": "%d videos, oracle/smm_oracle.c factored fp64 DP, one video at a time" % n}
 
 
+def train_step_rate(args, data, model):
+    """Secondary figure for config 4: frames/s of the unsupervised objective's forward + backward (emission, log Z
+    forward kernel, time-reversed backward kernel, marginal kernels, chain rule into the parameters), batch by batch
+    as SemiMarkovModel.fit does it (single-task batches of --batch_size videos, narration constraints on)."""
+    from action_segmentation_amd.batching import make_data_loader
+    m = model.model
+    m.train()
+    batches = list(make_data_loader(args, data, shuffle=False, batch_by_task=True, batch_size=args.batch_size))
+    cons_fn = model._test_constraints(data)
+
+    def one_pass():
+        frames = 0
+        for b in batches:
+            m.zero_grad()
+            cons = cons_fn(b) if cons_fn else None
+            addl = model.make_additional_allowed_ends(b['task_name'], b['lengths'])
+            ll, _ = m.log_likelihood(b['features'].to(model.device), b['lengths'], b['task_indices'], spans=None,
+                                     additional_allowed_ends_per_instance=addl, constraints=cons)
+            (-ll).backward()
+            frames += int(b['lengths'].sum())
+        torch.cuda.synchronize()
+        return frames
+    one_pass()
+    t0 = time.perf_counter()
+    frames = one_pass()
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "batches": len(batches), "ms_per_batch": dt / len(batches) * 1e3}
+
+
 def main():
     a = parse()
     rank, world, local, backend = dist_setup(a.gpus)
@@ -230,6 +259,8 @@ def main():
                                      2 * cells / (dp_ms * 1e-3) / FP64_VALU_PEAK)},
             "mof": float(counters[0] / counters[1]),
         }
+        if a.workload == 'cfg4':
+            res["logz_fwd_bwd"] = train_step_rate(args, data, model)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(data, model, pc)
             try:

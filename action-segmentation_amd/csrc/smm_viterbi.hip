@@ -278,9 +278,18 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                     for (int j = 0; j < SPW; ++j) {
                         if (j >= nv) break;
+                        // adds and maxes in groups of four independent registers, so that no v_max_f64 issues right
+                        // behind the v_add_f64 it depends on
 #pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            if (r != (u + 1) % R) A[j][r] = smm_fmax(A[j][r], hs[j] + L[j][(r - u + 1 + R) % R]);
+                        for (int r0 = 0; r0 < R; r0 += 4) {
+                            double tq[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (r0 + q < R) tq[q] = hs[j] + L[j][(r0 + q - u + 1 + R) % R];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (r0 + q < R && r0 + q != (u + 1) % R) A[j][r0 + q] = smm_fmax(A[j][r0 + q], tq[q]);
+                        }
                         L[j][(R - u) % R] = smm_wave_ror1(L[j][(R - u) % R]);
                     }
                 }

@@ -81,6 +81,13 @@ extern "C" size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *len
     return make_plan(shape, lengths_host).total;
 }
 
+extern "C" size_t smm_error_word_offset(const smm_shape *shape)
+{
+    if (!shape_ok(shape)) return 0;
+    return align_up(sizeof(SmmVideo) * shape->b, 256) + align_up(sizeof(int32_t) * shape->b, 256) +
+           align_up(sizeof(int32_t) * shape->n_groups, 256);
+}
+
 struct Staged {
     SmmVideo *videos;
     int32_t *order;

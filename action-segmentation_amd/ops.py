@@ -201,3 +201,12 @@ def to_host(t):
     out.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
     return out
+
+
+def error_flag(batch, ws=None):
+    """The kernels' error word for the last call on this batch's workspace (synchronises): non-zero means a NaN (or
+    inf - inf) reached the DP and the decode of that video stopped early."""
+    off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
+    if ws is None:
+        ws = workspace(batch.workspace_bytes(), torch.device('cuda', torch.cuda.current_device()))
+    return int(ws[off:off + 4].view(torch.int32).item())

@@ -80,6 +80,10 @@ int smm_device_count(void);
  * except between smm_logz_f64 and smm_logz_bwd_f64. */
 size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 
+/* Byte offset, inside the workspace, of the int32 error word the kernels set (non-zero: a NaN / inf-inf reached the
+ * DP of some video and its decode stopped early).  It is cleared at the start of every call.  Returns 0 on invalid shape. */
+size_t smm_error_word_offset(const smm_shape *shape);
+
 /*
  * Emission scorer.  elp[t][c] = cst[g][c] + sum_d x[t][d]*w[g][c][d] - 0.5*sum_d x[t][d]^2*inv_var[d] (+ cons[t][c])
  * which is the diagonal-Gaussian log density of modules:324-381 with w = mu/sigma^2,

@@ -282,3 +282,20 @@ def test_unsupported_shapes_fail_loudly():
         ops.viterbi(ops.Batch([3000], [3], 2000), z(3000, 3), z(1, 3, 3), z(1, 3), z(1, 2000, 3))
     with pytest.raises(SmmError):                       # log-partition at K > 512 with more than 14 states
         ops.logz(ops.Batch([1500], [20], 1024), z(1500, 20), z(1, 20, 20), z(1, 20), z(1, 1024, 20))
+
+
+def test_nan_input_sets_error_word_and_terminates():
+    ops = _ops()
+    p = make_problem(3, 2, 50, 4, 6)
+    p['elp'][1, 7, 2] = np.nan
+    dev = torch.device('cuda:0')
+    b, tmax, cm = p['elp'].shape
+    batch = ops.Batch(p['lengths'], [p['c']], p['k'], c_max=cm, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    torch.cuda.synchronize()
+    assert ops.error_flag(batch) != 0
+    p['elp'][1, 7, 2] = 0.0
+    ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    torch.cuda.synchronize()
+    assert ops.error_flag(batch) == 0

@@ -88,12 +88,44 @@ __device__ __forceinline__ void smm_wave_best3(double &v, int &k, int &c)
     }
 }
 
+// One frame of one state's ring (source step n, n % R == u after unrolling):
+//   finish the R-1 pushes of h[n-1] that position n+1 did not depend on, rotate the length ring, clear slot n,
+//   do the one push of h[n] that slot n+2 needs and hand A'[n+2] (sources <= n) to LDS.
+template <int R>
+__device__ __forceinline__ void smm_ring_frame(double (&A)[R], double (&L)[R], double &hs, double hn, int n, int u,
+                                               int lane, double *apart_slot)
+{
+    constexpr int RING = 64 * R;
+    const int r2 = (u + 2) % R;                                  // register of ring slot n+2 (static after unrolling)
+    const bool clear = lane == (n & (RING - 1)) / R;             // lane of ring slot n (register u)
+    const bool hand = lane == ((n + 2) & (RING - 1)) / R;        // lane of ring slot n+2
+    if (n >= 1) {
+        // adds and maxes in groups of four independent registers
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 4) {
+            double tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + q < R) tq[q] = hs + L[(r0 + q - u + 1 + R) % R];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + q < R && r0 + q != (u + 1) % R) A[r0 + q] = smm_fmax(A[r0 + q], tq[q]);
+        }
+        L[(R - u) % R] = smm_wave_ror1(L[(R - u) % R]);
+    }
+    hs = hn;
+    if (clear) A[u] = SMM_NEG_INF;                               // slot n now accumulates position n + RING
+    A[r2] = smm_fmax(A[r2], hs + L[(r2 - u + R) % R]);           // the push slot n+2 waits for
+    if (hand) *apart_slot = A[r2];
+}
+
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
-template <int R, int SPW, int NW, int HF>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, NW / 4)))
+// CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
+template <int R, int SPW, int NW, int HF, int CP>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
     constexpr int RING = 64 * R;
@@ -171,9 +203,25 @@ smm_viterbi_kernel(SmmDpArgs a)
         double cum = 0.0;
         double hcur = live ? init[to] : 0.0;              // h[n][to]
         double enext = live ? sh_elp[0][to] : 0.0;          // elp[n][to], read one frame ahead
+        // own ring (CP): state cx, same code as a pusher with one state
+        constexpr int cx = NP * SPW;
+        const bool has1 = CP && cx < C;
+        double A1[CP ? R : 1], L1[CP ? R : 1], hs1 = 0.0;
+        if (CP) {
+#pragma unroll
+            for (int r = 0; r < (CP ? R : 1); ++r) {
+                const int p = lane * R + r;
+                A1[r] = SMM_NEG_INF;
+                L1[r] = (has1 && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + cx] : SMM_NEG_INF;
+            }
+        }
         SMM_PROF_DECL;
-        for (int n = 0; n < T; ++n) {
-            {
+        for (int n0 = 0; n0 < T; n0 += (CP ? R : 1)) {
+#pragma unroll
+            for (int u = 0; u < (CP ? R : 1); ++u) {
+                const int n = n0 + u;
+                if (n >= T) break;
+                const double hn1 = (CP && has1) ? smm_readlane(hcur, cx) : 0.0;      // h[n][cx] before it is replaced
                 const double ecurv = enext;
                 const int n1 = n + 1;
                 enext = (live && n1 < T) ? sh_elp[(n1 >> 6) & 1][(n1 & 63) * cm + to] : 0.0;
@@ -197,6 +245,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const double2 gv = gp[q];
                         bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
                         bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
+                        // with its own ring the chain wave is register-bound: do not let the scheduler hoist all LDS reads
+                        if (CP && (q & 1)) __builtin_amdgcn_sched_barrier(0);
                     }
                     const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
                     hcur = beta - cum;
@@ -204,6 +254,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                         sh_h[nn & 1][to] = hcur;
                         hh[(size_t)nn * cm + to] = hcur;
                     }
+                }
+                if constexpr (CP) {
+                    if (has1) smm_ring_frame<R>(A1, L1, hs1, hn1, n, u, lane, &sh_apart[n & 1][cx]);
                 }
                 SMM_STAMP(q2);
                 __syncthreads();                                           // barrier n+1
@@ -219,6 +272,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // owns the fewest states
         int rank = w - 1;
         if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+        // (12 waves: every pusher owns SPW states, nothing to rebalance)
         const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
         double A[SPW][R], L[SPW][R], hs[SPW];
@@ -244,9 +298,6 @@ smm_viterbi_kernel(SmmDpArgs a)
             for (int u = 0; u < R; ++u) {
                 const int n = n0 + u;                            // source step; n % R == u
                 if (n >= T) break;
-                const int r2 = (u + 2) % R;                      // register of ring slot n+2 (static after unrolling)
-                const bool clear = lane == (n & (RING - 1)) / R;           // lane of ring slot n (register u)
-                const bool hand = lane == ((n + 2) & (RING - 1)) / R;      // lane of ring slot n+2
                 if (u == 0 && (n & 31) == 0) {
                     // next 64-frame chunk of elp: global -> registers at the start of a chunk, -> LDS half a chunk later
                     const int nbase = (n & ~63) + 64;
@@ -272,35 +323,12 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if (j >= nv) break;
                     hn[j] = sh_h[n & 1][j * NP + rank];          // h[n][c]  (LDS broadcast read, consumed below)
                 }
-                // While that read is in flight: the R-1 pushes of source n-1 that position n+1 did not depend on
-                // (everything but register (u+1)%R, pushed before the hand-over of the previous frame).
-                if (n >= 1) {
-#pragma unroll
-                    for (int j = 0; j < SPW; ++j) {
-                        if (j >= nv) break;
-                        // adds and maxes in groups of four independent registers, so that no v_max_f64 issues right
-                        // behind the v_add_f64 it depends on
-#pragma unroll
-                        for (int r0 = 0; r0 < R; r0 += 4) {
-                            double tq[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (r0 + q < R) tq[q] = hs[j] + L[j][(r0 + q - u + 1 + R) % R];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (r0 + q < R && r0 + q != (u + 1) % R) A[j][r0 + q] = smm_fmax(A[j][r0 + q], tq[q]);
-                        }
-                        L[j][(R - u) % R] = smm_wave_ror1(L[j][(R - u) % R]);
-                    }
-                }
+                // (smm_ring_frame overlaps that read with the R-1 left-over pushes of source n-1)
                 SMM_STAMP(q1);
 #pragma unroll
                 for (int j = 0; j < SPW; ++j) {
                     if (j >= nv) break;
-                    hs[j] = hn[j];
-                    if (clear) A[j][u] = SMM_NEG_INF;            // slot n now accumulates position n + RING
-                    A[j][r2] = smm_fmax(A[j][r2], hs[j] + L[j][(r2 - u + R) % R]);   // the push slot n+2 waits for
-                    if (hand) sh_apart[n & 1][j * NP + rank] = A[j][r2];             // sources <= n of position n+2
+                    smm_ring_frame<R>(A[j], L[j], hs[j], hn[j], n, u, lane, &sh_apart[n & 1][j * NP + rank]);
                 }
                 SMM_STAMP(q2);
                 __syncthreads();                                 // barrier n+1
@@ -409,8 +437,8 @@ template <int R, int SPW, int NW>
 static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_t stream)
 {
     if (spw != SPW || nw != NW) return 0;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8>), dim3(a.b), dim3(NW * 64), 0, stream, a);
-    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     return 1;
 }
 
@@ -427,6 +455,13 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
     if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
     (void)SPW16;
+    if constexpr (R == 16) {
+        // 22..23 states at K > 512: 12 waves (170 VGPRs each) = 11 pushers x 2 states + the chain wave's own ring
+        if (nw == 16 && c_need <= 23) {
+            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 16, 1>), dim3(a.b), dim3(12 * 64), 0, stream, a);
+            return SMM_OK;
+        }
+    }
     const int spw = (c_need + nw - 2) / (nw - 1);
     int hit = 0;
     if constexpr (R <= 4) {

@@ -162,6 +162,7 @@ def train_step_rate(args, data, model):
 
 def main():
     a = parse()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))   # host-side torch ops are tiny: a 256-thread pool only adds latency
     rank, world, local, backend = dist_setup(a.gpus)
     dev = torch.device('cuda', torch.cuda.current_device())
     red_dev = dev if backend != 'gloo' else torch.device('cpu')

@@ -9,6 +9,7 @@ SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
     "smm_error_word_offset",
     "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
+    "smm_dense_workspace_bytes", "smm_dense_dp_f32",
 ]
 
 
@@ -41,6 +42,8 @@ def load():
     lib.smm_version.restype = ctypes.c_char_p
     lib.smm_workspace_bytes.restype = ctypes.c_size_t
     lib.smm_workspace_bytes.argtypes = [ctypes.POINTER(SmmShape), ctypes.c_void_p]
+    lib.smm_dense_workspace_bytes.restype = ctypes.c_size_t
+    lib.smm_dense_workspace_bytes.argtypes = [ctypes.c_int32] * 4
     lib.smm_error_word_offset.restype = ctypes.c_size_t
     lib.smm_error_word_offset.argtypes = [ctypes.POINTER(SmmShape)]
     _lib = lib

@@ -324,3 +324,49 @@ extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_h
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ dense boundary
+static size_t dense_off(size_t &cur, size_t bytes)
+{
+    const size_t o = cur;
+    cur += align_up(bytes, 256);
+    return o;
+}
+
+extern "C" size_t smm_dense_workspace_bytes(int32_t b, int32_t n1, int32_t k, int32_t c)
+{
+    if (b < 1 || n1 < 1 || k < 1 || c < 1) return 0;
+    size_t cur = 0;
+    dense_off(cur, sizeof(int64_t) * b);
+    dense_off(cur, sizeof(double) * (size_t)b * k * k * c);
+    dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c);
+    dense_off(cur, (size_t)b * n1 * k * c);
+    dense_off(cur, sizeof(uint16_t) * (size_t)b * (n1 + 1) * c);
+    return cur;
+}
+
+extern "C" int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k,
+                                int32_t c, int32_t semiring, double *v, int64_t *spans, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    if (!scores || !lengths_host || !v || !workspace || b < 1 || n1 < 1 || k < 1 || c < 1) return SMM_ERR_ARG;
+    if (c > 255 || k > 65535) return SMM_ERR_UNSUPPORTED;
+    if (workspace_bytes < smm_dense_workspace_bytes(b, n1, k, c)) return SMM_ERR_WORKSPACE;
+    for (int i = 0; i < b; ++i)
+        if (lengths_host[i] < 1 || lengths_host[i] > n1 + 1) return SMM_ERR_ARG;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(workspace);
+    size_t cur = 0;
+    SmmDenseArgs a{};
+    int64_t *dlen = reinterpret_cast<int64_t *>(base + dense_off(cur, sizeof(int64_t) * b));
+    a.alpha = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * k * k * c));
+    a.beta = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c));
+    a.bp_from = reinterpret_cast<uint8_t *>(base + dense_off(cur, (size_t)b * n1 * k * c));
+    a.bp_k = reinterpret_cast<uint16_t *>(base + dense_off(cur, sizeof(uint16_t) * (size_t)b * (n1 + 1) * c));
+    SMM_HIP(hipMemcpyAsync(dlen, lengths_host, sizeof(int64_t) * b, hipMemcpyHostToDevice, hs));
+    a.edge = scores; a.lengths = dlen; a.v = v; a.spans = spans;
+    a.b = b; a.n1 = n1; a.k = k; a.c = c;
+    smm_launch_dense(a, semiring != 0, hs);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
+}

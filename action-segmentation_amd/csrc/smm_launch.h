@@ -38,3 +38,16 @@ struct SmmBwdArgs {
 };
 void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStream_t stream);
 void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream);
+
+struct SmmDenseArgs {
+    const float *edge;        // [b][n1][k][c][c]  (c_to, c_from)
+    const int64_t *lengths;   // [b] positions (device)
+    double *alpha;            // scratch [b][k][k][c]
+    double *beta;             // scratch [b][n1+1][c]
+    uint8_t *bp_from;         // scratch [b][n1][k][c]   (max semiring)
+    uint16_t *bp_k;           // scratch [b][n1+1][c]
+    double *v;                // [b]
+    int64_t *spans;           // [b][n1+1] or null
+    int32_t b, n1, k, c;
+};
+void smm_launch_dense(const SmmDenseArgs &a, bool log_semiring, hipStream_t stream);

@@ -152,6 +152,18 @@ int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const 
                      double *g_elp, double *g_trans, double *g_init, double *g_len,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The reference's inner boundary as it stands: semiring DP over DENSE potentials, for lattices small enough to be
+ * materialised (reference defaults).  Replaces torch_struct.SemiMarkovCRF(scores, lengths).argmax + from_parts
+ * (semiring = 0, max) and .partition (semiring = 1, log) -- call sites semimarkov_modules.py:624, 657, 677-679,
+ * src/models/test_semimarkov.py:312-314.
+ *   scores   dev fp32 [b][n1][k][c][c] indexed [n][k][c_to][c_from];  lengths_host[b] = positions (max == n1 + 1)
+ *   v        dev fp64 [b];  spans dev int64 [b][n1 + 1] (max semiring only, nullable)
+ */
+size_t smm_dense_workspace_bytes(int32_t b, int32_t n1, int32_t k, int32_t c);
+int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k, int32_t c,
+                     int32_t semiring, double *v, int64_t *spans, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

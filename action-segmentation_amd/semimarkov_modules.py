@@ -343,6 +343,10 @@ class SemiMarkovModule(nn.Module):
         f64 = torch.float64
         dev = device or self.gaussian_means.device
         vc = valid_classes
+        if vc is not None:      # checked on the host: an out-of-range id in a device gather is a GPU trap, not an exception
+            bad = [int(v) for v in vc if not 0 <= int(v) < self.n_classes]
+            if bad:
+                raise IndexError("valid_classes %s outside the model's %d classes" % (bad, self.n_classes))
         idx = self._merged(vc).to(dev)
         var = torch.diagonal(self.gaussian_cov).to(f64)
         mu = self.gaussian_means.to(f64)[idx]                                   # C x D

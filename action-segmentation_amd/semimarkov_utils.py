@@ -74,7 +74,7 @@ def semimarkov_sufficient_stats(feature_list, label_list, covariance_type, n_cla
     span_lengths = np.zeros(n_classes, dtype=np.float32)
     span_start_counts = np.zeros(n_classes, dtype=np.float32)
     span_transition_counts = np.zeros((n_classes, n_classes), dtype=np.float32)   # to, from
-    d = int(np.asarray(feature_list[0]).shape[1])
+    d = int(feature_list[0].shape[1])
     sum_x = np.zeros((n_classes, d))
     cnt = np.zeros(n_classes)
     tot = np.zeros(d)

@@ -44,10 +44,13 @@ class SynthCorpus:
 
 
 class SynthDatasplit(Dataset):
-    def __init__(self, cfg, seed=0, device='cpu', scale=1.0):
+    def __init__(self, cfg, seed=0, device='cpu', scale=1.0, video_seed=None):
+        """``seed`` fixes the label space (tasks, steps, class means, rates); ``video_seed`` (optional) draws a
+        different set of videos over the SAME label space -- a held-out split for a model fitted on ``seed``."""
         c = dict(CONFIGS[cfg]) if isinstance(cfg, str) else dict(cfg)
         self.cfg = c
         rng = np.random.default_rng(seed)
+        vrng = None if video_seed is None else np.random.default_rng([seed, video_seed])
         self.feature_dim = c['d']
         self.max_k = c['max_k']
         self.remove_background = False
@@ -59,7 +62,7 @@ class SynthDatasplit(Dataset):
         self._videos = {}
         means, rates = [], []
         n_videos = max(1, int(round(c['videos_per_task'] * scale)))
-        gen = torch.Generator(device=device).manual_seed(seed)
+        gen = torch.Generator(device=device).manual_seed(seed if video_seed is None else seed + 7919 * (video_seed + 1))
         for ti in range(c['n_tasks']):
             task = 'task%02d' % ti
             if c['steps'] is not None:
@@ -88,6 +91,12 @@ class SynthDatasplit(Dataset):
                     m, sg, lo, hi = c['t_lognormal']
                     t = int(np.clip(rng.lognormal(np.log(m), sg), lo, hi))
                 labels_local = self._sample_labels(rng, t, c1, rt, c['chain'], c['max_k'])
+                cons = self._narration(rng, labels_local, c1, t) if c.get('narration') else None
+                if vrng is not None:            # the structural stream above stays in step with the seed-only split
+                    if 't_fixed' not in c:
+                        t = int(np.clip(vrng.lognormal(np.log(m), sg), lo, hi))
+                    labels_local = self._sample_labels(vrng, t, c1, rt, c['chain'], c['max_k'])
+                    cons = self._narration(vrng, labels_local, c1, t) if c.get('narration') else None
                 name = '%s_v%03d' % (task, vi)
                 names.append(name)
                 lab = torch.from_numpy(labels_local)
@@ -96,8 +105,8 @@ class SynthDatasplit(Dataset):
                     t, d, generator=gen, device=device)
                 sample = dict(features=x, gt_single=lab + ids[0], task_name=task, video_name=name,
                               task_indices=torch.tensor(ids, dtype=torch.long))
-                if c.get('narration'):
-                    sample['constraints'] = self._narration(rng, labels_local, c1, t)
+                if cons is not None:
+                    sample['constraints'] = cons
                 self._videos[(task, name)] = sample
             self._videos_by_task[task] = names
         self.corpus = SynthCorpus(n_classes, indices_by_task, background)

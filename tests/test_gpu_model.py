@@ -70,3 +70,14 @@ def test_unsupervised_fit_improves_marginal_likelihood():
     assert log[-1] < log[0] - 1.0, log
     preds = model.predict(data)
     assert set(preds) == {n for (_, n) in data._videos}
+
+
+def test_cli_train_save_load_decode(tmp_path):
+    """--classifier semimarkov end to end: closed-form training, pickle, reload, decode (like decode.sh)."""
+    from action_segmentation_amd import cli
+    out = str(tmp_path / 'model')
+    s1 = cli.main(['--classifier', 'semimarkov', '--training', 'supervised', '--cuda', '--dataset', 'synthetic:tiny',
+                   '--sm_max_span_length', '12', '--batch_size', '2', '--model_output_path', out])
+    s2 = cli.main(['--classifier', 'semimarkov', '--cuda', '--dataset', 'synthetic:tiny', '--sm_max_span_length', '12',
+                   '--batch_size', '2', '--model_input_path', out])
+    assert s1 == s2 and s1['test_mof'] > 0.5

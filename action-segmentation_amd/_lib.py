@@ -10,6 +10,7 @@ SYMBOLS = [
     "smm_error_word_offset",
     "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
     "smm_dense_workspace_bytes", "smm_dense_dp_f32",
+    "smm_eval_workspace_bytes", "smm_eval_confusion_i64", "smm_eval_videos_i64",
 ]
 
 
@@ -17,6 +18,20 @@ class SmmShape(ctypes.Structure):
     _fields_ = [("b", ctypes.c_int32), ("d", ctypes.c_int32), ("n_groups", ctypes.c_int32),
                 ("c_max", ctypes.c_int32), ("k_rows", ctypes.c_int32), ("t_max", ctypes.c_int32),
                 ("total_frames", ctypes.c_int64)]
+
+
+class SmmEvalShape(ctypes.Structure):
+    _fields_ = [("b", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("c_max", ctypes.c_int32),
+                ("n_labels", ctypes.c_int32), ("gt_width", ctypes.c_int32), ("t_max", ctypes.c_int32),
+                ("total_frames", ctypes.c_int64)]
+
+
+EVAL_MAX_LABELS = 63
+EVAL_COUNTERS = 32
+EVAL_COUNTER_NAMES = ['frames', 'segs_gt', 'segs_pred', 'segs_pred_non_bg', 'multi', 'gt_labels', 'tp', 'pred_bg',
+                      'true_bg', 'iou_den', 'iou_num', 'gt_labels_non_bg', 'frames_non_bg', 'tp_non_bg', 'steps',
+                      'steps_non_bg', 'draw_hit', 'draw_hit_non_bg', 'mid_hit', 'mid_hit_non_bg', 'types',
+                      'types_non_bg', 'other', 'levenshtein']
 
 
 class SmmError(RuntimeError):
@@ -44,6 +59,8 @@ def load():
     lib.smm_workspace_bytes.argtypes = [ctypes.POINTER(SmmShape), ctypes.c_void_p]
     lib.smm_dense_workspace_bytes.restype = ctypes.c_size_t
     lib.smm_dense_workspace_bytes.argtypes = [ctypes.c_int32] * 4
+    lib.smm_eval_workspace_bytes.restype = ctypes.c_size_t
+    lib.smm_eval_workspace_bytes.argtypes = [ctypes.POINTER(SmmEvalShape), ctypes.c_void_p]
     lib.smm_error_word_offset.restype = ctypes.c_size_t
     lib.smm_error_word_offset.argtypes = [ctypes.POINTER(SmmShape)]
     _lib = lib

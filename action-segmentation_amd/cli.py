@@ -19,7 +19,7 @@ import torch
 
 from . import synth
 from .batching import add_training_args
-from .distributed import frame_accuracy_counters
+from .evaluation import STAT_KEYS, accuracy_corpus, summarise
 from .semimarkov import SemiMarkovModel
 
 CLASSIFIERS = {'semimarkov': SemiMarkovModel}
@@ -63,14 +63,25 @@ def build_parser():
     return p
 
 
-def evaluate(model, data, name):
+def optimal_assignment_for(args):
+    """main.py:126-135: Hungarian re-assignment only for unsupervised training without ordering constraints."""
+    if args.force_optimal_assignment:
+        return True
+    if args.training == 'supervised':
+        return False
+    if args.sm_constrain_transitions:
+        return False
+    return not ('train' in args.sm_constrain_with_narration or 'test' in args.sm_constrain_with_narration)
+
+
+def evaluate(model, data, name, args=None):
+    """main.py:126-160 ``test``: decode, then the per-task statistics of ``accuracy_corpus`` summed over tasks."""
     preds = model.predict(data)
-    gts = {n: smp['gt_single'].cpu().numpy() for (_, n), smp in data._videos.items()}
-    c = frame_accuracy_counters(preds, gts, data.corpus._background_indices)
-    stats = {'%s_mof' % name: c['mof'][0] / max(1, c['mof'][1]),
-             '%s_mof_non_bg' % name: c['mof_non_bg'][0] / max(1, c['mof_non_bg'][1])}
-    for k, v in stats.items():
-        print('%s: %.4f' % (k, v))
+    by_task = accuracy_corpus(data, preds, optimal_assignment_for(args) if args is not None else False,
+                              seed=getattr(args, 'seed', 0) if args is not None else 0)
+    stats = summarise(by_task, STAT_KEYS, prefix=name + '_')
+    print(', '.join(STAT_KEYS))
+    print(', '.join('%.4f' % stats[name + '_' + k] for k in STAT_KEYS))
     return preds, stats
 
 
@@ -107,8 +118,8 @@ def main(argv=None):
             os.makedirs(args.model_output_path, exist_ok=True)
             with open(os.path.join(args.model_output_path, 'synthetic.pkl'), 'wb') as f:
                 pickle.dump(model, f)
-    evaluate(model, train, 'train')
-    preds, stats = evaluate(model, test, 'test')
+    evaluate(model, train, 'train', args)
+    preds, stats = evaluate(model, test, 'test', args)
     if args.prediction_output_path:
         os.makedirs(args.prediction_output_path, exist_ok=True)
         for video, pred in preds.items():

@@ -210,3 +210,68 @@ def error_flag(batch, ws=None):
     if ws is None:
         ws = workspace(batch.workspace_bytes(), torch.device('cuda', torch.cuda.current_device()))
     return int(ws[off:off + 4].view(torch.int32).item())
+
+
+# ------------------------------------------------------------------------------------------------ evaluation counters
+class EvalBatch:
+    """Host metadata of one evaluation call: videos on the packed frame axis, their task and index inside the task."""
+
+    def __init__(self, lengths, frame_offset, group, n_groups, c_max, n_labels, gt_width=1, video_key=None,
+                 total_frames=None):
+        self.lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
+        self.b = int(self.lengths.shape[0])
+        self.frame_offset = np.ascontiguousarray(np.asarray(frame_offset, dtype=np.int64).reshape(-1))
+        self.group = np.ascontiguousarray(np.asarray(group, dtype=np.int32).reshape(-1))
+        self.video_key = None if video_key is None else np.ascontiguousarray(np.asarray(video_key, dtype=np.int32).reshape(-1))
+        self.n_groups, self.c_max, self.n_labels, self.gt_width = int(n_groups), int(c_max), int(n_labels), int(gt_width)
+        if self.c_max > _lib.EVAL_MAX_LABELS:
+            raise _lib.SmmError("libsmmdp: a task with %d labels exceeds SMM_EVAL_MAX_LABELS" % self.c_max)
+        if total_frames is None:
+            total_frames = int((self.frame_offset + self.lengths).max())
+        self.total_frames = int(total_frames)
+        self.shape = _lib.SmmEvalShape(self.b, self.n_groups, self.c_max, self.n_labels, self.gt_width,
+                                       int(self.lengths.max()), self.total_frames)
+
+    def workspace_bytes(self):
+        n = _lib.load().smm_eval_workspace_bytes(ctypes.byref(self.shape), self.lengths.ctypes.data)
+        if n == 0:
+            raise _lib.SmmError("libsmmdp: invalid evaluation batch shape")
+        return n
+
+
+def _eval_check(eb, pred, gt):
+    if pred.numel() < eb.total_frames or gt.numel() < eb.total_frames * eb.gt_width:
+        raise ValueError("pred / gt shorter than the packed frame axis")
+
+
+def eval_confusion(eb, pred, gt, local_of):
+    """(first gt label, predicted label) frame counts per task: int64 [n_groups, c_max+1, c_max+1].  (smm_eval_confusion_i64)"""
+    lib = _lib.load()
+    _eval_check(eb, pred, gt)
+    dev = pred.device
+    conf = torch.empty((eb.n_groups, eb.c_max + 1, eb.c_max + 1), dtype=torch.int64, device=dev)
+    ws = workspace(eb.workspace_bytes(), dev)
+    _lib.check(lib.smm_eval_confusion_i64(
+        ctypes.byref(eb.shape), ctypes.c_void_p(eb.lengths.ctypes.data), ctypes.c_void_p(eb.frame_offset.ctypes.data),
+        ctypes.c_void_p(eb.group.ctypes.data), _dev(pred, torch.int64, 'pred'), _dev(gt, torch.int64, 'gt'),
+        _dev(local_of, torch.int32, 'local_of'), _dev(conf, torch.int64, 'confusion'),
+        ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return conf
+
+
+def eval_videos(eb, pred, gt, local_of, cluster_of, gt_is_bg, pred_is_bg, seed=0):
+    """Per-video counters int64 [b, EVAL_COUNTERS] (columns: _lib.EVAL_COUNTER_NAMES).  (smm_eval_videos_i64)"""
+    lib = _lib.load()
+    _eval_check(eb, pred, gt)
+    dev = pred.device
+    out = torch.empty((eb.b, _lib.EVAL_COUNTERS), dtype=torch.int64, device=dev)
+    ws = workspace(eb.workspace_bytes(), dev)
+    _lib.check(lib.smm_eval_videos_i64(
+        ctypes.byref(eb.shape), ctypes.c_void_p(eb.lengths.ctypes.data), ctypes.c_void_p(eb.frame_offset.ctypes.data),
+        ctypes.c_void_p(eb.group.ctypes.data),
+        ctypes.c_void_p(None if eb.video_key is None else eb.video_key.ctypes.data),
+        _dev(pred, torch.int64, 'pred'), _dev(gt, torch.int64, 'gt'), _dev(local_of, torch.int32, 'local_of'),
+        _dev(cluster_of, torch.int32, 'cluster_of'), _dev(gt_is_bg, torch.uint8, 'gt_is_bg'),
+        _dev(pred_is_bg, torch.uint8, 'pred_is_bg'), ctypes.c_uint32(int(seed) & 0xFFFFFFFF),
+        _dev(out, torch.int64, 'counters'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return out

@@ -164,6 +164,63 @@ size_t smm_dense_workspace_bytes(int32_t b, int32_t n1, int32_t k, int32_t c);
 int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k, int32_t c,
                      int32_t semiring, double *v, int64_t *spans, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Evaluation counters of decoded frame labels against ground truth -- the per-frame loops of the reference's
+ * src/evaluation/accuracy.py as driven by Datasplit.accuracy_corpus (src/data/corpus.py:486-565).  Integer work only;
+ * the label assignment (identity / Hungarian on the confusion table) and the final ratios are the caller's.
+ *   pred        dev int64 [total_frames]            global class ids (what smm_decode_f32 writes to `labels`)
+ *   gt          dev int64 [total_frames][gt_width]  ground-truth ids, first column = "the" label, -1 = no further label
+ *   local_of    dev int32 [n_groups][n_labels]      global id -> local id in [0, c_max) of the video's task, -1 = not
+ *                                                   in the task (such frames are counted under local id c_max)
+ * smm_eval_confusion_i64  (accuracy.py:232-283 voting table, :500-521 per-class masks)
+ *   confusion   dev int64 [n_groups][c_max+1][c_max+1]  frames with (first gt label, predicted label); overwritten
+ * smm_eval_videos_i64     (accuracy.py:538-576 frame loop, :21-37 + :364-408 run lengths and edit distance,
+ *                          :410-472 step recall)
+ *   video_key   host int32 [b] index of the video inside its task (seeds the random frame draw; NULL: i)
+ *   cluster_of  dev int32 [n_groups][c_max+1]      local gt id -> predicted label that it owns after assignment, as a
+ *                                                  local id, or c_max+1+j for an invented label j, or -1 (none)
+ *   gt_is_bg    dev uint8 [n_groups][c_max+1]      local gt id is a background class
+ *   pred_is_bg  dev uint8 [n_groups][2*(c_max+1)]  (extended) predicted id is owned by a background class
+ *   seed        the frame drawn for `single_step_recall` is the candidate with the smallest hash(seed, key, t)
+ *   counters    dev int64 [b][SMM_EVAL_COUNTERS]   per video, indexed by smm_eval_counter; overwritten
+ */
+#define SMM_EVAL_MAX_LABELS 63
+#define SMM_EVAL_COUNTERS 32
+typedef enum smm_eval_counter {
+    SMM_EV_FRAMES = 0, SMM_EV_SEGS_GT = 1, SMM_EV_SEGS_PRED = 2, SMM_EV_SEGS_PRED_NON_BG = 3,
+    SMM_EV_MULTI = 4,            /* frames with more than one gt label */
+    SMM_EV_GT_LABELS = 5,        /* sum of gt labels per frame (recall denominator) */
+    SMM_EV_TP = 6,               /* prediction owned by one of the frame's gt labels */
+    SMM_EV_PRED_BG = 7, SMM_EV_TRUE_BG = 8,
+    SMM_EV_IOU_DEN = 9, SMM_EV_IOU_NUM = 10,          /* frames not (gt bg and pred bg); of those, true positives */
+    SMM_EV_GT_LABELS_NON_BG = 11, SMM_EV_FRAMES_NON_BG = 12, SMM_EV_TP_NON_BG = 13,
+    SMM_EV_STEPS = 14, SMM_EV_STEPS_NON_BG = 15,      /* distinct (remapped) gt labels of the video */
+    SMM_EV_DRAW_HIT = 16, SMM_EV_DRAW_HIT_NON_BG = 17, SMM_EV_MID_HIT = 18, SMM_EV_MID_HIT_NON_BG = 19,
+    SMM_EV_TYPES = 20, SMM_EV_TYPES_NON_BG = 21,      /* distinct predicted labels */
+    SMM_EV_OTHER = 22,           /* labels outside the task's table (must be 0 for the statistics to be meaningful) */
+    SMM_EV_LEVENSHTEIN = 23
+} smm_eval_counter;
+
+typedef struct smm_eval_shape {
+    int32_t b;          /* videos */
+    int32_t n_groups;   /* tasks */
+    int32_t c_max;      /* local label ids per task, <= SMM_EVAL_MAX_LABELS */
+    int32_t n_labels;   /* size of the global label space */
+    int32_t gt_width;   /* ground-truth labels per frame (>= 1) */
+    int32_t t_max;      /* max lengths[i] */
+    int64_t total_frames;
+} smm_eval_shape;
+
+size_t smm_eval_workspace_bytes(const smm_eval_shape *shape, const int64_t *lengths_host);
+int smm_eval_confusion_i64(const smm_eval_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                           const int32_t *group_host, const int64_t *pred, const int64_t *gt, const int32_t *local_of,
+                           int64_t *confusion, void *workspace, size_t workspace_bytes, void *stream);
+int smm_eval_videos_i64(const smm_eval_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                        const int32_t *group_host, const int32_t *video_key_host, const int64_t *pred, const int64_t *gt,
+                        const int32_t *local_of, const int32_t *cluster_of, const uint8_t *gt_is_bg,
+                        const uint8_t *pred_is_bg, uint32_t seed, int64_t *counters,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@ SYMBOLS = [
     "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
     "smm_dense_workspace_bytes", "smm_dense_dp_f32",
     "smm_eval_workspace_bytes", "smm_eval_confusion_i64", "smm_eval_videos_i64",
+    "smm_fit_workspace_bytes", "smm_fit_error_word_offset", "smm_fit_stats_f64",
 ]
 
 
@@ -61,6 +62,10 @@ def load():
     lib.smm_dense_workspace_bytes.argtypes = [ctypes.c_int32] * 4
     lib.smm_eval_workspace_bytes.restype = ctypes.c_size_t
     lib.smm_eval_workspace_bytes.argtypes = [ctypes.POINTER(SmmEvalShape), ctypes.c_void_p]
+    lib.smm_fit_workspace_bytes.restype = ctypes.c_size_t
+    lib.smm_fit_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.smm_fit_error_word_offset.restype = ctypes.c_size_t
+    lib.smm_fit_error_word_offset.argtypes = [ctypes.c_int32]
     lib.smm_error_word_offset.restype = ctypes.c_size_t
     lib.smm_error_word_offset.argtypes = [ctypes.POINTER(SmmShape)]
     _lib = lib

@@ -275,3 +275,38 @@ def eval_videos(eb, pred, gt, local_of, cluster_of, gt_is_bg, pred_is_bg, seed=0
         _dev(pred_is_bg, torch.uint8, 'pred_is_bg'), ctypes.c_uint32(int(seed) & 0xFFFFFFFF),
         _dev(out, torch.int64, 'counters'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ closed-form fit
+def fit_stats(x, labels, lengths, frame_offset, n_classes, max_k):
+    """Sufficient statistics of the supervised fit for videos on the packed frame axis (smm_fit_stats_f64).
+
+    x cuda fp32 [F, D], labels cuda int64 [F] -> dict of cuda tensors: sum_x fp64 [n_classes, D], sum_x2 fp64 [D],
+    frame_counts / span_counts / span_start_counts int64 [n_classes], span_transition_counts int64 [to, from].
+    """
+    lib = _lib.load()
+    dev = x.device
+    ln = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
+    fo = np.ascontiguousarray(np.asarray(frame_offset, dtype=np.int64).reshape(-1))
+    b, d = int(ln.shape[0]), int(x.shape[1])
+    n = int(n_classes)
+    out = dict(sum_x=torch.empty((n, d), dtype=torch.float64, device=dev),
+               sum_x2=torch.empty(d, dtype=torch.float64, device=dev),
+               frame_counts=torch.empty(n, dtype=torch.int64, device=dev),
+               span_counts=torch.empty(n, dtype=torch.int64, device=dev),
+               span_start_counts=torch.empty(n, dtype=torch.int64, device=dev),
+               span_transition_counts=torch.empty((n, n), dtype=torch.int64, device=dev))
+    ws = workspace(lib.smm_fit_workspace_bytes(b), dev)
+    _lib.check(lib.smm_fit_stats_f64(
+        ctypes.c_int32(b), ctypes.c_void_p(ln.ctypes.data), ctypes.c_void_p(fo.ctypes.data),
+        ctypes.c_int64(int(x.shape[0])), ctypes.c_int32(d), ctypes.c_int32(n),
+        ctypes.c_int32(0 if max_k is None else int(max_k)), _dev(x, torch.float32, 'x'),
+        _dev(labels, torch.int64, 'labels'), _dev(out['sum_x'], torch.float64, 'sum_x'),
+        _dev(out['sum_x2'], torch.float64, 'sum_x2'), _dev(out['frame_counts'], torch.int64, 'frame_counts'),
+        _dev(out['span_counts'], torch.int64, 'span_counts'),
+        _dev(out['span_start_counts'], torch.int64, 'span_start_counts'),
+        _dev(out['span_transition_counts'], torch.int64, 'span_transition_counts'),
+        ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    off = lib.smm_fit_error_word_offset(b)
+    out['_err'] = ws[off:off + 4].view(torch.int32)
+    return out

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .semimarkov_utils import semimarkov_sufficient_stats
+from .semimarkov_utils import semimarkov_sufficient_stats, semimarkov_sufficient_stats_device
 
 BIG_NEG = -1e9  # reference semimarkov_modules.py:20
 
@@ -151,10 +151,18 @@ class SemiMarkovModule(nn.Module):
         if self.transition_constraints is not None or self.init_constraints is not None:
             raise NotImplementedError("fit_supervised closed form with constrained state transitions")
         a = self.args
-        em, st = semimarkov_sufficient_stats(feature_list, label_list, 'tied_diag', self.n_classes, self.max_k)
+        # module on the GPU: one HIP pass over the features (csrc/smm_fit.hip); module on the host: the reference's
+        # host statement.  The placement decides, nothing falls back.
+        if self.gaussian_means.is_cuda:
+            stats_fn = lambda f, l: semimarkov_sufficient_stats_device(f, l, 'tied_diag', self.n_classes, self.max_k,
+                                                                       device=self.gaussian_means.device)
+        else:
+            stats_fn = lambda f, l: semimarkov_sufficient_stats(f, l, 'tied_diag', self.n_classes, self.max_k)
+        em, st = stats_fn(feature_list, label_list)
         if self.merge_classes is not None:
-            merged = [torch.as_tensor([self.merge_classes[int(ix)] for ix in labels]) for labels in label_list]
-            em_m, st_m = semimarkov_sufficient_stats(feature_list, merged, 'tied_diag', self.n_classes, self.max_k)
+            table = torch.as_tensor([self.merge_classes[i] for i in range(self.n_classes)], dtype=torch.long)
+            merged = [table.to(torch.as_tensor(labels).device)[torch.as_tensor(labels).long()] for labels in label_list]
+            em_m, st_m = stats_fn(feature_list, merged)
         else:
             em_m, st_m = em, st
         with np.errstate(divide='ignore', invalid='ignore'):

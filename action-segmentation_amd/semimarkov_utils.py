@@ -2,8 +2,10 @@
 
 Mirrors reference ``src/models/semimarkov/semimarkov_utils.py`` (same function names and conventions):
 ``labels_to_spans`` :6, ``rle_spans`` :26, ``spans_to_labels`` :51, ``semimarkov_sufficient_stats`` :74.
-Vectorised host code (these run once per corpus / are not on the device path; the HIP decode kernel
-emits span encodings and frame labels itself).
+The codecs are vectorised host code (the HIP decode kernel emits span encodings and frame labels itself);
+``semimarkov_sufficient_stats`` is the host statement the reference has, ``semimarkov_sufficient_stats_device`` the same
+statistics from one HIP pass over device-resident features (``csrc/smm_fit.hip``), used whenever the module lives on
+the GPU.
 """
 import numpy as np
 import torch
@@ -111,5 +113,50 @@ def semimarkov_sufficient_stats(feature_list, label_list, covariance_type, n_cla
         'span_lengths': span_lengths,
         'span_start_counts': span_start_counts,
         'span_transition_counts': span_transition_counts,
+        'instance_count': len(feature_list),
+    }
+
+
+class _Emissions:
+    pass
+
+
+def _stats_from_sums(sum_x, sum_x2, cnt, n_all, n_classes):
+    """sklearn's one-hot-responsibility estimates (nk = count + 10 eps) and the tied diagonal variance (+1e-6)."""
+    eps10 = 10 * np.finfo(np.float64).eps
+    em = _Emissions()
+    em.means_ = sum_x / (cnt + eps10)[:, None]
+    gmean = sum_x.sum(0) / (n_all + eps10)
+    var = sum_x2 / (n_all + eps10) - gmean ** 2 + 1e-6
+    em.covariances_ = np.tile(var[None], (n_classes, 1))
+    return em
+
+
+def semimarkov_sufficient_stats_device(feature_list, label_list, covariance_type, n_classes, max_k=None, device=None):
+    """``semimarkov_sufficient_stats`` computed on the GPU (no host pass over the features; no CPU fallback).
+
+    ``feature_list`` / ``label_list``: per video T x D fp32 and T int64 tensors (moved to ``device`` if they are not
+    there yet).  Same return value as the host function.
+    """
+    from . import ops
+    assert len(feature_list) == len(label_list)
+    assert covariance_type == 'tied_diag', "only the reference's tied diagonal covariance is built"
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    lengths = [int(f.shape[0]) for f in feature_list]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    x = torch.cat([torch.as_tensor(f).to(device=device, dtype=torch.float32) for f in feature_list]).contiguous()
+    y = torch.cat([torch.as_tensor(l).to(device=device, dtype=torch.int64) for l in label_list]).contiguous()
+    assert x.shape[0] == y.shape[0]
+    out = ops.fit_stats(x, y, lengths, offsets, n_classes, max_k)
+    if int(out['_err'].item()) != 0:
+        raise ValueError("labels outside [0, %d)" % n_classes)
+    host = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith('_')}
+    cnt = host['frame_counts'].astype(np.float64)
+    em = _stats_from_sums(host['sum_x'], host['sum_x2'], cnt, float(x.shape[0]), n_classes)
+    return em, {
+        'span_counts': host['span_counts'].astype(np.float32),
+        'span_lengths': host['frame_counts'].astype(np.float32),      # every frame lies in exactly one span of its label
+        'span_start_counts': host['span_start_counts'].astype(np.float32),
+        'span_transition_counts': host['span_transition_counts'].astype(np.float32),
         'instance_count': len(feature_list),
     }

@@ -171,9 +171,9 @@ def main():
 
     cfg = synth.CONFIGS[a.workload]
     data = synth.SynthDatasplit(a.workload, seed=1000 + rank, device=dev, scale=a.scale)
-    fit_args = synth.make_args(cfg['max_k'], cuda=False, batch_size=cfg['batch_size'])
+    fit_args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'])
     fitted = SemiMarkovModel.from_args(fit_args, data)
-    fitted.fit(data.subset(2), use_labels=True)       # closed-form fit on 2 videos per task: "trained" parameters
+    fitted.fit(data.subset(2), use_labels=True)       # closed-form fit (device statistics) on 2 videos per task
     args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'],
                            sm_constrain_transitions=bool(cfg.get('narration')),
                            sm_constrain_with_narration=['test'] if cfg.get('narration') else [])
@@ -230,6 +230,16 @@ def main():
                                                    optimal_assignment=False, seed=0)
         eval_ms.append((time.perf_counter() - e0) * 1e3)
     summary = evaluation.summarise(stats_by_task, evaluation.STAT_KEYS)
+    # closed-form fit statistics over the whole resident corpus: one HBM pass over the features
+    fit_ms = []
+    for _ in range(4):
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        ops.fit_stats(pc.x, gt_dev, pc.lengths, pc.frame_offset, data.corpus.n_classes, cfg['max_k'])
+        f1.record(stream)
+        torch.cuda.synchronize()
+        fit_ms.append(f0.elapsed_time(f1))
+    fit_bytes = frames * (4 * cfg['d'] + 16)
     lab = labels.numpy()
     correct = sum(int((lab[o:o + n] == data._videos[(tk, nm)]['gt_single'].cpu().numpy()).sum())
                   for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths))
@@ -280,6 +290,12 @@ def main():
                            "what": "accuracy_corpus statistics (confusion + per-video counters on the device, "
                                    "assignment and ratios on the host), all tasks, outside the timed decode",
                            "stats": {k: round(v, 6) for k, v in summary.items()}},
+            "fit_stats": {"ms": min(fit_ms[1:]), "frames_per_s": frames / (min(fit_ms[1:]) * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": fit_bytes / (min(fit_ms[1:]) * 1e-3) / 1e9,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": fit_bytes / (min(fit_ms[1:]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "algorithmic_bytes_per_launch": fit_bytes},
+                          "what": "smm_fit_stats_f64 (class sums + span statistics) over every frame of the workload"},
         }
         if a.workload == 'cfg4':
             res["logz_fwd_bwd"] = train_step_rate(args, data, model)

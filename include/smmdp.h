@@ -221,6 +221,26 @@ int smm_eval_videos_i64(const smm_eval_shape *shape, const int64_t *lengths_host
                         const uint8_t *pred_is_bg, uint32_t seed, int64_t *counters,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Sufficient statistics of the closed-form supervised fit -- semimarkov_utils.semimarkov_sufficient_stats
+ * (reference src/models/semimarkov/semimarkov_utils.py:74-126) as consumed by SemiMarkovModule.fit_supervised
+ * (semimarkov_modules.py:195-256).  One pass over the features (HBM-bound).
+ *   x        dev fp32 [total_frames][d];  labels dev int64 [total_frames] global class ids in [0, n_classes)
+ *   max_k    --sm_max_span_length: a run of one label counts as spans of at most max_k - 1 frames
+ *            (labels_to_spans, utils.py:6-23); <= 0: runs are never cut
+ *   sum_x    dev fp64 [n_classes][d]  per-class feature sums;   sum_x2 dev fp64 [d]  sum of squares over all frames
+ *   frame_counts / span_counts / span_start_counts dev int64 [n_classes];
+ *   span_transition_counts dev int64 [n_classes][n_classes] indexed [to][from]            (all outputs overwritten)
+ * The int32 at smm_fit_error_word_offset(b) in the workspace is non-zero when a label was outside [0, n_classes).
+ */
+size_t smm_fit_workspace_bytes(int32_t b);
+size_t smm_fit_error_word_offset(int32_t b);
+int smm_fit_stats_f64(int32_t b, const int64_t *lengths_host, const int64_t *frame_offset_host, int64_t total_frames,
+                      int32_t d, int32_t n_classes, int32_t max_k, const float *x, const int64_t *labels,
+                      double *sum_x, double *sum_x2, int64_t *frame_counts, int64_t *span_counts,
+                      int64_t *span_start_counts, int64_t *span_transition_counts,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

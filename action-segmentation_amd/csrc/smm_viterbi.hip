@@ -10,22 +10,26 @@
 //
 //   PUSHER waves (waves 1..NW-1), each owning SPW states ("one wavefront per (video, state) row").  The DP runs in
 //   PUSH form so that nothing K-proportional is ever reduced across lanes or leaves the register file:
-//     * ring slot p = n mod RING (RING = 64*R >= kp) holds the accumulator A[n][c] = max_k (h[n-k][c] + len[k][c])
+//     * ring slot p = (n-1) mod RING (RING = 64*R >= kp) holds the accumulator A[n][c] = max_k (h[n-k][c] + len[k][c])
 //       of a future position n, in lane p/R, register p%R of the state's wave;
-//     * when h[s][c] is final it is a wave-uniform scalar; every slot does A = max(A, h[s] + len[k]), k = n - s:
+//     * when h[s][c] is final it is a wave-uniform value; every slot does A = max(A, h[s] + len[k]), k = n - s:
 //       2 fp64 VALU ops per lattice cell (v_add_f64, v_max_f64), nothing else;
 //     * k shrinks by one per step for every slot, so the length table lives in registers too and is ROTATED one slot
-//       per step: R-1 registers are renamed (the loop is unrolled R times, so statically) and one crosses to the next
-//       lane with a single DPP wave_ror:1.
+//       per step: R-1 registers are renamed (the loop is unrolled, so statically) and one crosses to the next lane
+//       with a single DPP wave_ror:1.
 //
 //   one CHAIN wave (wave 0) that owns the serial part for ALL states, one lane per state: cumE += elp, gamma = cumE + A,
 //   the C x C transition, h = beta - cumE, and the history.  The transition is lane = target state: gamma[.] is
 //   broadcast through LDS and every lane folds its own row of the transition table (registers) over it; the two
 //   halves of the wave take half of the source states each and are merged with one v_permlane32_swap.
 //
-// Per frame: pushers do the ONE push the next position depends on, the owner lane hands A[n+1][c] to LDS, barrier 1,
-// then the pushers issue the other R-1 pushes of that frame WHILE the chain wave turns A[n+1][.] into h[n+1][.];
-// barrier 2; pushers read h[n+1][c].  The K-proportional work and the latency-bound serial chain overlap.
+// Hand-over in BLOCKS of B positions, one barrier per block.  The chain wave evaluates the K0 = 2B-1 shortest segment
+// lengths itself (h[n-1..n-K0] and len[1..K0] of its state sit in its registers; only the k = 1 term is on the serial
+// path); the pushers own k > K0 (their length rings hold -inf for k <= K0).  That slack is what decouples the two:
+// during block j the chain turns positions jB+1..(j+1)B into h values from the A' the pushers delivered a block
+// earlier, WHILE the pushers push the B sources of block j-1 through their rings and deliver A' of block j+1 (complete
+// for sources <= n-K0-1).  max is exact, every candidate is the same expression h[s] + len[k] wherever it is evaluated,
+// so the split changes nothing in the result.
 //
 // The forward pass keeps VALUES only.  The arg-max is recovered afterwards along the optimal path only (one row
 // scan per SEGMENT instead of arg-max tracking per cell) from the history, re-evaluating exactly the expressions of
@@ -34,40 +38,8 @@
 // HBM traffic per frame (c states): read elp 8c, write history 24c (cumE, h, gamma; frame-major), label 8 B.
 #include "smm_device.h"
 
-// Diagnostic build only (-DSMM_PROFILE, never shipped or timed): s_memtime stamps around the phases of a frame,
-// summed for workgroup 0 and written behind the workspace's error word (chain wave: +64 B, pusher wave 1: +192 B).
-#ifdef SMM_PROFILE
-#define SMM_STAMP(var)                                                            \
-    do {                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-    } while (0)
-#define SMM_PROF_DECL unsigned long long pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0
-#define SMM_ACC(slot, t_from, t_to) pa[slot] += (t_to) - (t_from)
-#define SMM_PROF_OUT(off)                                                         \
-    if (blockIdx.x == 0 && lane == 0) {                                           \
-        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + (off); \
-        for (int q = 0; q < 8; ++q) pp[q] = pa[q];                                \
-    }
-#define SMM_PROF_FRAME                                                            \
-    do {                                                                          \
-        SMM_ACC(0, q0, q1); SMM_ACC(1, q1, q2); SMM_ACC(2, q2, q3); SMM_ACC(3, q0, q3); \
-        if (q4) SMM_ACC(4, q4, q2);                                               \
-        SMM_ACC(7, 0, 1); q4 = q3;                                                \
-    } while (0)
-#define SMM_PROF_WAVE(wv)                                                         \
-    if (blockIdx.x == 0 && lane == 0) {                                           \
-        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err) + 40 + (wv); \
-        pp[0] = pa[4];                                                            \
-    }
-#else
-#define SMM_PROF_WAVE(wv) do { } while (0)
-#define SMM_PROF_FRAME do { } while (0)
-#define SMM_STAMP(var) do { } while (0)
-#define SMM_PROF_DECL do { } while (0)
-#define SMM_ACC(slot, a, b) do { } while (0)
-#define SMM_PROF_OUT(off) do { } while (0)
+#ifndef SMM_B
+#define SMM_B 4   // positions per hand-over block (development builds override it)
 #endif
 
 // wave-level lexicographic arg-max: larger val first, then smaller k, then smaller c
@@ -88,35 +60,72 @@ __device__ __forceinline__ void smm_wave_best3(double &v, int &k, int &c)
     }
 }
 
-// One frame of one state's ring (source step n, n % R == u after unrolling):
-//   finish the R-1 pushes of h[n-1] that position n+1 did not depend on, rotate the length ring, clear slot n,
-//   do the one push of h[n] that slot n+2 needs and hand A'[n+2] (sources <= n) to LDS.
+// One source step of one state's ring.  Push step t = s + B - 1 (s = source position), u = t mod R (static after
+// unrolling): logical register r of the length ring lives in physical register (r - u) mod R, so a step renames R-1
+// registers and moves one across lanes.
 template <int R>
-__device__ __forceinline__ void smm_ring_frame(double (&A)[R], double (&L)[R], double &hs, double hn, int n, int u,
-                                               int lane, double *apart_slot)
+__device__ __forceinline__ void smm_push(double (&A)[R], double (&L)[R], double hs, int u)
+{
+    // adds and maxes in groups of four independent registers
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += 4) {
+        double tq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < R) tq[q] = hs + L[(r0 + q - u + R) % R];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q < R) A[r0 + q] = smm_fmax(A[r0 + q], tq[q]);
+    }
+    L[(2 * R - 1 - u) % R] = smm_wave_ror1(L[(2 * R - 1 - u) % R]);
+}
+
+// Block j of one state's ring (jj = j mod UB, static): push the B sources of block j-1 (h values from LDS), then
+// hand A' of block j+1 to LDS and clear those slots (everything they still receive before they wrap is -inf).
+template <int R, int B>
+__device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], const double *h_blk, double *a_blk,
+                                               int j, int jj, int lane)
 {
     constexpr int RING = 64 * R;
-    const int r2 = (u + 2) % R;                                  // register of ring slot n+2 (static after unrolling)
-    const bool clear = lane == (n & (RING - 1)) / R;             // lane of ring slot n (register u)
-    const bool hand = lane == ((n + 2) & (RING - 1)) / R;        // lane of ring slot n+2
-    if (n >= 1) {
-        // adds and maxes in groups of four independent registers
+    double hv[B];
 #pragma unroll
-        for (int r0 = 0; r0 < R; r0 += 4) {
-            double tq[4];
+    for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (r0 + q < R) tq[q] = hs + L[(r0 + q - u + 1 + R) % R];
+    for (int i = 0; i < B; ++i) smm_push<R>(A, L, hv[i], (jj * B + i) % R);
+    if constexpr (R % B == 0) {
+        // the B slots share a lane
+        if (lane == (((j + 1) * B) & (RING - 1)) / R) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (r0 + q < R && r0 + q != (u + 1) % R) A[r0 + q] = smm_fmax(A[r0 + q], tq[q]);
+            for (int i = 0; i < B; ++i) {
+                const int r = ((jj + 1) * B + i) % R;
+                a_blk[i * SMM_MAX_STATES_DEV] = A[r];
+                A[r] = SMM_NEG_INF;
+            }
         }
-        L[(R - u) % R] = smm_wave_ror1(L[(R - u) % R]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int r = ((jj + 1) * B + i) % R;
+            if (lane == (((j + 1) * B + i) & (RING - 1)) / R) {
+                a_blk[i * SMM_MAX_STATES_DEV] = A[r];
+                A[r] = SMM_NEG_INF;
+            }
+        }
     }
-    hs = hn;
-    if (clear) A[u] = SMM_NEG_INF;                               // slot n now accumulates position n + RING
-    A[r2] = smm_fmax(A[r2], hs + L[(r2 - u + R) % R]);           // the push slot n+2 waits for
-    if (hand) *apart_slot = A[r2];
+}
+
+// Length ring of one state at push step 0 (source position -(B-1)): slot p waits for k = (p + B) mod RING.
+template <int R, int B>
+__device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], const double *len_col, int cm, int kp,
+                                              bool on, int lane)
+{
+    constexpr int RING = 64 * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = (lane * R + r + B) & (RING - 1);
+        A[r] = SMM_NEG_INF;
+        L[r] = (on && k >= 2 * B && k <= kp - 1) ? len_col[(size_t)k * cm] : SMM_NEG_INF;
+    }
 }
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
@@ -124,13 +133,15 @@ __device__ __forceinline__ void smm_ring_frame(double (&A)[R], double (&L)[R], d
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
-template <int R, int SPW, int NW, int HF, int CP>
+// B   positions per hand-over block (the chain wave then evaluates lengths 1..2B-1 itself)
+template <int R, int SPW, int NW, int HF, int CP, int B>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    constexpr int RING = 64 * R;
+    constexpr int K0 = 2 * B - 1;                          // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
-        const int vid = a.order[blockIdx.x];
+    constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
+    const int vid = a.order[blockIdx.x];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
     const int g = mv.group;
@@ -152,10 +163,13 @@ smm_viterbi_kernel(SmmDpArgs a)
     int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
     int64_t *labels = a.labels ? a.labels + mv.frame_off : nullptr;
 
-    __shared__ __attribute__((aligned(16))) double sh_apart[2][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
-    __shared__ __attribute__((aligned(16))) double sh_h[2][SMM_MAX_STATES_DEV];       // h[n][c]    chain -> pushers
-    __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];        // gamma[n][.] chain-private broadcast
-    __shared__ __attribute__((aligned(16))) double sh_elp[2][64 * SMM_MAX_STATES_DEV];  // elp rows of 64 frames, x2
+    // block q = positions qB+1 .. (q+1)B, buffer q & 1
+    __shared__ __attribute__((aligned(16))) double sh_apart[2][B][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
+    __shared__ __attribute__((aligned(16))) double sh_h[2][B][SMM_MAX_STATES_DEV];       // h[n][c]    chain -> pushers, HBM
+    __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
+    __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
+    __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
+    __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
 
@@ -164,31 +178,29 @@ smm_viterbi_kernel(SmmDpArgs a)
         for (int i = threadIdx.x; i <= a.t_max; i += blockDim.x) spans[i] = -1;
     if (threadIdx.x < SMM_MAX_STATES_DEV) {
         const int c = threadIdx.x;
-        sh_h[0][c] = (c < C) ? init[c] : 0.0;
-        sh_h[1][c] = 0.0;
-        sh_apart[0][c] = SMM_NEG_INF;
-        sh_apart[1][c] = SMM_NEG_INF;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            sh_apart[0][i][c] = SMM_NEG_INF;              // block 0 needs no pusher source
+            sh_apart[1][i][c] = SMM_NEG_INF;
+            sh_h[0][i][c] = SMM_NEG_INF;
+            sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
+            sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
+        }
         sh_gam[c] = SMM_NEG_INF;
         if (c < C) { hcum[c] = 0.0; hh[c] = init[c]; }                             // history of n = 0
     }
-    // elp reaches the chain wave through LDS: the pusher waves copy 64-frame chunks (64*cm contiguous doubles) one
-    // chunk ahead, so the chain wave itself never waits on a vector-memory counter (its history stores stay in flight).
-    {
-        const int nel = ((T < 64) ? T : 64) * cm;
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) sh_elp[0][i] = elp[i];
-    }
     __syncthreads();
 
-    // One barrier per frame.  During frame n (between barrier n and barrier n+1):
-    //   pushers  start the LDS read of h[n] (parity n), finish the pushes of h[n-1] meanwhile, clear ring slot n, do the
-    //            one push of h[n] that slot n+2 needs and hand A'[n+2][c] = max over sources <= n (slot n+2, owner
-    //            lane) to LDS (parity n+2 = n); the other R-1 pushes of h[n] follow after the barrier;
-    //   chain    reads A'[n+1][.] (handed over during frame n-1: sources <= n-1), adds the k = 1 term itself
-    //            (h[n] + len[1], both in its registers), and turns it into gamma[n+1], beta[n+1], h[n+1] (LDS, parity n+1).
-    // So the K-proportional pushes of frame n and the latency-bound serial chain of frame n+1 run side by side.
+    // The chain wave touches LDS only.  HBM traffic is moved block-wise by pusher waves, one role per wave so that no
+    // wave ever has loads and stores in flight together (vmcnt is one in-order counter: a wave that waits for a load
+    // would wait for its older stores as well):  wave 1 fetches the elp rows two blocks ahead (registers for one block,
+    // then LDS), wave 2 stores cumE and h, wave 3 stores gamma -- each a block after the chain wave produced it.
+    // A block is B*cm contiguous doubles in HBM and B rows of SMM_MAX_STATES_DEV in LDS.
+    constexpr int NE = (B * SMM_MAX_STATES_DEV + 63) / 64;   // elements per lane
+    const int J = (T + B - 1) / B;                         // blocks; one barrier each, in every wave
     if (w == 0) {
         // ============================================================================ chain wave
-        // The serial chain is the critical path of every frame; its SIMD partner is a pusher wave with an endless
+        // The serial chain is the critical path of a block; its SIMD partner is a pusher wave with an endless
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
         const int to = lane & 31, half = lane >> 5;
@@ -199,73 +211,73 @@ smm_viterbi_kernel(SmmDpArgs a)
             const int f = half * HF + i;
             tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
         }
-        const double len1 = (live && kp >= 2) ? len[(size_t)cm + to] : SMM_NEG_INF;   // len[1][to]
+        double lk[K0 + 1];                                // len[k][to], k = 1..K0
+#pragma unroll
+        for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
+        double hq[2 * B];                                 // h[n][to] of the last 2B positions, slot n mod 2B
+#pragma unroll
+        for (int i = 0; i < 2 * B; ++i) hq[i] = SMM_NEG_INF;
+        hq[0] = live ? init[to] : SMM_NEG_INF;
         double cum = 0.0;
-        double hcur = live ? init[to] : 0.0;              // h[n][to]
-        double enext = live ? sh_elp[0][to] : 0.0;          // elp[n][to], read one frame ahead
         // own ring (CP): state cx, same code as a pusher with one state
         constexpr int cx = NP * SPW;
         const bool has1 = CP && cx < C;
-        double A1[CP ? R : 1], L1[CP ? R : 1], hs1 = 0.0;
-        if (CP) {
+        double A1[CP ? R : 1], L1[CP ? R : 1];
+        if constexpr (CP) smm_ring_init<R, B>(A1, L1, len + cx, cm, kp, has1, lane);
+        constexpr int UC = CP ? UB : 2;                   // blocks per unrolled chain iteration (even)
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
+        for (int j0 = 0; j0 < J; j0 += UC) {
 #pragma unroll
-            for (int r = 0; r < (CP ? R : 1); ++r) {
-                const int p = lane * R + r;
-                A1[r] = SMM_NEG_INF;
-                L1[r] = (has1 && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + cx] : SMM_NEG_INF;
-            }
-        }
-        SMM_PROF_DECL;
-        for (int n0 = 0; n0 < T; n0 += (CP ? R : 1)) {
+            for (int jj = 0; jj < UC; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                double ap[B], ev[B];
 #pragma unroll
-            for (int u = 0; u < (CP ? R : 1); ++u) {
-                const int n = n0 + u;
-                if (n >= T) break;
-                const double hn1 = (CP && has1) ? smm_readlane(hcur, cx) : 0.0;      // h[n][cx] before it is replaced
-                const double ecurv = enext;
-                const int n1 = n + 1;
-                enext = (live && n1 < T) ? sh_elp[(n1 >> 6) & 1][(n1 & 63) * cm + to] : 0.0;
-                const int nn = n + 1;
-                SMM_STAMP(q0);
-                const double acc = smm_fmax(sh_apart[nn & 1][to], hcur + len1);      // A[nn][to]
-                cum = cum + ecurv;
-                const double gm = cum + acc;
-                if (half == 0 && live) {
-                    sh_gam[to] = gm;
-                    hgam[(size_t)nn * cm + to] = gm;
-                    hcum[(size_t)nn * cm + to] = cum;
+                for (int i = 0; i < B; ++i) {
+                    ap[i] = sh_apart[jj & 1][i][to];
+                    ev[i] = sh_e[jj & 1][i][to];
                 }
-                SMM_STAMP(q1);
-                if (nn < T) {
-                    // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
-                    const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
-                    double bq[4] = {SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF};   // 4 independent max chains
 #pragma unroll
-                    for (int q = 0; q < HF / 2; ++q) {
-                        const double2 gv = gp[q];
-                        bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
-                        bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
-                        // with its own ring the chain wave is register-bound: do not let the scheduler hoist all LDS reads
-                        if (CP && (q & 1)) __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < B; ++i) {
+                    const int n = j * B + 1 + i;           // position; n mod 2B == (jj*B + 1 + i) mod 2B
+                    if (n > T) break;
+                    constexpr int M = 2 * B;
+                    // k = 2..K0 do not depend on h[n-1]: off the serial path
+                    double sq[K0 + 1];
+#pragma unroll
+                    for (int k = 1; k <= K0; ++k) sq[k] = hq[((jj & 1) * B + 1 + i - k + 2 * M) % M] + lk[k];
+                    double acc = ap[i];
+#pragma unroll
+                    for (int k = K0; k >= 1; --k) acc = smm_fmax(acc, sq[k]);
+                    cum = cum + ev[i];
+                    const double gm = cum + acc;
+                    if (half == 0) {
+                        sh_gam[to] = gm;
+                        sh_g[jj & 1][i][to] = gm;
+                        sh_cum[jj & 1][i][to] = cum;
                     }
-                    const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
-                    hcur = beta - cum;
-                    if (half == 0 && live) {
-                        sh_h[nn & 1][to] = hcur;
-                        hh[(size_t)nn * cm + to] = hcur;
+                    if (n < T) {
+                        // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
+                        const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
+                        double bq[4] = {SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF};   // 4 independent max chains
+#pragma unroll
+                        for (int q = 0; q < HF / 2; ++q) {
+                            const double2 gv = gp[q];
+                            bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
+                            bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
+                        }
+                        const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
+                        const double hcur = beta - cum;
+                        hq[((jj & 1) * B + 1 + i) % M] = hcur;
+                        if (half == 0) sh_h[jj & 1][i][to] = hcur;
                     }
                 }
                 if constexpr (CP) {
-                    if (has1) smm_ring_frame<R>(A1, L1, hs1, hn1, n, u, lane, &sh_apart[n & 1][cx]);
+                    if (has1) smm_ring_block<R, B>(A1, L1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj, lane);
                 }
-                SMM_STAMP(q2);
-                __syncthreads();                                           // barrier n+1
-                SMM_STAMP(q3);
-                SMM_PROF_FRAME;
+                __syncthreads();                                           // end of block j
             }
         }
-        SMM_PROF_OUT(8);
-        SMM_PROF_WAVE(0);
     } else {
         // ============================================================================ pusher waves
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
@@ -275,69 +287,80 @@ smm_viterbi_kernel(SmmDpArgs a)
         // (12 waves: every pusher owns SPW states, nothing to rebalance)
         const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
-        double A[SPW][R], L[SPW][R], hs[SPW];
+        double A[SPW][R], L[SPW][R];
 #pragma unroll
-        for (int j = 0; j < SPW; ++j) {
-            const int c = j * NP + rank;
+        for (int js = 0; js < SPW; ++js)
+            smm_ring_init<R, B>(A[js], L[js], len + js * NP + rank, cm, kp, js < nv, lane);
+        // mover role of this wave: block-relative element e = lane + 64 q  <->  HBM offset e, LDS offset (e / cm, e % cm)
+        int lo[NE];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int p = lane * R + r;
-                A[j][r] = SMM_NEG_INF;
-                L[j][r] = (j < nv && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + c] : SMM_NEG_INF;
-            }
-            hs[j] = 0.0;
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            lo[q] = (e < B * cm) ? (e / cm) * SMM_MAX_STATES_DEV + e % cm : -1;
         }
-        constexpr int QMAX = (SMM_MAX_STATES_DEV + NP - 1) / NP;   // chunk elements per pusher thread
-        double pre[QMAX];
+        // wave 1: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
+        // a predicated load has to wait for the previous one into the same register.
+        const int64_t e_last = (int64_t)T * cm - 1;
+        double pre[NE];
+        if (w == 1) {
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) pre[q] = 0.0;
-        const int pidx = (w - 1) * 64 + lane;
-        SMM_PROF_DECL;
-        for (int n0 = 0; n0 < T; n0 += R) {
+            for (int q = 0; q < NE; ++q) {
+                const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
+                pre[q] = elp[e < e_last ? e : e_last];
+            }
+        }
+        // Everything loaded so far (tables, rings) has to have arrived before the loop: the compiler's wait-count
+        // bookkeeping would otherwise carry "maybe pending" into every iteration and make the waves that store the
+        // history wait for their own stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+        // history block q (positions qB+1 .. (q+1)B, rows <= T) from LDS to HBM
+        auto store_block = [&](const double *src, double *dst, int q) {
 #pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const int n = n0 + u;                            // source step; n % R == u
-                if (n >= T) break;
-                if (u == 0 && (n & 31) == 0) {
-                    // next 64-frame chunk of elp: global -> registers at the start of a chunk, -> LDS half a chunk later
-                    const int nbase = (n & ~63) + 64;
-                    const int nel = (T - nbase < 64 ? T - nbase : 64) * cm;        // <= 0 when there is no next chunk
-                    if ((n & 63) == 0) {
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x;
+                if (lo[x] >= 0 && q * B + 1 + e / cm <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+            }
+        };
+        for (int j0 = 0; j0 < J; j0 += UB) {
 #pragma unroll
-                        for (int q = 0; q < QMAX; ++q) {
-                            const int e = pidx + q * NP * 64;
-                            if (e < nel) pre[q] = elp[(size_t)nbase * cm + e];
-                        }
-                    } else {
+            for (int jj = 0; jj < UB; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                if (w == 1) {
+                    // block j+1 (fetched a block ago) -> LDS, then fetch block j+2
+                    double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
-                        for (int q = 0; q < QMAX; ++q) {
-                            const int e = pidx + q * NP * 64;
-                            if (e < nel) sh_elp[(nbase >> 6) & 1][e] = pre[q];
-                        }
+                    for (int q = 0; q < NE; ++q)
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                        pre[q] = elp[e < e_last ? e : e_last];
                     }
+                } else if (w == 2) {
+                    if (j >= 1) {
+                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
+                        store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1);
+                    }
+                } else if (w == 3) {
+                    if (j >= 1) store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                 }
-                SMM_STAMP(q0);
-                double hn[SPW];
 #pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    if (j >= nv) break;
-                    hn[j] = sh_h[n & 1][j * NP + rank];          // h[n][c]  (LDS broadcast read, consumed below)
+                for (int js = 0; js < SPW; ++js) {
+                    if (js >= nv) break;
+                    const int c = js * NP + rank;
+                    smm_ring_block<R, B>(A[js], L[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
                 }
-                // (smm_ring_frame overlaps that read with the R-1 left-over pushes of source n-1)
-                SMM_STAMP(q1);
-#pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    if (j >= nv) break;
-                    smm_ring_frame<R>(A[j], L[j], hs[j], hn[j], n, u, lane, &sh_apart[n & 1][j * NP + rank]);
-                }
-                SMM_STAMP(q2);
-                __syncthreads();                                 // barrier n+1
-                SMM_STAMP(q3);
-                SMM_PROF_FRAME;
+                __syncthreads();                                 // end of block j
             }
         }
-        if (w == 1) { SMM_PROF_OUT(24); }
-        SMM_PROF_WAVE(w);
+        // the last block's history
+        if (w == 2) {
+            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
+            store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1);
+        } else if (w == 3) {
+            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
+        }
     }
 
     // -------------------------------------------------------------------------------- last position
@@ -437,8 +460,10 @@ template <int R, int SPW, int NW>
 static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_t stream)
 {
     if (spw != SPW || nw != NW) return 0;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0>), dim3(a.b), dim3(NW * 64), 0, stream, a);
-    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
+    constexpr int B = (NW == 16 && R >= 8) ? 2 : SMM_B;
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     return 1;
 }
 
@@ -458,7 +483,7 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     if constexpr (R == 16) {
         // 22..23 states at K > 512: 12 waves (170 VGPRs each) = 11 pushers x 2 states + the chain wave's own ring
         if (nw == 16 && c_need <= 23) {
-            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 16, 1>), dim3(a.b), dim3(12 * 64), 0, stream, a);
+            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 16, 1, 2>), dim3(a.b), dim3(12 * 64), 0, stream, a);
             return SMM_OK;
         }
     }
@@ -490,12 +515,19 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)
 {
+    // SMM_DEV_R (development builds only): instantiate one ring size, for quick compile-measure cycles
+#ifndef SMM_DEV_R
+#define SMM_DEV_R 0
+#endif
+#define SMM_CASE_R(rr) case rr: if constexpr (SMM_DEV_R == 0 || SMM_DEV_R == rr) return launch_r<rr>(a, c_need, stream); else break;
     switch (r) {
-    case 1: return launch_r<1>(a, c_need, stream);
-    case 2: return launch_r<2>(a, c_need, stream);
-    case 4: return launch_r<4>(a, c_need, stream);
-    case 8: return launch_r<8>(a, c_need, stream);
-    case 16: return launch_r<16>(a, c_need, stream);
-    default: return SMM_ERR_UNSUPPORTED;
+    SMM_CASE_R(1)
+    SMM_CASE_R(2)
+    SMM_CASE_R(4)
+    SMM_CASE_R(8)
+    SMM_CASE_R(16)
+    default: break;
     }
+#undef SMM_CASE_R
+    return SMM_ERR_UNSUPPORTED;
 }

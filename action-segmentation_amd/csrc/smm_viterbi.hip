@@ -38,8 +38,34 @@
 // HBM traffic per frame (c states): read elp 8c, write history 24c (cumE, h, gamma; frame-major), label 8 B.
 #include "smm_device.h"
 
+// Diagnostic build only (-DSMM_PROFILE, never shipped or timed): per wave of workgroup 0, cycles between leaving a
+// block barrier and arriving at the next one ("busy") and cycles spent in the barrier, summed over the blocks and
+// written behind the workspace's error word (uint64 slots 8+w and 24+w; slot 7 = number of blocks).
+#ifdef SMM_PROFILE
+#define SMM_PROF_DECL unsigned long long p_busy = 0, p_wait = 0, p_t0 = __builtin_readcyclecounter()
+#define SMM_BLOCK_BARRIER()                                                        \
+    do {                                                                          \
+        const unsigned long long t1 = __builtin_readcyclecounter();               \
+        __syncthreads();                                                          \
+        const unsigned long long t2 = __builtin_readcyclecounter();               \
+        p_busy += t1 - p_t0; p_wait += t2 - t1; p_t0 = t2;                        \
+    } while (0)
+#define SMM_PROF_OUT()                                                            \
+    if (blockIdx.x == 0 && lane == 0) {                                           \
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err);   \
+        pp[8 + w] = p_busy; pp[24 + w] = p_wait; pp[7] = (unsigned long long)J;   \
+    }
+#else
+#define SMM_PROF_DECL do { } while (0)
+#define SMM_BLOCK_BARRIER() __syncthreads()
+#define SMM_PROF_OUT() do { } while (0)
+#endif
+
 #ifndef SMM_B
 #define SMM_B 4   // positions per hand-over block (development builds override it)
+#endif
+#ifndef SMM_D
+#define SMM_D 1
 #endif
 
 // wave-level lexicographic arg-max: larger val first, then smaller k, then smaller c
@@ -80,18 +106,27 @@ __device__ __forceinline__ void smm_push(double (&A)[R], double (&L)[R], double 
     L[(2 * R - 1 - u) % R] = smm_wave_ror1(L[(2 * R - 1 - u) % R]);
 }
 
-// Block j of one state's ring (jj = j mod UB, static): push the B sources of block j-1 (h values from LDS), then
-// hand A' of block j+1 to LDS and clear those slots (everything they still receive before they wrap is -inf).
-template <int R, int B>
-__device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], const double *h_blk, double *a_blk,
-                                               int j, int jj, int lane)
+// Block j of one state's ring (jj = j mod UB, static): push B sources, then hand A' of block j+1 to LDS and clear
+// those slots (everything they still receive before they wrap is -inf).  D = 1: the first source is the LAST row of the
+// previous block, kept in a register (hd), so the pushes that follow a barrier do not wait for LDS; the last row of
+// this block is kept for the next one.
+template <int R, int B, int D>
+__device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], double &hd, const double *h_blk,
+                                               double *a_blk, int j, int jj, int lane)
 {
     constexpr int RING = 64 * R;
     double hv[B];
 #pragma unroll
     for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
+    if constexpr (D == 1) {
+        smm_push<R>(A, L, hd, (jj * B) % R);
 #pragma unroll
-    for (int i = 0; i < B; ++i) smm_push<R>(A, L, hv[i], (jj * B + i) % R);
+        for (int i = 1; i < B; ++i) smm_push<R>(A, L, hv[i - 1], (jj * B + i) % R);
+        hd = hv[B - 1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < B; ++i) smm_push<R>(A, L, hv[i], (jj * B + i) % R);
+    }
     if constexpr (R % B == 0) {
         // the B slots share a lane
         if (lane == (((j + 1) * B) & (RING - 1)) / R) {
@@ -114,17 +149,18 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], c
     }
 }
 
-// Length ring of one state at push step 0 (source position -(B-1)): slot p waits for k = (p + B) mod RING.
-template <int R, int B>
+// Length ring of one state at push step 0 (source position -(B-1+D)): slot p waits for k = (p + B + D) mod RING;
+// lengths up to K0 = 2B+D-1 belong to the chain wave.
+template <int R, int B, int D>
 __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], const double *len_col, int cm, int kp,
                                               bool on, int lane)
 {
     constexpr int RING = 64 * R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int k = (lane * R + r + B) & (RING - 1);
+        const int k = (lane * R + r + B + D) & (RING - 1);
         A[r] = SMM_NEG_INF;
-        L[r] = (on && k >= 2 * B && k <= kp - 1) ? len_col[(size_t)k * cm] : SMM_NEG_INF;
+        L[r] = (on && k >= 2 * B + D && k <= kp - 1) ? len_col[(size_t)k * cm] : SMM_NEG_INF;
     }
 }
 
@@ -133,14 +169,17 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
-// B   positions per hand-over block (the chain wave then evaluates lengths 1..2B-1 itself)
-template <int R, int SPW, int NW, int HF, int CP, int B>
+// B   positions per hand-over block; D = 1: pushers lag one more source (see smm_ring_block); the chain wave evaluates
+//     lengths 1..2B+D-1 itself
+template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    constexpr int K0 = 2 * B - 1;                          // segment lengths the chain wave evaluates itself
+    constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
+    constexpr int M = (D ? 4 : 2) * B;                     // chain wave: h[n] of the last M > K0 positions, slot n mod M
+    constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
     const int vid = a.order[blockIdx.x];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
@@ -191,10 +230,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
     __syncthreads();
 
-    // The chain wave touches LDS only.  HBM traffic is moved block-wise by pusher waves, one role per wave so that no
-    // wave ever has loads and stores in flight together (vmcnt is one in-order counter: a wave that waits for a load
-    // would wait for its older stores as well):  wave 1 fetches the elp rows two blocks ahead (registers for one block,
-    // then LDS), wave 2 stores cumE and h, wave 3 stores gamma -- each a block after the chain wave produced it.
+    // The chain wave touches LDS only (a wave that waits for a load waits for its older stores as well: vmcnt is one
+    // in-order counter).  HBM traffic is moved block-wise by pusher wave MW: it fetches the elp rows two blocks ahead
+    // (registers for one block, then LDS) and stores cumE, h and gamma a block after the chain wave produced them.
     // A block is B*cm contiguous doubles in HBM and B rows of SMM_MAX_STATES_DEV in LDS.
     constexpr int NE = (B * SMM_MAX_STATES_DEV + 63) / 64;   // elements per lane
     const int J = (T + B - 1) / B;                         // blocks; one barrier each, in every wave
@@ -214,17 +252,19 @@ smm_viterbi_kernel(SmmDpArgs a)
         double lk[K0 + 1];                                // len[k][to], k = 1..K0
 #pragma unroll
         for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
-        double hq[2 * B];                                 // h[n][to] of the last 2B positions, slot n mod 2B
+        double hq[M];                                     // h[n][to], slot n mod M
 #pragma unroll
-        for (int i = 0; i < 2 * B; ++i) hq[i] = SMM_NEG_INF;
+        for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
         hq[0] = live ? init[to] : SMM_NEG_INF;
         double cum = 0.0;
         // own ring (CP): state cx, same code as a pusher with one state
         constexpr int cx = NP * SPW;
         const bool has1 = CP && cx < C;
-        double A1[CP ? R : 1], L1[CP ? R : 1];
-        if constexpr (CP) smm_ring_init<R, B>(A1, L1, len + cx, cm, kp, has1, lane);
-        constexpr int UC = CP ? UB : 2;                   // blocks per unrolled chain iteration (even)
+        double A1[CP ? R : 1], L1[CP ? R : 1], hd1 = SMM_NEG_INF;
+        if constexpr (CP) smm_ring_init<R, B, D>(A1, L1, len + cx, cm, kp, has1, lane);
+        constexpr int UM = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even,
+        constexpr int UC = (CP && UB > UM) ? UB : UM;     // and a multiple of UB when the wave owns a ring
+        SMM_PROF_DECL;
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
         for (int j0 = 0; j0 < J; j0 += UC) {
 #pragma unroll
@@ -239,13 +279,12 @@ smm_viterbi_kernel(SmmDpArgs a)
                 }
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
-                    const int n = j * B + 1 + i;           // position; n mod 2B == (jj*B + 1 + i) mod 2B
+                    const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
                     if (n > T) break;
-                    constexpr int M = 2 * B;
                     // k = 2..K0 do not depend on h[n-1]: off the serial path
                     double sq[K0 + 1];
 #pragma unroll
-                    for (int k = 1; k <= K0; ++k) sq[k] = hq[((jj & 1) * B + 1 + i - k + 2 * M) % M] + lk[k];
+                    for (int k = 1; k <= K0; ++k) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
                     double acc = ap[i];
 #pragma unroll
                     for (int k = K0; k >= 1; --k) acc = smm_fmax(acc, sq[k]);
@@ -268,16 +307,17 @@ smm_viterbi_kernel(SmmDpArgs a)
                         }
                         const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
                         const double hcur = beta - cum;
-                        hq[((jj & 1) * B + 1 + i) % M] = hcur;
+                        hq[(jj * B + 1 + i) % M] = hcur;
                         if (half == 0) sh_h[jj & 1][i][to] = hcur;
                     }
                 }
                 if constexpr (CP) {
-                    if (has1) smm_ring_block<R, B>(A1, L1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj, lane);
+                    if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane);
                 }
-                __syncthreads();                                           // end of block j
+                SMM_BLOCK_BARRIER();                                       // end of block j
             }
         }
+        SMM_PROF_OUT();
     } else {
         // ============================================================================ pusher waves
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
@@ -287,22 +327,25 @@ smm_viterbi_kernel(SmmDpArgs a)
         // (12 waves: every pusher owns SPW states, nothing to rebalance)
         const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
-        double A[SPW][R], L[SPW][R];
+        double A[SPW][R], L[SPW][R], hd[SPW];
 #pragma unroll
-        for (int js = 0; js < SPW; ++js)
-            smm_ring_init<R, B>(A[js], L[js], len + js * NP + rank, cm, kp, js < nv, lane);
+        for (int js = 0; js < SPW; ++js) {
+            smm_ring_init<R, B, D>(A[js], L[js], len + js * NP + rank, cm, kp, js < nv, lane);
+            hd[js] = SMM_NEG_INF;
+        }
         // mover role of this wave: block-relative element e = lane + 64 q  <->  HBM offset e, LDS offset (e / cm, e % cm)
-        int lo[NE];
+        int lo[NE], row[NE];
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
             const int e = lane + 64 * q;
-            lo[q] = (e < B * cm) ? (e / cm) * SMM_MAX_STATES_DEV + e % cm : -1;
+            row[q] = e / cm;
+            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
         }
         // wave 1: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
         const int64_t e_last = (int64_t)T * cm - 1;
         double pre[NE];
-        if (w == 1) {
+        if (w == MW) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
@@ -318,15 +361,16 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
             for (int x = 0; x < NE; ++x) {
                 const int e = lane + 64 * x;
-                if (lo[x] >= 0 && q * B + 1 + e / cm <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
             }
         };
+        SMM_PROF_DECL;
         for (int j0 = 0; j0 < J; j0 += UB) {
 #pragma unroll
             for (int jj = 0; jj < UB; ++jj) {
                 const int j = j0 + jj;
                 if (j >= J) break;
-                if (w == 1) {
+                if (w == MW) {
                     // block j+1 (fetched a block ago) -> LDS, then fetch block j+2
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
@@ -337,28 +381,26 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
                         pre[q] = elp[e < e_last ? e : e_last];
                     }
-                } else if (w == 2) {
                     if (j >= 1) {
                         store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
                         store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1);
+                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                     }
-                } else if (w == 3) {
-                    if (j >= 1) store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                 }
 #pragma unroll
                 for (int js = 0; js < SPW; ++js) {
                     if (js >= nv) break;
                     const int c = js * NP + rank;
-                    smm_ring_block<R, B>(A[js], L[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
+                    smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
                 }
-                __syncthreads();                                 // end of block j
+                SMM_BLOCK_BARRIER();                             // end of block j
             }
         }
+        SMM_PROF_OUT();
         // the last block's history
-        if (w == 2) {
+        if (w == MW) {
             store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
             store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1);
-        } else if (w == 3) {
             store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
         }
     }

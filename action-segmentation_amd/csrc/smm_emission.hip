@@ -20,30 +20,41 @@
 //       {d0 + 4k + j}.  Any feature <-> (j, k) assignment is valid as long as B uses the same one.
 //   B operand (lane l): w[d0 + 4 (l >> 4) + j][s0 + (l & 15)]  from an LDS copy of the group's weight table.
 //   C/D (lane l, reg i): frame f0 + (l >> 4) + 4 i, state s0 + (l & 15)  -> 128-B contiguous row pieces on store.
-// One workgroup = 4 waves on one video; every wave walks 16-frame tiles with a grid stride.
+// One workgroup = 8 waves on one video sharing the LDS copy of the weights (2 workgroups per CU at D = 200, 32 states:
+// 4 waves per SIMD); every wave walks 16-frame tiles with a grid stride.  The kernel is bound by HBM latency unless
+// enough bytes are in flight: x is fetched in CHUNKS of 4 macro-steps (4 KB per wave) through a 3-deep register
+// pipeline that runs across tile boundaries -- two chunks are always in flight while the third feeds the MFMAs.
 typedef double smm_d4 __attribute__((ext_vector_type(4)));
 
-template <int NT>   // state tiles of 16 (1: C <= 16, 2: C <= 32)
-__global__ void __launch_bounds__(256)
-smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ n_states,
+#define SMM_EM_WAVES 8
+#define SMM_EM_TILES_PER_WAVE 8
+
+// NT   state tiles of 16 (1: C <= 16, 2: C <= 32)        VEC  D % 4 == 0: 16-byte loads of x
+// CONS narration constraints are added (they travel through the same pipeline as x: a load in the epilogue would make
+//      the wave wait for every x load in flight)
+template <int NT, bool VEC, bool CONS>
+__global__ void __launch_bounds__(SMM_EM_WAVES * 64)
+smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
-                    float *__restrict__ elp32, int D, int cm)
+                    float *__restrict__ elp32, int D, int cm, int tpw)
 {
     extern __shared__ __attribute__((aligned(16))) double wl[];      // [D16][16*NT + 1]: this group's weights (zero padded) | inv_var
-    const int vid = blockIdx.y;
+    const int vid = order[blockIdx.y];                               // longest videos first: no long workgroup starts late
     const SmmVideo mv = videos[vid];
     const int T = mv.T, g = mv.group;
     const int C = n_states[g];
     const int ntiles = (T + 15) >> 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)(blockIdx.x * 4) >= ntiles) return;                     // whole block has nothing to do
+    // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
+    const int nbv = (ntiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw);
+    if ((int)blockIdx.x >= nbv) return;
     const int D16 = (D + 15) & ~15;
     constexpr int WS = 16 * NT + 1;                                  // LDS row stride (doubles): weights + inv_var
     const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // state tiles this video really needs
     {
         const double *__restrict__ w = wall + (size_t)g * D * cm;
-        for (int i = threadIdx.x; i < D16 * WS; i += 256) {
+        for (int i = threadIdx.x; i < D16 * WS; i += SMM_EM_WAVES * 64) {
             const int d = i / WS, c = i - d * WS;
             wl[i] = (d >= D) ? 0.0 : ((c == 16 * NT) ? iv[d] : ((c < C) ? w[(size_t)d * cm + c] : 0.0));
         }
@@ -53,45 +64,89 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     const float *__restrict__ xv = xall + (size_t)mv.frame_off * D;
     const double *__restrict__ cst = cstall + (size_t)g * cm;
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int f0 = tile << 4;
+    const int tile0 = blockIdx.x * SMM_EM_WAVES + wave, tstride = nbv * SMM_EM_WAVES;
+    if (tile0 >= ntiles) return;
+    const int nmy = (ntiles - tile0 + tstride - 1) / tstride;        // tiles of this wave
+    const int nms = D16 >> 4;                                        // macro-steps of 16 features per tile
+    const int nch = (nms + 3) >> 2;                                  // chunks of 4 macro-steps per tile
+    const int total = nmy * nch;                                     // chunk sequence of this wave
+
+    // fetch side of the pipeline: chunk (lt, lc) = tile tile0 + lt * tstride, macro-steps 4 lc .. 4 lc + 3
+    int lt = 0, lc = 0;
+    // (branch-free on the vector path: tiles past the end re-read the last tile, macro-steps past the end re-read the
+    // last macro-step -- cache hits that are never consumed -- so that the compiler can count the loads in flight
+    // instead of waiting for all of them)
+    auto fetch = [&](float4 (&buf)[4], float (&cb)[CONS ? 4 * NT : 1]) {
+        const int ltc = lt < nmy ? lt : nmy - 1;
+        const int f0 = (tile0 + ltc * tstride) << 4;
         const int f = (f0 + fr < T) ? f0 + fr : T - 1;               // clamp: rows past the end are computed, not stored
         const float *__restrict__ xrow = xv + (size_t)f * D;
-        smm_d4 acc[NT];
+        if constexpr (CONS) {
+            // constraints of this chunk's tile in the accumulator layout (used by the tile's last chunk only)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
-        double q = 0.0;
-        auto load4 = [&](int d0) -> float4 {
-            const int db = d0 + 4 * kq;                              // this lane's 4 features of the macro-step
-            float4 r;
-            if (db + 3 < D && (D & 3) == 0) {
-                r = *reinterpret_cast<const float4 *>(xrow + db);
-            } else {
+            for (int i = 0; i < 4; ++i) {
+                const int ff = f0 + kq + 4 * i;
+                const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = 16 * t + fr;
+                    cb[4 * t + i] = cons[rowo + (c < cm ? c : cm - 1)];
+                }
+            }
+        }
+        if constexpr (VEC) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int ms = (4 * lc + m < nms) ? 4 * lc + m : nms - 1;
+                int db = 16 * ms + 4 * kq;                           // this lane's 4 features of the macro-step
+                db = db + 3 < D ? db : D - 4;                        // (the zero-padded weights ignore what is read there)
+                buf[m] = *reinterpret_cast<const float4 *>(xrow + db);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int db = 16 * (4 * lc + m) + 4 * kq;
+                float4 r;
                 r.x = (db + 0 < D) ? xrow[db + 0] : 0.f;
                 r.y = (db + 1 < D) ? xrow[db + 1] : 0.f;
                 r.z = (db + 2 < D) ? xrow[db + 2] : 0.f;
                 r.w = (db + 3 < D) ? xrow[db + 3] : 0.f;
-            }
-            return r;
-        };
-        float4 xn1 = load4(0), xn2 = load4(16);                      // two macro-steps of x in flight ahead of the MFMAs
-        for (int d0 = 0; d0 < D16; d0 += 16) {
-            const int db = d0 + 4 * kq;
-            const float4 x4 = xn1;
-            xn1 = xn2;
-            xn2 = load4(d0 + 32);
-            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double a = (double)xs[j];
-                const int d = db + j;
-                q = fma(a * wl[(size_t)d * WS + 16 * NT], a, q);
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
-                if (NT == 2 && nt == 2)
-                    acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + 16 + fr], acc[NT - 1], 0, 0, 0);
+                buf[m] = r;
             }
         }
-        // q: this lane summed the features with k index kq of frame fr; add the four k groups (lanes fr + 16 k)
+        if (++lc == nch) { lc = 0; ++lt; }
+    };
+
+    // compute side
+    int ct = 0, cc = 0;
+    smm_d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+    double q = 0.0;
+    double cstv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cstv[t] = (16 * t + fr < C) ? cst[16 * t + fr] : 0.0;
+    auto consume = [&](const float4 (&buf)[4], const float (&cb)[CONS ? 4 * NT : 1]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ms = 4 * cc + m;
+            if (ms < nms) {
+                const int db = 16 * ms + 4 * kq;
+                const float xs[4] = {buf[m].x, buf[m].y, buf[m].z, buf[m].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double a = (double)xs[j];
+                    const int d = db + j;
+                    q = fma(a * wl[(size_t)d * WS + 16 * NT], a, q);
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
+                    if (NT == 2 && nt == 2)
+                        acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + 16 + fr], acc[NT - 1], 0, 0, 0);
+                }
+            }
+        }
+        if (++cc < nch) return;
+        // tile finished.  q: this lane summed the features with k index kq of frame fr; add the four k groups
+        const int f0 = (tile0 + ct * tstride) << 4;
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
 #pragma unroll
@@ -105,14 +160,34 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                     const int c = 16 * t + fr;
                     if (c < C) {
                         const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
-                        double v = (cst[c] + acc[t][i]) - 0.5 * qr;
-                        if (cons) v += (double)cons[o];
+                        double v = (cstv[t] + acc[t][i]) - 0.5 * qr;
+                        if constexpr (CONS) v += (double)cb[4 * t + i];
                         if (elp64) elp64[o] = v;
                         if (elp32) elp32[o] = (float)v;
                     }
                 }
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+        q = 0.0;
+        cc = 0;
+        ++ct;
+    };
+
+    float4 b0[4], b1[4], b2[4];
+    float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1], c2[CONS ? 4 * NT : 1];
+    fetch(b0, c0);
+    fetch(b1, c1);
+    for (int it = 0; it < total; it += 3) {
+        fetch(b2, c2);
+        consume(b0, c0);
+        if (it + 1 >= total) break;
+        fetch(b0, c0);
+        consume(b1, c1);
+        if (it + 2 >= total) break;
+        fetch(b1, c1);
+        consume(b2, c2);
     }
 }
 
@@ -124,26 +199,35 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
     for (; i < n; i += stride) dst[i] = (double)src[i];
 }
 
-void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, hipStream_t stream)
+void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, int64_t total_frames, hipStream_t stream)
 {
     const int d16 = (a.d + 15) & ~15;
     const int tiles = (t_max + 15) / 16;
-    int bx = (tiles + 4 * 8 - 1) / (4 * 8);                 // ~8 tiles per wave: amortises the LDS fill of the weights
+    // up to 8 tiles per wave (amortises the LDS fill of the weights), fewer when that would leave CUs without a
+    // workgroup: aim at >= 2 workgroups on each of the 256 CUs
+    int64_t tpw = (total_frames / 16 + a.b) / (512 * SMM_EM_WAVES);
+    tpw = tpw < 1 ? 1 : (tpw > SMM_EM_TILES_PER_WAVE ? SMM_EM_TILES_PER_WAVE : tpw);
+    int bx = (int)((tiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw));
     if (bx < 1) bx = 1;
-    dim3 grid(bx, a.b), block(256);
+    dim3 grid(bx, a.b), block(SMM_EM_WAVES * 64);
     const size_t lds = sizeof(double) * d16 * (ct <= 16 ? 17 : 33);          // <= 160 KiB checked by the caller
-    if (ct <= 16) {
+    const bool vec = (a.d & 3) == 0;
+    auto go = [&](auto kern) {
         if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_emission_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(smm_emission_kernel<1>, grid, block, lds, stream, a.videos, a.n_states, a.x, a.w, a.cst,
-                           a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max);
-    } else {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_emission_kernel<2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(smm_emission_kernel<2>, grid, block, lds, stream, a.videos, a.n_states, a.x, a.w, a.cst,
-                           a.inv_var, a.cons, a.elp64, a.elp32, a.d, a.c_max);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
+                           a.elp64, a.elp32, a.d, a.c_max, (int)tpw);
+    };
+    const int sel = (ct <= 16 ? 0 : 4) + (vec ? 2 : 0) + (a.cons ? 1 : 0);
+    switch (sel) {
+    case 0: go(smm_emission_kernel<1, false, false>); break;
+    case 1: go(smm_emission_kernel<1, false, true>); break;
+    case 2: go(smm_emission_kernel<1, true, false>); break;
+    case 3: go(smm_emission_kernel<1, true, true>); break;
+    case 4: go(smm_emission_kernel<2, false, false>); break;
+    case 5: go(smm_emission_kernel<2, false, true>); break;
+    case 6: go(smm_emission_kernel<2, true, false>); break;
+    default: go(smm_emission_kernel<2, true, true>); break;
     }
 }
 

@@ -4,6 +4,7 @@
 
 struct SmmEmArgs {
     const SmmVideo *videos;
+    const int32_t *order;    // [b] block -> video (most work first)
     const int32_t *n_states;
     const float *x;          // [total_frames][d]
     const double *w;         // [g][d][c_max]
@@ -15,7 +16,7 @@ struct SmmEmArgs {
     int32_t d, c_max, b;
 };
 
-void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, hipStream_t stream);
+void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, int64_t total_frames, hipStream_t stream);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);

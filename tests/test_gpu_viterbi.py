@@ -74,6 +74,10 @@ SHAPES = [
     (3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64), (3, 200, 7, 65),
     (2, 300, 17, 130), (2, 600, 20, 300), (1, 1300, 23, 600), (2, 150, 32, 40), (1, 2100, 11, 1024),
     (2, 64, 4, 2), (3, 65, 1, 5), (2, 2, 3, 4),
+    # hand-over blocks of the chain / pusher split: every ring size with lengths that end inside a block, the
+    # 8-wave / 12-wave (22..23 states) / 16-wave configurations at K > 512, ring wrap-around
+    (2, 1030, 21, 1024), (1, 1100, 28, 1024), (2, 530, 22, 513), (1, 2200, 5, 1024), (2, 260, 21, 256),
+    (2, 9, 3, 3), (3, 7, 2, 20), (3, 3, 3, 4), (2, 515, 9, 400),
 ]
 
 

@@ -1,5 +1,6 @@
 // smm_api.hip -- host side of libsmmdp.so: argument checks, launch planning, C ABI (include/smmdp.h).
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -43,9 +44,11 @@ extern "C" int smm_device_count(void)
 // ------------------------------------------------------------------------------------------------ planning
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+#define SMM_MAX_PAIRS 256
+
 struct SmmPlan {
-    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err
-    size_t o_order, o_nstates, o_err;
+    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err | pair progress counters
+    size_t o_order, o_nstates, o_err, o_pflags;
     size_t hist_doubles;   // sum over videos of 8*c_max*(T+1): forward cumE/h/gamma, backward cumE/h/gamma, 2 transposes
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
@@ -63,7 +66,8 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
     p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
-    p.meta_bytes = p.o_err + 512;   // error word + diagnostic counters
+    p.o_pflags = p.o_err + 512;     // error word + diagnostic counters, then 2 counters per leader / follower pair
+    p.meta_bytes = p.o_pflags + align_up(sizeof(int32_t) * 2 * (size_t)std::min(s->b, SMM_MAX_PAIRS), 256);
     size_t h = 0;
     for (int i = 0; i < s->b; ++i) h += 8 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;
@@ -96,8 +100,62 @@ struct Staged {
     double *hist;
     double *elp;
     double *tabs;
+    int32_t *pair_flags;
     int kp_max, c_need;
+    int n_pairs;           // Viterbi only: the first n_pairs videos of `order` may run on two CUs each
 };
+
+// Two-CU pairs for the longest videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the time of its longest
+// videos while other CUs idle; a paired video runs ~1.7x faster on two CUs.  Cost model in ns per frame (measured on
+// MI355X at K = 1024): one CU: the most loaded SIMD's states x 73, at least the chain wave's 230; two CUs: the chain
+// wave's latency, 265 (<= 16 states) or 355 (its transition step folds 16 sources per half-wave instead of 8).
+// n_pairs = the count (all pairs within the first wave of workgroups: 2 n_pairs <= CUs, so leader and follower are
+// co-resident) that minimises the simulated makespan of a longest-first list schedule.
+static double frame_ns_single(int c)
+{
+    int nv[7];
+    for (int r = 0; r < 7; ++r) nv[r] = c > r ? (c - r + 6) / 7 : 0;
+    const int load = std::max(std::max(nv[0] + nv[4], nv[1] + nv[5]), nv[2] + nv[3]);
+    return std::max(230.0, 73.0 * load) + 5.0;
+}
+
+static int choose_pairs(const SmmVideo *hv, const int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need)
+{
+    if (const char *e = std::getenv("SMM_PAIRS")) {
+        const int v = std::atoi(e);
+        if (v >= 0) return std::min(std::min(v, b), SMM_MAX_PAIRS);
+    }
+    if (kp_max <= 512 || c_need > 21 || std::getenv("SMM_NW")) return 0;   // pair mode exists for 1024-slot rings, 8 waves
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    int eligible = 0;                                                        // a prefix of the order
+    while (eligible < b && eligible < SMM_MAX_PAIRS && 2 * (eligible + 1) <= n_cu) {
+        const SmmVideo &v = hv[order[eligible]];
+        if (v.T < 1024 || v.kp < 256 || n_states[v.group] < 4) break;
+        ++eligible;
+    }
+    int best_n = 0;
+    double best_t = 1e300;
+    std::vector<double> cu(n_cu);
+    for (int n = 0; n <= eligible; n += (n < 8 ? 1 : (n < 32 ? 4 : 8))) {
+        std::fill(cu.begin(), cu.end(), 0.0);
+        // pairs occupy CUs 2i, 2i+1 from time 0; the rest is list-scheduled on the earliest free CU
+        for (int i = 0; i < n; ++i)
+            cu[2 * i] = cu[2 * i + 1] = hv[order[i]].T * (n_states[hv[order[i]].group] > 16 ? 355.0 : 265.0);
+        std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+        for (int i = n; i < b; ++i) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += hv[order[i]].T * frame_ns_single(n_states[hv[order[i]].group]);
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+        }
+        const double t = *std::max_element(cu.begin(), cu.end());
+        if (t < best_t * 0.97) { best_t = t; best_n = n; }                   // pair only for a clear gain
+    }
+    return best_n;
+}
+
+
 
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
@@ -143,6 +201,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         return (int64_t)hv[a].T * n_states[hv[a].group] > (int64_t)hv[b].T * n_states[hv[b].group];
     });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
+    out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need);
 
     char *base = static_cast<char *>(ws);
     // pageable source: the runtime copies it out before returning, so `host` may die with this frame
@@ -151,6 +210,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     out->order = reinterpret_cast<int32_t *>(base + p.o_order);
     out->n_states = reinterpret_cast<int32_t *>(base + p.o_nstates);
     out->err = reinterpret_cast<int32_t *>(base + p.o_err);
+    out->pair_flags = reinterpret_cast<int32_t *>(base + p.o_pflags);
     out->hist = reinterpret_cast<double *>(base + p.meta_bytes);
     out->elp = out->hist + p.hist_doubles;
     out->tabs = out->elp + p.elp_doubles;
@@ -193,6 +253,8 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling aid, see SmmDpArgs::flags
         a.flags = dbg ? std::atoi(dbg) : 0;
     }
+    a.n_pairs = st.n_pairs;
+    a.pair_flags = st.pair_flags;
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());

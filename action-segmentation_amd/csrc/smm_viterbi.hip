@@ -137,6 +137,16 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
                 A[r] = SMM_NEG_INF;
             }
         }
+    } else if constexpr (B % R == 0) {
+        // the B slots are all R registers of B/R consecutive lanes
+        const int d = lane - (((j + 1) * B) & (RING - 1)) / R;
+        if (d >= 0 && d < B / R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a_blk[(d * R + r) * SMM_MAX_STATES_DEV] = A[r];
+                A[r] = SMM_NEG_INF;
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
@@ -149,18 +159,181 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
     }
 }
 
-// Length ring of one state at push step 0 (source position -(B-1+D)): slot p waits for k = (p + B + D) mod RING;
-// lengths up to K0 = 2B+D-1 belong to the chain wave.
-template <int R, int B, int D>
-__device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], const double *len_col, int cm, int kp,
-                                              bool on, int lane)
+// Length ring of one state at push step 0: slot p waits for k = (p + off) mod RING and takes part for kmin <= k <= kmax.
+template <int R>
+__device__ __forceinline__ void smm_ring_init_range(double (&A)[R], double (&L)[R], const double *len_col, int cm, int off,
+                                                    int kmin, int kmax, bool on, int lane)
 {
     constexpr int RING = 64 * R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int k = (lane * R + r + B + D) & (RING - 1);
+        const int k = (lane * R + r + off) & (RING - 1);
         A[r] = SMM_NEG_INF;
-        L[r] = (on && k >= 2 * B + D && k <= kp - 1) ? len_col[(size_t)k * cm] : SMM_NEG_INF;
+        L[r] = (on && k >= kmin && k <= kmax) ? len_col[(size_t)k * cm] : SMM_NEG_INF;
+    }
+}
+
+// Block protocol (source position -(B-1+D) at push step 0): slot p waits for k = (p + B + D) mod RING; lengths up to
+// K0 = 2B+D-1 belong to the chain wave.
+template <int R, int B, int D>
+__device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], const double *len_col, int cm, int kp,
+                                              bool on, int lane)
+{
+    smm_ring_init_range<R>(A, L, len_col, cm, B + D, 2 * B + D, kp - 1, on, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PAIR mode: a long video on TWO CUs.  The time of a corpus is the time of its longest videos, one CU each, while
+// other CUs idle; a video cannot be cut along T, but its lattice can be cut along the segment LENGTH:
+//   leader workgroup    chain wave + pushers for the SHORT range K0 < k <= 127 of every state (128-slot rings) and for
+//                       the LONG range 128 <= k <= kp-1 of the first cl states;
+//   follower workgroup  8 pusher waves for the long range of the other states.
+// A long-range candidate for position n has a source <= n - 128, so the follower may lag the chain by ~100 positions:
+// it reads h rows from the history the leader writes anyway and returns A'_long rows through a fourth history array,
+// SMM_BF positions per exchange.  Progress counters in the workspace order the two (pair_flags[2i] = h rows published,
+// [2i+1] = A'_long rows published).  Exchanged data and counters use agent-scope (sc1) loads and stores -- the per-XCD
+// L2s are not coherent with each other -- each producer drains its own stores (vmcnt(0)) before it bumps the counter.
+// Every wait is bounded: a partner that never shows up (the two workgroups are co-resident when the grid's first
+// wave of workgroups holds all pairs, which the host guarantees for in-order dispatch) sets error word 2 instead of
+// hanging.  max is exact and the candidates are the same expressions, so the result is bit-identical to one CU's.
+#define SMM_KS 127        // short range: K0 < k <= 127 (leader, 128-slot rings); long range: 128 <= k <= kp-1
+#define SMM_BF 16
+#define SMM_SPIN_LIMIT (1 << 22)
+
+__device__ __forceinline__ int smm_pair_cl(int C)
+{
+    // The leader's SIMDs are already busy with the chain wave and the short range of every state: it keeps a few
+    // long-range states so that the follower's SIMDs hold at most 3 rings each (12 states) where possible, and never
+    // more than the follower's capacity (8 waves x 2 rings).
+    const int cl = C > 12 ? C - 12 : 0;
+    return cl > 5 ? 5 : cl;
+}
+
+__device__ __forceinline__ double smm_ld_agent(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void smm_st_agent(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane waits until a progress counter reaches `need` (bounded).  `seen` caches the last value read: the partner
+// usually runs ahead, and a poll is a round trip to memory.  Returns false once the partner is given up on.
+__device__ __forceinline__ bool smm_wait_progress(const int32_t *ctr, int need, int &seen, int32_t *err, bool alive)
+{
+    if (!alive) return false;
+    if (seen >= need) return true;
+    for (int spin = 0; spin < SMM_SPIN_LIMIT; ++spin) {
+        seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= need) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    atomicExch(err, 2);
+    return false;
+}
+
+// Follower workgroup of a pair: 8 pusher waves, wave w owns states cl + w and cl + w + 8 (long range only).
+// Blocks of SMM_BF sources.  Wave 0 fetches the h rows of the next block while the block is pushed (registers, then LDS);
+// wave 4 stores the block's A' rows and publishes the previous block's once its stores have drained.
+__device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo &mv, int C, int pair)
+{
+    constexpr int R = 16, RING = 1024, BF = SMM_BF, KL = SMM_KS + 1;
+    constexpr int NX = BF * 16 / 64;                          // row elements per lane of the moving waves (nf <= 16)
+    const int T = mv.T, cm = a.c_max, kp = mv.kp, g = mv.group;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int cl = smm_pair_cl(C), nf = C - cl;
+    const double *len = a.len + (size_t)g * a.k_rows * cm;
+    double *hh = a.hist + mv.hist_off + (size_t)cm * (T + 1);
+    double *along = a.hist + mv.hist_off + (size_t)3 * cm * (T + 1);
+    int32_t *prog_h = a.pair_flags + 2 * pair, *prog_a = prog_h + 1;
+    __shared__ __attribute__((aligned(16))) double f_h[2][BF][SMM_MAX_STATES_DEV];
+    __shared__ __attribute__((aligned(16))) double f_a[2][BF][SMM_MAX_STATES_DEV];
+
+    // positions 1..127 have no long-range candidate
+    const int n0 = (T < SMM_KS) ? T : SMM_KS;
+    for (int i = threadIdx.x; i < n0 * nf; i += blockDim.x) smm_st_agent(&along[(size_t)(1 + i / nf) * cm + cl + i % nf], SMM_NEG_INF);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(prog_a, n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (T <= SMM_KS) return;
+
+    double A[2][R], L[2][R];
+#pragma unroll
+    for (int js = 0; js < 2; ++js)
+        smm_ring_init_range<R>(A[js], L[js], len + cl + w + 8 * js, cm, KL, KL, kp - 1, w + 8 * js < nf, lane);
+    // element x of this lane in a block of rows: (row, column) = ((lane + 64 x) / nf, cl + (lane + 64 x) % nf)
+    int xr[NX], xc[NX];
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+        const int e = lane + 64 * x;
+        xr[x] = (e < BF * nf) ? e / nf : -1;
+        xc[x] = cl + e % nf;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const int QF = (T - KL) / BF + 1;                         // sources 0 .. T-128 are needed
+    bool alive = true;
+    int seen = 0;
+    double hreg[NX];
+    // h rows of block q (sources q BF ..), once the leader has published them; rows past T-1 do not exist
+    auto fetch = [&](int q) {
+        const int s0 = q * BF;
+        int ok = 1;
+        if (lane == 0) {
+            alive = smm_wait_progress(prog_h, (s0 + BF - 1 < T - 1) ? s0 + BF - 1 : T - 1, seen, a.err, alive);
+            ok = alive;
+        }
+        ok = __builtin_amdgcn_readfirstlane(ok);
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            const int row = xr[x] < 0 ? 0 : xr[x];
+            const int sr = (s0 + row <= T - 1) ? s0 + row : T - 1;
+            const double v = smm_ld_agent(&hh[(size_t)sr * cm + xc[x]]);
+            hreg[x] = (ok && xr[x] >= 0 && s0 + xr[x] <= T - 1) ? v : SMM_NEG_INF;
+        }
+    };
+    auto stage = [&](int q) {
+#pragma unroll
+        for (int x = 0; x < NX; ++x)
+            if (xr[x] >= 0) f_h[q & 1][xr[x]][xc[x]] = hreg[x];
+    };
+    if (w == 0) { fetch(0); stage(0); }
+    __syncthreads();
+    for (int q = 0; q < QF; ++q) {
+        const int s0 = q * BF;
+        if (w == 0 && q + 1 < QF) fetch(q + 1);               // in flight while this block is pushed
+        const bool hand = lane == (s0 & (RING - 1)) / R;
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {
+            if (w + 8 * js >= nf) break;
+            const int c = cl + w + 8 * js;
+            double hv[BF];
+#pragma unroll
+            for (int i = 0; i < BF; ++i) hv[i] = f_h[q & 1][i][c];
+#pragma unroll
+            for (int i = 0; i < BF; ++i) smm_push<R>(A[js], L[js], hv[i], i);
+            if (hand) {
+#pragma unroll
+                for (int i = 0; i < BF; ++i) { f_a[q & 1][i][c] = A[js][i]; A[js][i] = SMM_NEG_INF; }
+            }
+        }
+        __syncthreads();
+        if (w == 0 && q + 1 < QF) stage(q + 1);
+        if (w == 4) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // the previous block's rows are out
+            if (q >= 1 && lane == 0) __hip_atomic_store(prog_a, s0 - BF + KL + BF - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int x = 0; x < NX; ++x) {
+                const int n = s0 + KL + xr[x];
+                if (xr[x] >= 0 && n <= T) smm_st_agent(&along[(size_t)n * cm + xc[x]], f_a[q & 1][xr[x]][xc[x]]);
+            }
+        }
+        __syncthreads();
+    }
+    if (w == 4) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (lane == 0) __hip_atomic_store(prog_a, (QF - 1) * BF + KL + BF - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -171,20 +344,35 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
 // B   positions per hand-over block; D = 1: pushers lag one more source (see smm_ring_block); the chain wave evaluates
 //     lengths 1..2B+D-1 itself
-template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D>
+// PAIR 1: the first 2*a.n_pairs workgroups are leader / follower pairs (R = 16, 8 waves only; see PAIR mode above)
+template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
+    static_assert(!PAIR || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair mode: 1024-slot rings, 8 waves");
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
     constexpr int M = (D ? 4 : 2) * B;                     // chain wave: h[n] of the last M > K0 positions, slot n mod M
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
-    const int vid = a.order[blockIdx.x];
+    // role: 0 one workgroup per video, 1 leader, 2 follower of pair blockIdx.x / 2
+    int role = 0, vsel = blockIdx.x;
+    if (PAIR) {
+        if ((int)blockIdx.x < 2 * a.n_pairs) { role = 1 + (blockIdx.x & 1); vsel = blockIdx.x >> 1; }
+        else vsel = blockIdx.x - a.n_pairs;
+    }
+    const int pair = blockIdx.x >> 1;
+    const int vid = a.order[vsel];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
     const int g = mv.group;
     const int C = a.n_states[g];
+    if (PAIR && role == 2) {
+        if (T > 0) smm_follower(a, mv, C, pair);
+        return;
+    }
+    const bool lead = PAIR && role == 1;
+    const int cl = lead ? smm_pair_cl(C) : 0;                 // leader: long-range states it keeps
     const int cm = a.c_max;
     const int kp = mv.kp;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: scalar branches
@@ -208,6 +396,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
+    __shared__ __attribute__((aligned(16))) double sh_along[PAIR ? 2 : 1][PAIR ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
@@ -224,9 +413,13 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_h[0][i][c] = SMM_NEG_INF;
             sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
+            if (PAIR) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[PAIR ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
         sh_gam[c] = SMM_NEG_INF;
-        if (c < C) { hcum[c] = 0.0; hh[c] = init[c]; }                             // history of n = 0
+        if (c < C) {                                                               // history of n = 0
+            hcum[c] = 0.0;
+            if (lead) smm_st_agent(&hh[c], init[c]); else hh[c] = init[c];         // (a pair's follower reads h rows)
+        }
     }
     __syncthreads();
 
@@ -275,6 +468,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     ap[i] = sh_apart[jj & 1][i][to];
+                    if (PAIR) ap[i] = smm_fmax(ap[i], sh_along[PAIR ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
                     ev[i] = sh_e[jj & 1][i][to];
                 }
 #pragma unroll
@@ -318,6 +512,126 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
         }
         SMM_PROF_OUT();
+    } else if (PAIR && lead) {
+        // ============================================================================ pusher waves of a pair's leader
+        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14 and long range
+        // (128 <= k <= kp-1, 1024-slot rings) of states rank, rank+7 below cl.  The follower's long-range A' rows come
+        // back through HBM; four pusher waves move the HBM traffic (below).
+        constexpr int SPS = 3, SPL = 2, RS = 2;
+        const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+        const int kshort = (kp - 1 < SMM_KS) ? kp - 1 : SMM_KS;
+        double As[SPS][RS], Ls[SPS][RS], hds[SPS];
+#pragma unroll
+        for (int js = 0; js < SPS; ++js) {
+            const int c = js * NP + rank;
+            smm_ring_init_range<RS>(As[js], Ls[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
+            hds[js] = SMM_NEG_INF;
+        }
+        double Al[SPL][R], Ll[SPL][R], hdl[SPL];
+#pragma unroll
+        for (int js = 0; js < SPL; ++js) {
+            const int c = js * NP + rank;
+            smm_ring_init_range<R>(Al[js], Ll[js], len + c, cm, B + D, SMM_KS + 1, kp - 1, c < cl, lane);
+            hdl[js] = SMM_NEG_INF;
+        }
+        int lo[NE], row[NE];
+        bool mine[NE];                                                     // element belongs to a follower-owned column
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            row[q] = e / cm;
+            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
+            mine[q] = lo[q] >= 0 && e % cm >= cl && e % cm < C;
+        }
+        double *along = hgam + (size_t)cm * (T + 1);                       // fourth history array: A'_long rows of the follower
+        int32_t *prog_h = a.pair_flags + 2 * pair, *prog_a = prog_h + 1;
+        const int64_t e_last = (int64_t)T * cm - 1, a_last = (int64_t)(T + 1) * cm - 1;
+        // Movers: every wave waits only for what it issued TWO blocks ago (nothing younger of its own is in flight),
+        // so the hipcc-inserted vmcnt(0) costs nothing.  Loaders: wave 4 on even blocks, wave 7 on odd blocks -- at
+        // block j write block j+1 (fetched at block j-2) to LDS, then fetch block j+3.  Storers: wave 5 on even
+        // blocks, wave 6 on odd blocks -- at block j publish the rows up to (j-2)B (its own stores of block j-2 have
+        // drained, the other storer's older ones drained before the last barrier), then store history block j-1.
+        const int ldpar = (w == 4) ? 0 : ((w == 7) ? 1 : -1);
+        const int stpar = (w == 5) ? 0 : ((w == 6) ? 1 : -1);
+        double pre[NE], pal[NE];
+        bool alive = true;
+        int seen = 0;
+        if (ldpar >= 0) {
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int64_t e = (int64_t)(1 + ldpar) * B * cm + lane + 64 * q;   // block 1 (even loader) / block 2 (odd)
+                pre[q] = elp[e < e_last ? e : e_last];
+                pal[q] = SMM_NEG_INF;                                              // positions <= 3B < 128: nothing long-range
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0), see the single-workgroup pushers
+        auto store_block = [&](const double *src, double *dst, int q, bool shared) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x;
+                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) {
+                    if (shared) smm_st_agent(&dst[(size_t)(q * B + 1) * cm + e], src[lo[x]]);
+                    else dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+                }
+            }
+        };
+        SMM_PROF_DECL;
+        for (int j0 = 0; j0 < J; j0 += UB) {
+#pragma unroll
+            for (int jj = 0; jj < UB; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                if (ldpar == (jj & 1)) {
+                    // block j+1 (fetched two blocks ago) -> LDS
+                    double *dst = &sh_e[(jj + 1) & 1][0][0];
+                    double *dsa = &sh_along[(jj + 1) & 1][0][0];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+                        if (mine[q]) dsa[lo[q]] = pal[q];
+                    }
+                    // fetch block j+3: elp rows, and the follower's A' rows once it has published them
+                    if (lane == 0) alive = smm_wait_progress(prog_a, ((j + 4) * B < T) ? (j + 4) * B : T, seen, a.err, alive);
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
+                        pre[q] = elp[e < e_last ? e : e_last];
+                        const int64_t ea = e + cm;                                 // position = frame + 1
+                        pal[q] = smm_ld_agent(&along[ea < a_last ? ea : a_last]);
+                    }
+                } else if (stpar == (jj & 1)) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    if (j >= 3 && lane == 0)
+                        __hip_atomic_store(prog_h, (j - 2) * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (j >= 1) {
+                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1, false);
+                        store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1, true);
+                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1, false);
+                    }
+                }
+#pragma unroll
+                for (int js = 0; js < SPS; ++js) {
+                    const int c = js * NP + rank;
+                    if (c >= C) break;
+                    smm_ring_block<RS, B, D>(As[js], Ls[js], hds[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
+                }
+#pragma unroll
+                for (int js = 0; js < SPL; ++js) {
+                    const int c = js * NP + rank;
+                    if (c >= cl) break;
+                    smm_ring_block<R, B, D>(Al[js], Ll[js], hdl[js], &sh_h[(jj + 1) & 1][0][c], &sh_along[(jj + 1) & 1][0][c], j, jj, lane);
+                }
+                SMM_BLOCK_BARRIER();                             // end of block j
+            }
+        }
+        SMM_PROF_OUT();
+        // the last block's history; every h row is out once both storers have drained
+        if (stpar == (J & 1)) {
+            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1, false);
+            store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1, true);
+            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1, false);
+        }
+        if (stpar >= 0) __builtin_amdgcn_s_waitcnt(0x0F70);                 // (published after the barrier below)
     } else {
         // ============================================================================ pusher waves
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
@@ -408,6 +722,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     // -------------------------------------------------------------------------------- last position
     // sh_gam holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
+    if (PAIR && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
+        __hip_atomic_store(a.pair_flags + 2 * pair, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w == 0) {
         double f = SMM_NEG_INF;
         if (lane <= C) {
@@ -504,6 +820,15 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
     if (spw != SPW || nw != NW) return 0;
     // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
     constexpr int B = (NW == 16 && R >= 8) ? 2 : SMM_B;
+    if constexpr (R == 16 && NW == 8 && B == 4 && SMM_D == 1) {
+        if (a.n_pairs > 0) {                                     // pairs first: a.b + n_pairs workgroups
+            const dim3 grid(a.b + a.n_pairs);
+            if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
+            else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
+            return 1;
+        }
+    }
+    if (a.n_pairs > 0) return 0;                                 // (the host only pairs for the configuration above)
     if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     return 1;

@@ -212,6 +212,18 @@ def error_flag(batch, ws=None):
     return int(ws[off:off + 4].view(torch.int32).item())
 
 
+def check_decoded(batch):
+    """Call after the decode's outputs have reached the host (the stream is idle then): raises SmmError when the DP
+    kernel flagged the run.  1: a NaN / inf - inf reached the DP; 2: a two-CU pair (smm_viterbi.hip, PAIR mode) gave
+    up waiting for its partner workgroup -- the outputs are invalid; SMM_PAIRS=0 in the environment disables pairing."""
+    flag = error_flag(batch)
+    if flag == 2:
+        raise _lib.SmmError("libsmmdp: a leader / follower workgroup pair timed out waiting for its partner (the two "
+                            "were not co-resident on the GPU); rerun with SMM_PAIRS=0")
+    if flag != 0:
+        raise _lib.SmmError("libsmmdp: NaN (or inf - inf) in the DP inputs; decode stopped early (error word %d)" % flag)
+
+
 # ------------------------------------------------------------------------------------------------ evaluation counters
 class EvalBatch:
     """Host metadata of one evaluation call: videos on the packed frame axis, their task and index inside the task."""

@@ -194,6 +194,7 @@ class SemiMarkovModel(object):
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True)
         from . import ops
         labels = ops.to_host(out['labels']).numpy().copy()
+        ops.check_decoded(pc.batch)
         preds = {}
         for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
             preds[name] = labels[off:off + t]

@@ -402,6 +402,7 @@ class SemiMarkovModule(nn.Module):
         out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
                            want_elp=return_elp, want_labels=False)
         pred_spans = out['spans'].cpu()
+        ops.check_decoded(out['_batch'])
         if return_elp:
             b, tmax = features.shape[:2]
             return pred_spans, out['elp'].view(b, tmax, -1)
@@ -425,11 +426,13 @@ class SemiMarkovModule(nn.Module):
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
         endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
-        return ops.decode(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
-                          tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
-                          tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
-                          class_map=tab['class_map'].view(1, -1), want_spans=want_spans, want_labels=want_labels,
-                          want_elp=want_elp)
+        out = ops.decode(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
+                         tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
+                         tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
+                         class_map=tab['class_map'].view(1, -1), want_spans=want_spans, want_labels=want_labels,
+                         want_elp=want_elp)
+        out['_batch'] = batch
+        return out
 
     # ------------------------------------------------------------------ packed multi-task decode
     def prepare_packed(self, pc):

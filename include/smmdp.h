@@ -80,8 +80,10 @@ int smm_device_count(void);
  * except between smm_logz_f64 and smm_logz_bwd_f64. */
 size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 
-/* Byte offset, inside the workspace, of the int32 error word the kernels set (non-zero: a NaN / inf-inf reached the
- * DP of some video and its decode stopped early).  It is cleared at the start of every call.  Returns 0 on invalid shape. */
+/* Byte offset, inside the workspace, of the int32 error word the kernels set.  1: a NaN / inf-inf reached the DP of
+ * some video and its decode stopped early.  2: a video decoded by a pair of workgroups on two CUs (long videos at
+ * K > 512; environment SMM_PAIRS=0 disables pairing) gave up waiting for its partner workgroup: outputs invalid.
+ * It is cleared at the start of every call.  Returns 0 on invalid shape. */
 size_t smm_error_word_offset(const smm_shape *shape);
 
 /*

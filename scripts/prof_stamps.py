@@ -40,6 +40,13 @@ def run(b, T, C, K):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pair':
+        for c in (21, 19, 17, 15, 13, 11):
+            for n in (0, 64):
+                os.environ['SMM_PAIRS'] = str(n)
+                print('SMM_PAIRS', n)
+                run(64, 4096, c, 1024)
+        sys.exit(0)
     run(64, 2048, 16, 256)
     run(64, 4096, 21, 1024)
     run(64, 4096, 20, 1024)

@@ -91,6 +91,43 @@ def test_viterbi_bit_exact_vs_factored_oracle(shape, ends):
     check(p, out, spans, v)
 
 
+PAIR_SHAPES = [
+    # b, tmax, c, k: 1024-slot rings (kp > 512); every video forced onto two CUs (leader + follower workgroups)
+    (2, 1500, 21, 1024), (3, 1100, 11, 1024), (2, 700, 16, 600), (2, 2100, 5, 1024), (1, 3000, 20, 1024),
+    (4, 640, 4, 1024), (2, 1300, 17, 520),
+]
+
+
+@pytest.mark.parametrize('shape', PAIR_SHAPES)
+@pytest.mark.parametrize('ends', [False, True])
+def test_viterbi_pair_mode_bit_exact(shape, ends, monkeypatch):
+    """The two-CU split of a video (short / long segment-length ranges, progress counters through HBM) must not
+    change a bit: same oracle, same checks as the one-workgroup path."""
+    b, tmax, c, k = shape
+    monkeypatch.setenv('SMM_PAIRS', str(b))
+    p = make_problem(hash(shape) % 1000 + 3, b, tmax, c, k, ends=ends)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+
+
+def test_viterbi_pair_mode_mixed_grid(monkeypatch):
+    """Pairs in front of the grid, single workgroups behind them, one launch; a paired video shorter than 64 frames."""
+    shape = (5, 1400, 13, 1024)
+    b, tmax, c, k = shape
+    monkeypatch.setenv('SMM_PAIRS', '2')
+    p = make_problem(77, b, tmax, c, k, ends=True)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    monkeypatch.setenv('SMM_PAIRS', '2')
+    p = make_problem(78, 2, 1200, 9, 1024, ends=False, min_len=1)
+    p['lengths'][1] = 40
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+
+
 @pytest.mark.parametrize('seed', range(6))
 def test_viterbi_integer_lattices_tie_order(seed):
     """Exact ties everywhere: the (k asc, from asc) arg-max order must match the oracle and the dense DP."""

@@ -138,7 +138,8 @@ static int choose_pairs(const SmmVideo *hv, const int32_t *order, const int32_t 
     int best_n = 0;
     double best_t = 1e300;
     std::vector<double> cu(n_cu);
-    for (int n = 0; n <= eligible; n += (n < 8 ? 1 : (n < 32 ? 4 : 8))) {
+    // (host time is on the caller's critical path: a handful of candidate counts, ~b heap operations each)
+    for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
         std::fill(cu.begin(), cu.end(), 0.0);
         // pairs occupy CUs 2i, 2i+1 from time 0; the rest is list-scheduled on the earliest free CU
         for (int i = 0; i < n; ++i)

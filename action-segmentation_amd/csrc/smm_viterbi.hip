@@ -338,7 +338,7 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 }
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
-// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
+// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8, 12 or 16)
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
@@ -492,18 +492,24 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if (n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
-                        double bq[4] = {SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF, SMM_NEG_INF};   // 4 independent max chains
+                        double bq[4];                                // 4 independent max chains
 #pragma unroll
                         for (int q = 0; q < HF / 2; ++q) {
                             const double2 gv = gp[q];
-                            bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
-                            bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
+                            if (q < 2) {
+                                bq[2 * q] = gv.x + tr[2 * q];
+                                bq[2 * q + 1] = gv.y + tr[2 * q + 1];
+                            } else {
+                                bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
+                                bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
+                            }
                         }
                         const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % M] = hcur;
                         if (half == 0) sh_h[jj & 1][i][to] = hcur;
                     }
+
                 }
                 if constexpr (CP) {
                     if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane);
@@ -824,12 +830,15 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
         if (a.n_pairs > 0) {                                     // pairs first: a.b + n_pairs workgroups
             const dim3 grid(a.b + a.n_pairs);
             if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
+            else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
             else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
             return 1;
         }
     }
     if (a.n_pairs > 0) return 0;                                 // (the host only pairs for the configuration above)
+    // HF: source states per half of the chain wave (2 HF >= states)
     if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     return 1;
 }
@@ -850,7 +859,7 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     if constexpr (R == 16) {
         // 22..23 states at K > 512: 12 waves (170 VGPRs each) = 11 pushers x 2 states + the chain wave's own ring
         if (nw == 16 && c_need <= 23) {
-            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 16, 1, 2>), dim3(a.b), dim3(12 * 64), 0, stream, a);
+            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), dim3(a.b), dim3(12 * 64), 0, stream, a);
             return SMM_OK;
         }
     }

@@ -471,18 +471,26 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if (PAIR) ap[i] = smm_fmax(ap[i], sh_along[PAIR ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
                     ev[i] = sh_e[jj & 1][i][to];
                 }
+                // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
+                // candidates k = 2..K0, A'[n+1], cumE[n+1] -- is evaluated in the shadow of position n's LDS round trip
+                // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
+                auto partial = [&](int i) {                  // max(A'[n], max_{k=2..K0} h[n-k] + len[k]), n = jB+1+i
+                    double sq[K0 + 1];
+#pragma unroll
+                    for (int k = 2; k <= K0; ++k) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
+                    double acc = ap[i];
+#pragma unroll
+                    for (int k = K0; k >= 2; --k) acc = smm_fmax(acc, sq[k]);
+                    return acc;
+                };
+                double pacc = partial(0);
+                double cumn = cum + ev[0];
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
                     if (n > T) break;
-                    // k = 2..K0 do not depend on h[n-1]: off the serial path
-                    double sq[K0 + 1];
-#pragma unroll
-                    for (int k = 1; k <= K0; ++k) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
-                    double acc = ap[i];
-#pragma unroll
-                    for (int k = K0; k >= 1; --k) acc = smm_fmax(acc, sq[k]);
-                    cum = cum + ev[i];
+                    const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
+                    cum = cumn;
                     const double gm = cum + acc;
                     if (half == 0) {
                         sh_gam[to] = gm;
@@ -492,16 +500,24 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if (n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
+                        double2 gv[HF / 2];
+#pragma unroll
+                        for (int q = 0; q < HF / 2; ++q) gv[q] = gp[q];
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i + 1 < B) {
+                            pacc = partial(i + 1 < B ? i + 1 : 0);
+                            cumn = cum + ev[i + 1 < B ? i + 1 : 0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                         double bq[4];                                // 4 independent max chains
 #pragma unroll
                         for (int q = 0; q < HF / 2; ++q) {
-                            const double2 gv = gp[q];
                             if (q < 2) {
-                                bq[2 * q] = gv.x + tr[2 * q];
-                                bq[2 * q + 1] = gv.y + tr[2 * q + 1];
+                                bq[2 * q] = gv[q].x + tr[2 * q];
+                                bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
                             } else {
-                                bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv.x + tr[2 * q]);
-                                bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv.y + tr[2 * q + 1]);
+                                bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv[q].x + tr[2 * q]);
+                                bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
                             }
                         }
                         const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
@@ -509,7 +525,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                         hq[(jj * B + 1 + i) % M] = hcur;
                         if (half == 0) sh_h[jj & 1][i][to] = hcur;
                     }
-
                 }
                 if constexpr (CP) {
                     if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane);

@@ -11,7 +11,7 @@ def run(b, T, C, K):
     r = 1
     while 64 * r < min(K, T):
         r *= 2
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libsmmdp_prof%d.so' % r)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get('SMM_PROF_LIB', 'libsmmdp_prof%d.so' % r))
     _lib._lib = None
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(0)

@@ -39,7 +39,12 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
                     float *__restrict__ elp32, int D, int cm, int tpw)
 {
-    extern __shared__ __attribute__((aligned(16))) double wl[];      // [D16][16*NT + 1]: this group's weights (zero padded) | inv_var
+    // LDS: this group's weights (zero padded) in the order the lanes read them, then inv_var[D16].
+    //   NT = 2: row d = 16 pairs {w[d][fr], w[d][16+fr]} (one ds_read_b128 per lane and MFMA pair; rows 256 B: the four
+    //           k groups of a macro-step read rows 4 apart = 1 KB apart, conflict-free in ds_read_b128's lane groups)
+    //   NT = 1: row d = 16 doubles, row stride 20 doubles (160 B: rows 4 apart land 128 B apart modulo the 256-B bank
+    //           span, so the two k groups of a ds_read_b64 half-wave do not collide)
+    extern __shared__ __attribute__((aligned(16))) double wl[];
     const int vid = order[blockIdx.y];                               // longest videos first: no long workgroup starts late
     const SmmVideo mv = videos[vid];
     const int T = mv.T, g = mv.group;
@@ -50,14 +55,17 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     const int nbv = (ntiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw);
     if ((int)blockIdx.x >= nbv) return;
     const int D16 = (D + 15) & ~15;
-    constexpr int WS = 16 * NT + 1;                                  // LDS row stride (doubles): weights + inv_var
+    constexpr int WS = (NT == 2) ? 32 : 20;                          // LDS row stride (doubles)
     const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // state tiles this video really needs
+    double *ivl = wl + (size_t)D16 * WS;
     {
         const double *__restrict__ w = wall + (size_t)g * D * cm;
-        for (int i = threadIdx.x; i < D16 * WS; i += SMM_EM_WAVES * 64) {
-            const int d = i / WS, c = i - d * WS;
-            wl[i] = (d >= D) ? 0.0 : ((c == 16 * NT) ? iv[d] : ((c < C) ? w[(size_t)d * cm + c] : 0.0));
+        for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
+            const int d = i / (16 * NT), r = i - d * (16 * NT);
+            const int c = (NT == 2) ? (r >> 1) + 16 * (r & 1) : r;  // NT = 2: pairs {fr, 16 + fr}
+            wl[(size_t)d * WS + r] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
         }
+        for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
     }
     __syncthreads();
     const int fr = lane & 15, kq = lane >> 4;
@@ -137,10 +145,14 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                 for (int j = 0; j < 4; ++j) {
                     const double a = (double)xs[j];
                     const int d = db + j;
-                    q = fma(a * wl[(size_t)d * WS + 16 * NT], a, q);
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
-                    if (NT == 2 && nt == 2)
-                        acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + 16 + fr], acc[NT - 1], 0, 0, 0);
+                    q = fma(a * ivl[d], a, q);
+                    if constexpr (NT == 2) {
+                        const double2 wv = *reinterpret_cast<const double2 *>(&wl[(size_t)d * WS + 2 * fr]);
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv.x, acc[0], 0, 0, 0);
+                        if (nt == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv.y, acc[NT - 1], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -210,7 +222,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, int64_t total_fr
     int bx = (int)((tiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw));
     if (bx < 1) bx = 1;
     dim3 grid(bx, a.b), block(SMM_EM_WAVES * 64);
-    const size_t lds = sizeof(double) * d16 * (ct <= 16 ? 17 : 33);          // <= 160 KiB checked by the caller
+    const size_t lds = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);          // <= 160 KiB checked by the caller
     const bool vec = (a.d & 3) == 0;
     auto go = [&](auto kern) {
         if (lds > 48 * 1024)

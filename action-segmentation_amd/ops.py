@@ -57,7 +57,7 @@ class Batch:
 def _dev(t, dtype, name):
     if t is None:
         return None
-    if not t.is_cuda:
+    if not t.is_cuda and not (name == 'labels' and t.is_pinned()):
         raise _lib.SmmError("libsmmdp: %s must be a CUDA/HIP tensor (there is no CPU path)" % name)
     if t.dtype != dtype:
         raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
@@ -83,9 +83,29 @@ def workspace(nbytes, device):
     return buf
 
 
-def _outputs(batch, device, want_spans, want_labels):
+_host_labels = {}
+
+
+def _labels_on_host(batch, device):
+    """Pinned host buffer the DP kernel writes the frame labels into directly (host-pinned memory is mapped into the
+    GPU's address space on ROCm; the stores go over PCIe while the kernel is still decoding other videos, so there is
+    no separate device -> host copy at the end).  Valid after the stream has been synchronised, until the next call."""
+    buf = _host_labels.get(device.index)
+    if buf is None or buf.numel() < batch.total_frames:
+        buf = torch.empty(int(batch.total_frames * 1.25) + 16, dtype=torch.int64, pin_memory=True)
+        _host_labels[device.index] = buf
+    out = buf[:batch.total_frames]
+    if int(batch.lengths.sum()) != batch.total_frames:
+        out.fill_(-1)                                  # frames no video covers (padded layouts) keep the -1 filler
+    return out
+
+
+def _outputs(batch, device, want_spans, want_labels, labels_on_host=False):
     spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
-    labels = torch.full((batch.total_frames,), -1, dtype=torch.int64, device=device) if want_labels else None
+    if want_labels and labels_on_host:
+        labels = _labels_on_host(batch, device)
+    else:
+        labels = torch.full((batch.total_frames,), -1, dtype=torch.int64, device=device) if want_labels else None
     best = torch.empty(batch.b, dtype=torch.float64, device=device)
     n_segs = torch.empty(batch.b, dtype=torch.int32, device=device)
     return spans, labels, best, n_segs
@@ -108,13 +128,16 @@ def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False):
     return elp64, elp32
 
 
-def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True):
-    """Viterbi on emission scores.  elp fp64 (smm_viterbi_f64) or fp32 (smm_viterbi_f32, tables fp32 too)."""
+def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True,
+            labels_on_host=False):
+    """Viterbi on emission scores.  elp fp64 (smm_viterbi_f64) or fp32 (smm_viterbi_f32, tables fp32 too).
+    ``labels_on_host``: the kernel writes the frame labels straight into pinned host memory (see _labels_on_host);
+    synchronise the stream before reading them."""
     lib = _lib.load()
     dev = elp.device
     dt = elp.dtype
     fn = lib.smm_viterbi_f64 if dt == torch.float64 else lib.smm_viterbi_f32
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host)
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(fn(
@@ -127,11 +150,12 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
-           want_spans=True, want_labels=True, want_elp=False):
-    """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream."""
+           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False):
+    """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream.
+    ``labels_on_host``: see ``viterbi``."""
     lib = _lib.load()
     dev = x.device
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host)
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want_elp else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()

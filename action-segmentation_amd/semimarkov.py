@@ -191,9 +191,12 @@ class SemiMarkovModel(object):
         return self.model.prepare_packed(pc)
 
     def predict_packed(self, pc):
-        out = self.model.decode_packed(pc, want_spans=False, want_labels=True)
+        import torch
         from . import ops
-        labels = ops.to_host(out['labels']).numpy().copy()
+        # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here
+        out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
+        torch.cuda.current_stream().synchronize()
+        labels = out['labels'].numpy().copy()
         ops.check_decoded(pc.batch)
         preds = {}
         for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):

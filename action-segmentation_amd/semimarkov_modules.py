@@ -477,7 +477,7 @@ class SemiMarkovModule(nn.Module):
                              kp=pc.kp, d=d, total_frames=pc.x.size(0))
         return pc
 
-    def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False):
+    def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False, labels_on_host=False):
         """One emission launch + one DP launch for a whole PackedCorpus.  Returns the dict of ops.decode
         (``labels``: int64 [total_frames] global class ids; ``spans``: [n_videos, t_max+1])."""
         self._require_device(pc.x, 'decode_packed')
@@ -486,7 +486,7 @@ class SemiMarkovModule(nn.Module):
         t = pc.tables
         return ops.decode(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
                           cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'], want_spans=want_spans,
-                          want_labels=want_labels, want_elp=want_elp)
+                          want_labels=want_labels, want_elp=want_elp, labels_on_host=labels_on_host)
 
     # ------------------------------------------------------------------ likelihoods (reference :597-658)
     def gold_score(self, features, lengths, valid_classes, spans, additional_allowed_ends_per_instance=None,

@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|cfg4] [--scale S]
 
-One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + D->H copy of the
-labels) over this rank's synthetic corpus, features already resident in HBM.  Default workload: cfg3, the shape
+One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + labels on the host: the
+DP kernel writes them into pinned host memory over PCIe while it decodes) over this rank's synthetic corpus, features
+already resident in HBM.  Default workload: cfg3, the shape
 BASELINE.json's metric is quoted on (CrossTask-shaped: 18 tasks x 20 videos, T ~ 6k (500..14k), 11..23 states per
 task, max span L = K-1 = 1023, D = 200).  With N > 1 (torchrun, one rank per GPU) every rank decodes its own
 corpus of that size (weak scaling; videos are independent, so there is no data-path collective); RCCL carries the
@@ -187,15 +188,16 @@ def main():
 
     def step(events=None):
         """emission -> DP -> labels on the host.  (Same two launches as smm_decode_f32; split only so that HIP
-        events can bracket the DP kernel on the stream it runs on.)"""
+        events can bracket the DP kernel on the stream it runs on.)  Returns the int64 labels as a CPU tensor."""
         elp64, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
         if events:
             events[0].record(stream)
         out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
-                          class_map=t['class_map'], want_spans=False, want_labels=True)
+                          class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=True)
         if events:
             events[1].record(stream)
-        return ops.to_host(out['labels']), out['labels']
+        stream.synchronize()          # the kernel wrote the labels into pinned host memory: they are on the host now
+        return out['labels']
 
     def sync():
         torch.cuda.synchronize()
@@ -203,14 +205,16 @@ def main():
             torch.distributed.barrier()
 
     for _ in range(a.warmup):
-        labels, labels_dev = step()
+        labels = step()
     sync()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i in range(a.steps):
-        labels, labels_dev = step(evs[i])
+        labels = step(evs[i])
     sync()
     dt = time.perf_counter() - t0
+    ops.check_decoded(pc.batch)
+    labels_dev = labels.to(dev)      # the evaluation kernels below (outside the timed region) read device labels
     dp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
     # evaluation, outside the timed region: the reference's per-task statistics from device counters.

@@ -128,6 +128,25 @@ def test_viterbi_pair_mode_mixed_grid(monkeypatch):
     check(p, out, spans, v)
 
 
+def test_labels_written_to_pinned_host_memory():
+    """labels_on_host: the DP kernel stores the frame labels straight into pinned host memory; same values as the
+    device tensor, for a padded layout (filler -1 between videos) and for one above the pairing threshold."""
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    for shape in [(3, 90, 5, 12), (2, 1500, 9, 1024)]:
+        b, tmax, c, k = shape
+        p = make_problem(5, b, tmax, c, k, ends=True)
+        batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+        t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+        args = (t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]), t(p['endpen']))
+        ref = ops.viterbi(batch, *args)
+        torch.cuda.synchronize()
+        out = ops.viterbi(batch, *args, labels_on_host=True)
+        torch.cuda.synchronize()
+        assert not out['labels'].is_cuda
+        np.testing.assert_array_equal(out['labels'].numpy(), ref['labels'].cpu().numpy())
+
+
 @pytest.mark.parametrize('seed', range(6))
 def test_viterbi_integer_lattices_tie_order(seed):
     """Exact ties everywhere: the (k asc, from asc) arg-max order must match the oracle and the dense DP."""

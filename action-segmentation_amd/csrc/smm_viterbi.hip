@@ -398,6 +398,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ __attribute__((aligned(16))) double sh_along[PAIR ? 2 : 1][PAIR ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
+    __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
 
@@ -450,6 +451,13 @@ smm_viterbi_kernel(SmmDpArgs a)
         for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
         hq[0] = live ? init[to] : SMM_NEG_INF;
         double cum = 0.0;
+        // Both halves of the wave compute every position; only the lower half's results are wanted in LDS.  The upper
+        // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
+        // s_and_saveexec / branch / s_or groups per position) on the serial path.
+        double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
+        double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
+        double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
+        double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
         // own ring (CP): state cx, same code as a pusher with one state
         constexpr int cx = NP * SPW;
         const bool has1 = CP && cx < C;
@@ -492,11 +500,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                     const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
                     cum = cumn;
                     const double gm = cum + acc;
-                    if (half == 0) {
-                        sh_gam[to] = gm;
-                        sh_g[jj & 1][i][to] = gm;
-                        sh_cum[jj & 1][i][to] = cum;
-                    }
+                    st_gam[0] = gm;
+                    st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
+                    st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
                     if (n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
@@ -523,7 +529,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % M] = hcur;
-                        if (half == 0) sh_h[jj & 1][i][to] = hcur;
+                        st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
                     }
                 }
                 if constexpr (CP) {

@@ -134,25 +134,52 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     double cstv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) cstv[t] = (16 * t + fr < C) ? cst[16 * t + fr] : 0.0;
+    // B operands of one macro-step: 4 x {w[d][fr], w[d][16 + fr]}, d = 16 ms + 4 kq + j.  They are read from LDS one
+    // macro-step ahead of the MFMAs that use them (wcur lives across consume() calls and across tiles: the weights do
+    // not depend on the tile), so an MFMA never waits for its own LDS read.  inv_var[d] is read at the top of the
+    // macro-step and used after its MFMAs have been issued.
+    double wcur[4][NT];
+    auto load_ops = [&](int ms, double (&wv)[4][NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = 16 * ms + 4 * kq + j;
+            if constexpr (NT == 2) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(&wl[(size_t)d * WS + 2 * fr]);
+                wv[j][0] = t2.x;
+                wv[j][NT - 1] = t2.y;
+            } else {
+                wv[j][0] = wl[(size_t)d * WS + fr];
+            }
+        }
+    };
+    load_ops(0, wcur);
     auto consume = [&](const float4 (&buf)[4], const float (&cb)[CONS ? 4 * NT : 1]) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int ms = 4 * cc + m;
             if (ms < nms) {
-                const int db = 16 * ms + 4 * kq;
-                const float xs[4] = {buf[m].x, buf[m].y, buf[m].z, buf[m].w};
+                double wnext[4][NT], iv4[4];
+                load_ops(ms + 1 < nms ? ms + 1 : 0, wnext);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) iv4[j] = ivl[16 * ms + 4 * kq + j];
+                double av[4];
+                av[0] = (double)buf[m].x; av[1] = (double)buf[m].y; av[2] = (double)buf[m].z; av[3] = (double)buf[m].w;
+                if (nt == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
+                        acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][NT - 1], acc[NT - 1], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const double a = (double)xs[j];
-                    const int d = db + j;
-                    q = fma(a * ivl[d], a, q);
-                    if constexpr (NT == 2) {
-                        const double2 wv = *reinterpret_cast<const double2 *>(&wl[(size_t)d * WS + 2 * fr]);
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv.x, acc[0], 0, 0, 0);
-                        if (nt == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wv.y, acc[NT - 1], 0, 0, 0);
-                    } else {
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wl[(size_t)d * WS + fr], acc[0], 0, 0, 0);
-                    }
+                    q = fma(av[j] * iv4[j], av[j], q);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wcur[j][t] = wnext[j][t];
                 }
             }
         }
@@ -187,19 +214,17 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
         ++ct;
     };
 
-    float4 b0[4], b1[4], b2[4];
-    float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1], c2[CONS ? 4 * NT : 1];
+    // two chunk buffers: one in flight while the other feeds the MFMAs (a third would push the kernel past 128 VGPRs,
+    // i.e. from two workgroups per CU to one)
+    float4 b0[4], b1[4];
+    float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1];
     fetch(b0, c0);
-    fetch(b1, c1);
-    for (int it = 0; it < total; it += 3) {
-        fetch(b2, c2);
+    for (int it = 0; it < total; it += 2) {
+        fetch(b1, c1);
         consume(b0, c0);
         if (it + 1 >= total) break;
         fetch(b0, c0);
         consume(b1, c1);
-        if (it + 2 >= total) break;
-        fetch(b1, c1);
-        consume(b2, c2);
     }
 }
 

@@ -27,6 +27,10 @@ CONFIGS = {
     # configs[2]: full CrossTask primary, 18 tasks, long videos T up to ~14k, L=1024 (the metric's shape)
     'cfg3': dict(n_tasks=18, videos_per_task=20, steps=(5, 10), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
                  chain=True, rate=(20, 400), batch_size=5),
+    # the same with SURVEY 8d's full state range 11..23 (2*steps+1, steps 5..11): tasks with 22-23 states put the whole
+    # launch on the 12-wave kernel configuration, which has no two-CU pair mode yet
+    'cfg3s': dict(n_tasks=18, videos_per_task=20, steps=(5, 11), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
+                  chain=True, rate=(20, 400), batch_size=5),
     # configs[3]: ordering constraints + narration constraints, small shapes
     'cfg4': dict(n_tasks=6, videos_per_task=10, steps=(3, 7), t_lognormal=(900, 0.4, 200, 2048), max_k=64, d=200,
                  chain=True, rate=(10, 50), batch_size=5, narration=True),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the semi-Markov decode path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg1|cfg4] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3s|cfg2|cfg1|cfg4] [--scale S]
 
 One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + labels on the host: the
 DP kernel writes them into pinned host memory over PCIe while it decodes) over this rank's synthetic corpus, features
@@ -36,7 +36,7 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=2)
-    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4'])
+    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3s', 'cfg4'])
     p.add_argument('--scale', type=float, default=1.0, help='videos per task multiplier')
     p.add_argument('--no-cpu-baseline', action='store_true')
     return p.parse_args()

@@ -1,6 +1,7 @@
 // smm_api.hip -- host side of libsmmdp.so: argument checks, launch planning, C ABI (include/smmdp.h).
 #include <algorithm>
 #include <functional>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -103,6 +104,7 @@ struct Staged {
     int32_t *pair_flags;
     int kp_max, c_need;
     int n_pairs;           // Viterbi only: the first n_pairs videos of `order` may run on two CUs each
+    bool pairs_cover_big;  // every video with more than 21 states is among them
 };
 
 // Two-CU pairs for the longest videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the time of its longest
@@ -119,44 +121,91 @@ static double frame_ns_single(int c)
     return std::max(230.0, 73.0 * load) + 5.0;
 }
 
-static int choose_pairs(const SmmVideo *hv, const int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need)
+// Reorders `order` (most work first on entry) into [paired videos | single videos], both most work first, and returns
+// the number of pairs.  Videos with more than 21 states MUST be paired (a single 8-wave workgroup holds 21 rings; a
+// pair's leader + follower hold 23): *big_ok says whether all of them are (else the caller falls back to the 12-wave
+// configuration, without pairs).  Optional pairs: the n most expensive eligible videos, n chosen by simulation.
+static int choose_pairs(const SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need,
+                        bool *big_ok)
 {
-    if (const char *e = std::getenv("SMM_PAIRS")) {
-        const int v = std::atoi(e);
-        if (v >= 0) return std::min(std::min(v, b), SMM_MAX_PAIRS);
-    }
-    if (kp_max <= 512 || c_need > 21 || std::getenv("SMM_NW")) return 0;   // pair mode exists for 1024-slot rings, 8 waves
+    *big_ok = false;
+    int forced = -1;
+    if (const char *e = std::getenv("SMM_PAIRS")) forced = std::atoi(e);
+    if (kp_max <= 512 || c_need > 23 || std::getenv("SMM_NW")) return 0;   // pair mode exists for 1024-slot rings, 8 waves
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
-    int eligible = 0;                                                        // a prefix of the order
-    while (eligible < b && eligible < SMM_MAX_PAIRS && 2 * (eligible + 1) <= n_cu) {
-        const SmmVideo &v = hv[order[eligible]];
-        if (v.T < 1024 || v.kp < 256 || n_states[v.group] < 4) break;
-        ++eligible;
+    std::vector<int32_t> must, opt, rest;
+    for (int i = 0; i < b; ++i) {
+        const SmmVideo &v = hv[order[i]];
+        const int c = n_states[v.group];
+        if (c > 21) must.push_back(order[i]);
+        else if ((forced > 0 || (v.T >= 1024 && v.kp >= 256 && c >= 4)) && opt.size() == (size_t)(i - (int)must.size()))
+            opt.push_back(order[i]);
+        else rest.push_back(order[i]);                                      // (optional pairs: a prefix of the <= 21-state order)
     }
+    if ((int)must.size() > SMM_MAX_PAIRS) return 0;
+    if (c_need > 21 && forced == 0) return 0;                               // pairing switched off: 12-wave configuration
+    const int cap = std::max(0, std::min(SMM_MAX_PAIRS, n_cu / 2) - (int)must.size());
+    const int eligible = std::min((int)opt.size(), cap);
+    auto pair_ns = [&](int32_t v) { return hv[v].T * (n_states[hv[v].group] > 16 ? 355.0 : 265.0); };
+    auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(n_states[hv[v].group]); };
     int best_n = 0;
-    double best_t = 1e300;
-    std::vector<double> cu(n_cu);
-    // (host time is on the caller's critical path: a handful of candidate counts, ~b heap operations each)
-    for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
-        std::fill(cu.begin(), cu.end(), 0.0);
-        // pairs occupy CUs 2i, 2i+1 from time 0; the rest is list-scheduled on the earliest free CU
-        for (int i = 0; i < n; ++i)
-            cu[2 * i] = cu[2 * i + 1] = hv[order[i]].T * (n_states[hv[order[i]].group] > 16 ? 355.0 : 265.0);
-        std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-        for (int i = n; i < b; ++i) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            cu.back() += hv[order[i]].T * frame_ns_single(n_states[hv[order[i]].group]);
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+    if (forced >= 0) {
+        best_n = std::min(std::min(forced, (int)opt.size()), SMM_MAX_PAIRS - (int)must.size());
+    } else {
+        double best_t = 1e300;
+        std::vector<double> cu(n_cu);
+        // (host time is on the caller's critical path: a handful of candidate counts, ~b heap operations each)
+        for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
+            // list schedule in grid order: pairs (two earliest-free CUs each) in front, then one CU per video
+            std::fill(cu.begin(), cu.end(), 0.0);
+            std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+            auto run_pair = [&](int32_t v) {
+                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+                const double t0 = cu.back(); cu.pop_back();
+                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+                const double t1 = std::max(t0, cu.back()) + pair_ns(v);
+                cu.back() = t1; std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+                cu.push_back(t1); std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+            };
+            auto run_single = [&](int32_t v) {
+                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+                cu.back() += single_ns(v);
+                std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+            };
+            size_t im = 0;
+            int io = 0;
+            while (im < must.size() || io < n) {                             // merged by cost, like the final order
+                if (io >= n || (im < must.size() && pair_ns(must[im]) >= pair_ns(opt[io]))) run_pair(must[im++]);
+                else run_pair(opt[io++]);
+            }
+            for (size_t i = n; i < opt.size(); ++i) run_single(opt[i]);
+            for (int32_t v : rest) run_single(v);
+            const double t = *std::max_element(cu.begin(), cu.end());
+            if (std::getenv("SMM_VERBOSE")) std::fprintf(stderr, "libsmmdp:   %d optional pairs -> %.3f ms predicted\n", n, t * 1e-6);
+            if (t < best_t * 0.97) { best_t = t; best_n = n; }               // pair only for a clear gain
         }
-        const double t = *std::max_element(cu.begin(), cu.end());
-        if (t < best_t * 0.97) { best_t = t; best_n = n; }                   // pair only for a clear gain
     }
-    return best_n;
+    if (std::getenv("SMM_VERBOSE"))
+        std::fprintf(stderr, "libsmmdp: %d videos, %zu with > 21 states (always paired), %d optional pairs of %d eligible, %d CUs\n",
+                     b, must.size(), best_n, eligible, n_cu);
+    // new order: pairs (most expensive first), then the singles in their old relative order
+    std::vector<int32_t> pairs(must);
+    pairs.insert(pairs.end(), opt.begin(), opt.begin() + best_n);
+    std::stable_sort(pairs.begin(), pairs.end(), [&](int32_t x, int32_t y) { return pair_ns(x) > pair_ns(y); });
+    std::vector<int32_t> singles;
+    {
+        std::vector<char> paired(b, 0);
+        for (int32_t v : pairs) paired[v] = 1;
+        for (int i = 0; i < b; ++i)
+            if (!paired[order[i]]) singles.push_back(order[i]);
+    }
+    std::copy(pairs.begin(), pairs.end(), order);
+    std::copy(singles.begin(), singles.end(), order + pairs.size());
+    *big_ok = true;
+    return (int)pairs.size();
 }
-
-
 
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
@@ -202,7 +251,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         return (int64_t)hv[a].T * n_states[hv[a].group] > (int64_t)hv[b].T * n_states[hv[b].group];
     });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
-    out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need);
+    out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
 
     char *base = static_cast<char *>(ws);
     // pageable source: the runtime copies it out before returning, so `host` may die with this frame
@@ -256,6 +305,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     }
     a.n_pairs = st.n_pairs;
     a.pair_flags = st.pair_flags;
+    if (st.pairs_cover_big) a.flags |= 4;
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());

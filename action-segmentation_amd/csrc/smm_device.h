@@ -34,7 +34,8 @@ struct SmmDpArgs {
     int32_t *n_segs;           // [b] or null
     int32_t *err;              // [1] sticky error flag (NaN in the inputs)
     int32_t c_max, k_rows, t_max, b;
-    int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined)
+    int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
+                               // backward; bit 2: every video with more than 21 states is in the paired prefix
     int32_t n_pairs;           // the first n_pairs entries of order[] run as leader / follower pairs (smm_viterbi.hip)
     int32_t *pair_flags;       // [2 * n_pairs] progress counters, zero at launch
 };

@@ -205,8 +205,10 @@ __device__ __forceinline__ int smm_pair_cl(int C)
     // The leader's SIMDs are already busy with the chain wave and the short range of every state: it keeps a few
     // long-range states so that the follower's SIMDs hold at most 3 rings each (12 states) where possible, and never
     // more than the follower's capacity (8 waves x 2 rings).
-    const int cl = C > 12 ? C - 12 : 0;
-    return cl > 5 ? 5 : cl;
+    int cl = C > 12 ? C - 12 : 0;
+    if (cl > 5) cl = 5;
+    if (C - cl > 16) cl = C - 16;                             // 22..23 states: 6..7 (the only way such a video runs here)
+    return cl;
 }
 
 __device__ __forceinline__ double smm_ld_agent(const double *p)
@@ -541,10 +543,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         SMM_PROF_OUT();
     } else if (PAIR && lead) {
         // ============================================================================ pusher waves of a pair's leader
-        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14 and long range
+        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21 and long range
         // (128 <= k <= kp-1, 1024-slot rings) of states rank, rank+7 below cl.  The follower's long-range A' rows come
         // back through HBM; four pusher waves move the HBM traffic (below).
-        constexpr int SPS = 3, SPL = 2, RS = 2;
+        constexpr int SPS = 4, SPL = 2, RS = 2;
         const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
         const int kshort = (kp - 1 < SMM_KS) ? kp - 1 : SMM_KS;
         double As[SPS][RS], Ls[SPS][RS], hds[SPS];
@@ -784,10 +786,13 @@ smm_viterbi_kernel(SmmDpArgs a)
     __syncthreads();
     while (n > 0) {
         const int kmax = (kp - 1 < n) ? kp - 1 : n;
-        double wgt = 0.0, gmv = SMM_NEG_INF;
+        double wgt = 0.0, gmv = SMM_NEG_INF, cnl = 0.0;
         if (lane < C) {
+            // one round trip for everything phase A and B need of position n: gamma row, cumE row, weights
+            const double g0 = hgam[(size_t)n * cm + lane];
+            cnl = hcum[(size_t)n * cm + lane];
             wgt = (to == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to * cm + lane];
-            gmv = hgam[(size_t)n * cm + lane] + wgt;
+            gmv = g0 + wgt;
         }
         const double rmax = smm_row_max16(gmv);
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
@@ -796,7 +801,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         while (fmask) {
             const int f = __builtin_amdgcn_readfirstlane(__ffsll(fmask) - 1);
             fmask &= fmask - 1;
-            const double cn = hcum[(size_t)n * cm + f];
+            const double cn = smm_readlane(cnl, f);
             const double wf = smm_readlane(wgt, f);
             const double *hcol = hh + f;
             const int lim = (kmax < k - 1) ? kmax : k - 1;      // an equal k with a larger state loses
@@ -875,6 +880,12 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     int nw = 8;
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
+    if constexpr (R == 16) {
+        // 22..23 states, every such video paired by the host (a.flags bit 2): the 8-wave kernel, whose pair leaders hold
+        // 28 short-range states and whose single workgroups only ever see <= 21
+        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 23 && nw == 8)
+            return launch_if<16, 3, 8>(a, 3, 8, c_need, stream) ? SMM_OK : SMM_ERR_UNSUPPORTED;
+    }
     if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
     (void)SPW16;
     if constexpr (R == 16) {

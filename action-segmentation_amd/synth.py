@@ -24,12 +24,12 @@ CONFIGS = {
     # configs[0]-like: one long video of one task
     'cfg1': dict(n_tasks=1, videos_per_task=1, steps=None, n_states=20, t_fixed=10000, max_k=1024, d=200, chain=False,
                  rate=(20, 400), batch_size=1),
-    # configs[2]: full CrossTask primary, 18 tasks, long videos T up to ~14k, L=1024 (the metric's shape)
-    'cfg3': dict(n_tasks=18, videos_per_task=20, steps=(5, 10), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
+    # configs[2]: full CrossTask primary, 18 tasks, long videos T up to ~14k, L=1024 (the metric's shape); states per
+    # task = 2*steps+1 = 11..23.  Videos with 22-23 states run as two-CU pairs.
+    'cfg3': dict(n_tasks=18, videos_per_task=20, steps=(5, 11), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
                  chain=True, rate=(20, 400), batch_size=5),
-    # the same with SURVEY 8d's full state range 11..23 (2*steps+1, steps 5..11): tasks with 22-23 states put the whole
-    # launch on the 12-wave kernel configuration, which has no two-CU pair mode yet
-    'cfg3s': dict(n_tasks=18, videos_per_task=20, steps=(5, 11), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
+    # the same capped at 21 states per task (what one 8-wave workgroup holds at K = 1024), for comparison
+    'cfg3c': dict(n_tasks=18, videos_per_task=20, steps=(5, 10), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
                   chain=True, rate=(20, 400), batch_size=5),
     # configs[3]: ordering constraints + narration constraints, small shapes
     'cfg4': dict(n_tasks=6, videos_per_task=10, steps=(3, 7), t_lognormal=(900, 0.4, 200, 2048), max_k=64, d=200,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the semi-Markov decode path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3s|cfg2|cfg1|cfg4] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3c|cfg2|cfg1|cfg4] [--scale S]
 
 One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + labels on the host: the
 DP kernel writes them into pinned host memory over PCIe while it decodes) over this rank's synthetic corpus, features
@@ -36,9 +36,13 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=2)
-    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3s', 'cfg4'])
+    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3c', 'cfg4'])
     p.add_argument('--scale', type=float, default=1.0, help='videos per task multiplier')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--seed', type=int, default=1000, help='corpus seed of rank 0 (rank r uses seed + r)')
+    p.add_argument('--fit-videos', type=int, default=6, help='videos per task the closed-form fit sees (untimed)')
+    p.add_argument('--labels-via-copy', action='store_true',
+                   help='labels to a device tensor + D->H copy through a pinned buffer instead of kernel stores to pinned host memory')
     return p.parse_args()
 
 
@@ -171,10 +175,10 @@ def main():
     from action_segmentation_amd.semimarkov import SemiMarkovModel
 
     cfg = synth.CONFIGS[a.workload]
-    data = synth.SynthDatasplit(a.workload, seed=1000 + rank, device=dev, scale=a.scale)
+    data = synth.SynthDatasplit(a.workload, seed=a.seed + rank, device=dev, scale=a.scale)
     fit_args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'])
     fitted = SemiMarkovModel.from_args(fit_args, data)
-    fitted.fit(data.subset(2), use_labels=True)       # closed-form fit (device statistics) on 2 videos per task
+    fitted.fit(data.subset(a.fit_videos), use_labels=True)   # closed-form fit (device statistics) on a few videos per task
     args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'],
                            sm_constrain_transitions=bool(cfg.get('narration')),
                            sm_constrain_with_narration=['test'] if cfg.get('narration') else [])
@@ -193,9 +197,11 @@ def main():
         if events:
             events[0].record(stream)
         out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
-                          class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=True)
+                          class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=not a.labels_via_copy)
         if events:
             events[1].record(stream)
+        if a.labels_via_copy:
+            return ops.to_host(out['labels'])
         stream.synchronize()          # the kernel wrote the labels into pinned host memory: they are on the host now
         return out['labels']
 

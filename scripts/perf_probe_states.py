@@ -23,6 +23,10 @@ def probe(b, T, C, K, cmax=None, reps=3):
         ts.append(e0.elapsed_time(e1))
     ms = min(ts)
     print(f"b={b} T={T} C={C} K={K} pairs={os.environ.get('SMM_PAIRS','auto')}: {ms:.3f} ms  ns/frame/video={ms*1e6/T:.0f}", flush=True)
-for c in (21, 22, 23, 24, 28, 32):
-    os.environ['SMM_PAIRS'] = '0'
-    probe(64, 4096, c, 1024)
+for c in (21, 22, 23):
+    for pairs in ('0', None):
+        if pairs is None:
+            os.environ.pop('SMM_PAIRS', None)
+        else:
+            os.environ['SMM_PAIRS'] = pairs
+        probe(64, 4096, c, 1024)

@@ -94,7 +94,7 @@ def test_viterbi_bit_exact_vs_factored_oracle(shape, ends):
 PAIR_SHAPES = [
     # b, tmax, c, k: 1024-slot rings (kp > 512); every video forced onto two CUs (leader + follower workgroups)
     (2, 1500, 21, 1024), (3, 1100, 11, 1024), (2, 700, 16, 600), (2, 2100, 5, 1024), (1, 3000, 20, 1024),
-    (4, 640, 4, 1024), (2, 1300, 17, 520),
+    (4, 640, 4, 1024), (2, 1300, 17, 520), (2, 1200, 23, 1024), (3, 900, 22, 700),
 ]
 
 
@@ -126,6 +126,38 @@ def test_viterbi_pair_mode_mixed_grid(monkeypatch):
     out = run_gpu(p)
     spans, v = run_oracle(p)
     check(p, out, spans, v)
+
+
+def test_viterbi_22_23_states_ride_in_pairs():
+    """More than 21 states at K > 512 do not fit one 8-wave workgroup's registers: such videos are always decoded by a
+    leader / follower pair, next to single workgroups for the other tasks of the same launch (two parameter groups)."""
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    k, cm = 1024, 23
+    cs = [23, 13, 22]
+    group = np.array([0, 1, 0, 2, 1], dtype=np.int32)
+    lengths = np.array([1300, 1500, 900, 1100, 700], dtype=np.int64)
+    tmax = int(lengths.max())
+    b = len(lengths)
+    probs = [make_problem(100 + i, 1, tmax, cs[g], k, c_max=cm, ends=(i % 2 == 0)) for i, g in enumerate(group)]
+    tabs = [make_problem(200 + g, 1, 8, c, k, c_max=cm) for g, c in enumerate(cs)]     # one table set per group
+    elp = np.stack([p['elp'][0] for p in probs])                                        # [b, tmax, cm]
+    endpen = np.stack([p['endpen'][0] if p['endpen'] is not None else np.zeros(cm) for p in probs])
+    for i, g in enumerate(group):
+        endpen[i, cs[g]:] = -1e9
+    batch = ops.Batch(lengths, cs, k, c_max=cm, t_max=tmax, total_frames=b * tmax, group=group)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    out = ops.viterbi(batch, t(elp.reshape(b * tmax, cm)), t(np.stack([x['trans'] for x in tabs])),
+                      t(np.stack([x['init'] for x in tabs])), t(np.stack([x['lens'] for x in tabs])), t(endpen))
+    torch.cuda.synchronize()
+    assert ops.error_flag(batch) == 0
+    out = {kk: v.cpu().numpy() for kk, v in out.items()}
+    for i, g in enumerate(group):
+        c = cs[g]
+        spans, v = F.viterbi(elp[i:i + 1, :, :c], lengths[i:i + 1], tabs[g]['trans'][:c, :c], tabs[g]['init'][:c],
+                             tabs[g]['lens'][:, :c], endpen[i:i + 1, :c])
+        assert out['best'][i] == v[0]
+        np.testing.assert_array_equal(out['spans'][i], spans[0])
 
 
 def test_labels_written_to_pinned_host_memory():

@@ -100,9 +100,11 @@ def _labels_on_host(batch, device):
     return out
 
 
-def _outputs(batch, device, want_spans, want_labels, labels_on_host=False):
+def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None):
     spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
-    if want_labels and labels_on_host:
+    if labels_out is not None:
+        labels = labels_out
+    elif want_labels and labels_on_host:
         labels = _labels_on_host(batch, device)
     else:
         labels = torch.full((batch.total_frames,), -1, dtype=torch.int64, device=device) if want_labels else None
@@ -111,11 +113,13 @@ def _outputs(batch, device, want_spans, want_labels, labels_on_host=False):
     return spans, labels, best, n_segs
 
 
-def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False):
-    """x fp32 [total_frames, d] -> elp fp64 and/or fp32 [total_frames, c_max].  (smm_emission_f64)"""
+def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False, out64=None):
+    """x fp32 [total_frames, d] -> elp fp64 and/or fp32 [total_frames, c_max].  (smm_emission_f64)
+    ``out64``: write into this [total_frames, c_max] tensor (sub-batches of one packed frame axis share it)."""
     lib = _lib.load()
     dev = x.device
-    elp64 = torch.empty((batch.total_frames, batch.c_max), dtype=torch.float64, device=dev) if want64 else None
+    elp64 = out64 if out64 is not None else (
+        torch.empty((batch.total_frames, batch.c_max), dtype=torch.float64, device=dev) if want64 else None)
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want32 else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, _, ns = batch.host_ptrs()
@@ -129,7 +133,7 @@ def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False):
 
 
 def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True,
-            labels_on_host=False):
+            labels_on_host=False, labels_out=None):
     """Viterbi on emission scores.  elp fp64 (smm_viterbi_f64) or fp32 (smm_viterbi_f32, tables fp32 too).
     ``labels_on_host``: the kernel writes the frame labels straight into pinned host memory (see _labels_on_host);
     synchronise the stream before reading them."""
@@ -137,7 +141,7 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
     dev = elp.device
     dt = elp.dtype
     fn = lib.smm_viterbi_f64 if dt == torch.float64 else lib.smm_viterbi_f32
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out)
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(fn(

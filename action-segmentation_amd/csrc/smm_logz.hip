@@ -283,8 +283,14 @@ static int logz_launch_r(const SmmDpArgs &a, double *logz, int c_need, hipStream
     constexpr int SPW8 = (40 / R) > 5 ? 5 : (40 / R);
     int nw = 8;
     if ((c_need + 6) / 7 > SPW8) nw = 16;
-    const int spw = (c_need + nw - 2) / (nw - 1);
-    if (nw == 16 && 5 * R * spw + 50 > 128) return SMM_ERR_UNSUPPORTED;     // K > 512 with more than 15 states
+    int spw = (c_need + nw - 2) / (nw - 1);
+    if (nw == 16 && 5 * R * spw + 50 > 128) {
+        // K > 512 with more than 15 states: the rings no longer fit the register file.  8 waves x 3..5 states per
+        // pusher with the overflow in scratch: correct, a few times slower (a two-CU split as in the Viterbi kernel's
+        // PAIR mode is the fast answer and is not built for the log semiring).
+        nw = 8;
+        spw = (c_need + 6) / 7;
+    }
     int hit = 0;
     if constexpr (R <= 4) {
         hit = logz_launch_if<R, 1, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 2, 8>(a, logz, spw, nw, c_need, stream) ||
@@ -297,7 +303,9 @@ static int logz_launch_r(const SmmDpArgs &a, double *logz, int c_need, hipStream
               logz_launch_if<R, 1, 16>(a, logz, spw, nw, c_need, stream);
     } else if constexpr (R == 16) {
         hit = logz_launch_if<R, 1, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 2, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 1, 16>(a, logz, spw, nw, c_need, stream);
+              logz_launch_if<R, 1, 16>(a, logz, spw, nw, c_need, stream) ||
+              logz_launch_if<R, 3, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 4, 8>(a, logz, spw, nw, c_need, stream) ||
+              logz_launch_if<R, 5, 8>(a, logz, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
 }

@@ -292,7 +292,9 @@ def test_emission_matches_oracle(cfg):
 
 @pytest.mark.parametrize('shape', [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64),
                                    (3, 200, 7, 65), (2, 300, 17, 130), (2, 600, 14, 300), (1, 1300, 12, 1024),
-                                   (2, 150, 32, 40), (2, 64, 4, 2)])
+                                   (2, 150, 32, 40), (2, 64, 4, 2),
+                                   # more than 15 states at K > 512: the register-spilling configurations
+                                   (1, 700, 21, 600), (2, 560, 23, 1024), (1, 600, 30, 520)])
 @pytest.mark.parametrize('ends', [False, True])
 def test_log_partition_matches_oracle(shape, ends):
     """LogSemiring forward kernel vs the fp64 CPU twin; tolerance of the path is 1e-4 relative."""
@@ -312,7 +314,8 @@ def test_log_partition_matches_oracle(shape, ends):
 
 
 @pytest.mark.parametrize('shape', [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64),
-                                   (3, 200, 7, 65), (2, 300, 17, 130), (2, 150, 32, 40), (1, 700, 12, 520)])
+                                   (3, 200, 7, 65), (2, 300, 17, 130), (2, 150, 32, 40), (1, 700, 12, 520),
+                                   (1, 640, 20, 560)])
 @pytest.mark.parametrize('ends', [False, True])
 def test_log_partition_gradients_match_oracle(shape, ends):
     """Posterior marginals (d logZ / d elp, trans, init, len) vs the exact fp64 forward-backward of the CPU twin."""

@@ -68,6 +68,11 @@ __device__ __forceinline__ double smm_dpp(double x)
 // lane i <- lane i-1, lane 0 <- lane 63
 __device__ __forceinline__ double smm_wave_ror1(double x) { return smm_dpp<SMM_DPP_WAVE_ROR1>(x); }
 
+__device__ __forceinline__ float smm_wave_ror1f(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), SMM_DPP_WAVE_ROR1, 0xf, 0xf, false));
+}
+
 // v_max_f64 without the canonicalising self-max hipcc puts in front of fmax() operands it cannot prove quiet
 // (no NaNs ever enter the DP: inputs are finite or -inf and nothing subtracts infinities).
 __device__ __forceinline__ double smm_fmax(double a, double b)

@@ -21,6 +21,7 @@
 #define SMM_LOG2E 1.4426950408889634
 #define SMM_LN2 0.6931471805599453
 #define SMM_MASKED (-1e300)      // "never": finite so that (-inf) - (-inf) cannot happen in x - m
+#define SMM_MASKED_F (-3.0e38f)  // the same for the fp32 copy of the length table kept in the rings
 
 __device__ __forceinline__ float smm_exp_neg_abs(float d)   // exp(-|d|)
 {
@@ -196,8 +197,12 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
         if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
         const int nv_all = (C - rank + NP - 1) / NP;
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
-        double M[SPW][R], L[SPW][R], hs[SPW];
-        float S[SPW][R];
+        // A ring slot keeps m (fp64), s (fp32) and its length score as fp32: 4 registers, so that 21 states x 1024
+        // slots fit the register file (with an fp64 copy they spill from 15 states on).  Rounding len to fp32 moves a
+        // candidate by <= 6e-8 |len| nats -- 1e-6 where candidates carry weight, against a tolerance of 1e-4 relative
+        // on log Z ~ 1e5 -- and the time-reversed run sees the same rounded table, so forward and backward agree.
+        double M[SPW][R], hs[SPW];
+        float S[SPW][R], L[SPW][R];
 #pragma unroll
         for (int j = 0; j < SPW; ++j) {
             const int c = j * NP + rank;
@@ -206,7 +211,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                 const int p = lane * R + r;
                 M[j][r] = SMM_NEG_INF;
                 S[j][r] = 0.f;
-                L[j][r] = (j < nv && p >= 1 && p <= kp - 1) ? len[(size_t)p * cm + c] : SMM_MASKED;
+                L[j][r] = (j < nv && p >= 1 && p <= kp - 1) ? fmaxf((float)len[(size_t)p * cm + c], SMM_MASKED_F) : SMM_MASKED_F;
             }
             hs[j] = 0.0;
         }
@@ -253,12 +258,17 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     if (j >= nv) break;
                     if (clear) { M[j][u] = SMM_NEG_INF; S[j][u] = 0.f; }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) smm_lse_push(M[j][r], S[j][r], hs[j] + L[j][(r - u + R) % R]);
+                    for (int r = 0; r < R; ++r) {
+                        smm_lse_push(M[j][r], S[j][r], hs[j] + (double)L[j][(r - u + R) % R]);
+                        // four slots in flight are enough to cover the exp latency; without the fence the scheduler
+                        // interleaves all R updates and their temporaries push the rings out of the register file
+                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (hand) {
                         sh_am[n & 1][j * NP + rank] = M[j][r2];
                         sh_as[n & 1][j * NP + rank] = S[j][r2];
                     }
-                    L[j][(R - 1 - u + R) % R] = smm_wave_ror1(L[j][(R - 1 - u + R) % R]);
+                    L[j][(R - 1 - u + R) % R] = smm_wave_ror1f(L[j][(R - 1 - u + R) % R]);
                 }
                 __syncthreads();
             }
@@ -279,12 +289,12 @@ static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int nw, int
 template <int R>
 static int logz_launch_r(const SmmDpArgs &a, double *logz, int c_need, hipStream_t stream)
 {
-    // a pusher needs ~5*R*SPW + 50 VGPRs (m fp64, s fp32, len fp64 per slot): 8 waves -> R*SPW <= 40, 16 waves -> <= 15
-    constexpr int SPW8 = (40 / R) > 5 ? 5 : (40 / R);
+    // a pusher needs ~4*R*SPW + 50 VGPRs (m fp64, s fp32, len fp32 per slot): 8 waves -> R*SPW <= 50, 16 waves -> <= 19
+    constexpr int SPW8 = (50 / R) > 5 ? 5 : (50 / R);
     int nw = 8;
     if ((c_need + 6) / 7 > SPW8) nw = 16;
     int spw = (c_need + nw - 2) / (nw - 1);
-    if (nw == 16 && 5 * R * spw + 50 > 128) {
+    if (nw == 16 && 4 * R * spw + 50 > 128) {
         // K > 512 with more than 15 states: the rings no longer fit the register file.  8 waves x 3..5 states per
         // pusher with the overflow in scratch: correct, a few times slower (a two-CU split as in the Viterbi kernel's
         // PAIR mode is the fast answer and is not built for the log semiring).

@@ -23,7 +23,7 @@
 //   broadcast through LDS and every lane folds its own row of the transition table (registers) over it; the two
 //   halves of the wave take half of the source states each and are merged with one v_permlane32_swap.
 //
-// Hand-over in BLOCKS of B positions, one barrier per block.  The chain wave evaluates the K0 = 2B-1 shortest segment
+// Hand-over in BLOCKS of B positions, one barrier per block.  The chain wave evaluates the K0 = 2B+D-1 shortest segment
 // lengths itself (h[n-1..n-K0] and len[1..K0] of its state sit in its registers; only the k = 1 term is on the serial
 // path); the pushers own k > K0 (their length rings hold -inf for k <= K0).  That slack is what decouples the two:
 // during block j the chain turns positions jB+1..(j+1)B into h values from the A' the pushers delivered a block
@@ -36,6 +36,9 @@
 // the forward pass, so it is bit-identical to tracking back-pointers.
 //
 // HBM traffic per frame (c states): read elp 8c, write history 24c (cumE, h, gamma; frame-major), label 8 B.
+//
+// The most expensive videos of a launch -- and every video with 22..23 states -- run on TWO CUs (PAIR mode below: the
+// lattice is cut along the segment length).
 #include "smm_device.h"
 
 // Diagnostic build only (-DSMM_PROFILE, never shipped or timed): per wave of workgroup 0, cycles between leaving a
@@ -684,7 +687,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             row[q] = e / cm;
             lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
         }
-        // wave 1: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
+        // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
         const int64_t e_last = (int64_t)T * cm - 1;
         double pre[NE];

@@ -35,7 +35,7 @@
 // scan per SEGMENT instead of arg-max tracking per cell) from the history, re-evaluating exactly the expressions of
 // the forward pass, so it is bit-identical to tracking back-pointers.
 //
-// HBM traffic per frame (c states): read elp 8c, write history 24c (cumE, h, gamma; frame-major), label 8 B.
+// HBM traffic per frame (c states): read elp 8c, write history 24c (cumE and gamma frame-major, h state-major), label 8 B.
 //
 // The most expensive videos of a launch -- and every video with 22..23 states -- run on TWO CUs (PAIR mode below: the
 // lattice is cut along the segment length).
@@ -268,13 +268,17 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 #pragma unroll
     for (int js = 0; js < 2; ++js)
         smm_ring_init_range<R>(A[js], L[js], len + cl + w + 8 * js, cm, KL, KL, kp - 1, w + 8 * js < nf, lane);
-    // element x of this lane in a block of rows: (row, column) = ((lane + 64 x) / nf, cl + (lane + 64 x) % nf)
-    int xr[NX], xc[NX];
+    // element x of this lane in a block of rows.  A' rows are row-major like the other history arrays: (row, column) =
+    // ((lane + 64 x) / nf, cl + (lane + 64 x) % nf); the h history is state-major (see the kernel): (column, row) =
+    // (cl + (lane + 64 x) / BF, (lane + 64 x) % BF), BF consecutive lanes read 128 contiguous bytes.
+    int xr[NX], xc[NX], hr[NX], hc[NX];
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
         const int e = lane + 64 * x;
         xr[x] = (e < BF * nf) ? e / nf : -1;
         xc[x] = cl + e % nf;
+        hr[x] = (e < BF * nf) ? e % BF : -1;
+        hc[x] = cl + e / BF;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     const int QF = (T - KL) / BF + 1;                         // sources 0 .. T-128 are needed
@@ -292,16 +296,17 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
         ok = __builtin_amdgcn_readfirstlane(ok);
 #pragma unroll
         for (int x = 0; x < NX; ++x) {
-            const int row = xr[x] < 0 ? 0 : xr[x];
+            const int row = hr[x] < 0 ? 0 : hr[x];
+            const int col = hr[x] < 0 ? cl : hc[x];
             const int sr = (s0 + row <= T - 1) ? s0 + row : T - 1;
-            const double v = smm_ld_agent(&hh[(size_t)sr * cm + xc[x]]);
-            hreg[x] = (ok && xr[x] >= 0 && s0 + xr[x] <= T - 1) ? v : SMM_NEG_INF;
+            const double v = smm_ld_agent(&hh[(size_t)col * (T + 1) + sr]);
+            hreg[x] = (ok && hr[x] >= 0 && s0 + hr[x] <= T - 1) ? v : SMM_NEG_INF;
         }
     };
     auto stage = [&](int q) {
 #pragma unroll
         for (int x = 0; x < NX; ++x)
-            if (xr[x] >= 0) f_h[q & 1][xr[x]][xc[x]] = hreg[x];
+            if (hr[x] >= 0) f_h[q & 1][hr[x]][hc[x]] = hreg[x];
     };
     if (w == 0) { fetch(0); stage(0); }
     __syncthreads();
@@ -390,7 +395,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
     const int64_t *cmap = a.class_map ? a.class_map + (size_t)g * (cm + 1) : nullptr;
     double *hcum = a.hist + mv.hist_off;                  // [T+1][cm]  cumE[n][c]
-    double *hh = hcum + (size_t)cm * (T + 1);             // [T+1][cm]  h[n][c]
+    double *hh = hcum + (size_t)cm * (T + 1);             // [cm][T+1]  h[n][c], STATE-major: the back-trace scans one
+                                                          // state's column over up to kp-1 positions per segment
     double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c]
     int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
     int64_t *labels = a.labels ? a.labels + mv.frame_off : nullptr;
@@ -424,7 +430,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         sh_gam[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
             hcum[c] = 0.0;
-            if (lead) smm_st_agent(&hh[c], init[c]); else hh[c] = init[c];         // (a pair's follower reads h rows)
+            if (lead) smm_st_agent(&hh[(size_t)c * (T + 1)], init[c]);             // (a pair's follower reads h rows)
+            else hh[(size_t)c * (T + 1)] = init[c];
         }
     }
     __syncthreads();
@@ -597,14 +604,21 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0), see the single-workgroup pushers
-        auto store_block = [&](const double *src, double *dst, int q, bool shared) {
+        auto store_block = [&](const double *src, double *dst, int q) {
 #pragma unroll
             for (int x = 0; x < NE; ++x) {
                 const int e = lane + 64 * x;
-                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) {
-                    if (shared) smm_st_agent(&dst[(size_t)(q * B + 1) * cm + e], src[lo[x]]);
-                    else dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
-                }
+                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+            }
+        };
+        // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes), with
+        // agent-scope stores: the follower reads them
+        auto store_h_block = [&](const double *src, int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x, c = e / B, i = e % B;
+                if (c < C && q * B + 1 + i <= T)
+                    smm_st_agent(&hh[(size_t)c * (T + 1) + q * B + 1 + i], src[i * SMM_MAX_STATES_DEV + c]);
             }
         };
         SMM_PROF_DECL;
@@ -636,9 +650,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if (j >= 3 && lane == 0)
                         __hip_atomic_store(prog_h, (j - 2) * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (j >= 1) {
-                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1, false);
-                        store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1, true);
-                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1, false);
+                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
+                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
+                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                     }
                 }
 #pragma unroll
@@ -659,9 +673,9 @@ smm_viterbi_kernel(SmmDpArgs a)
         SMM_PROF_OUT();
         // the last block's history; every h row is out once both storers have drained
         if (stpar == (J & 1)) {
-            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1, false);
-            store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1, true);
-            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1, false);
+            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
+            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
+            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
         }
         if (stpar >= 0) __builtin_amdgcn_s_waitcnt(0x0F70);                 // (published after the barrier below)
     } else {
@@ -710,6 +724,14 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
             }
         };
+        // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes)
+        auto store_h_block = [&](const double *src, int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x, c = e / B, i = e % B;
+                if (c < C && q * B + 1 + i <= T) hh[(size_t)c * (T + 1) + q * B + 1 + i] = src[i * SMM_MAX_STATES_DEV + c];
+            }
+        };
         SMM_PROF_DECL;
         for (int j0 = 0; j0 < J; j0 += UB) {
 #pragma unroll
@@ -729,7 +751,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     }
                     if (j >= 1) {
                         store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
-                        store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1);
+                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
                         store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                     }
                 }
@@ -746,7 +768,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // the last block's history
         if (w == MW) {
             store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
-            store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1);
+            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
             store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
         }
     }
@@ -785,6 +807,12 @@ smm_viterbi_kernel(SmmDpArgs a)
     // one lane per state) finds the maximum and the usually single state that attains it from 8*C bytes of the
     // gamma history; phase B scans only that state's row for the first k (16 B per candidate), all waves abreast.
     int n = T, to = sh_c, nseg = 0, round = 0;
+#ifdef SMM_PROFILE
+    unsigned long long bt_a = 0, bt_b = 0, bt_c = 0, bt_t = __builtin_readcyclecounter();   // phase A / B / labels, workgroup 0
+#define SMM_BT_STAMP(acc) do { const unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - bt_t; bt_t = t_; } while (0)
+#else
+#define SMM_BT_STAMP(acc) do { } while (0)
+#endif
     if (threadIdx.x == 0) { sh_kmin[0] = 0xffffffffu; sh_kmin[1] = 0xffffffffu; sh_kmin[2] = 0xffffffffu; }
     __syncthreads();
     while (n > 0) {
@@ -801,17 +829,18 @@ smm_viterbi_kernel(SmmDpArgs a)
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
         unsigned long long fmask = __ballot(lane < C && gmv == best);
         int k = 0x7fffffff, c = 0x7fffffff;
+        SMM_BT_STAMP(bt_a);
         while (fmask) {
             const int f = __builtin_amdgcn_readfirstlane(__ffsll(fmask) - 1);
             fmask &= fmask - 1;
             const double cn = smm_readlane(cnl, f);
             const double wf = smm_readlane(wgt, f);
-            const double *hcol = hh + f;
+            const double *hcol = hh + (size_t)f * (T + 1);     // contiguous: this state's h over all positions
             const int lim = (kmax < k - 1) ? kmax : k - 1;      // an equal k with a larger state loses
             for (int kb = 0; kb < lim; kb += NW * 64) {
                 const int kk = kb + w * 64 + lane + 1;
                 bool hit = false;
-                if (kk <= lim) hit = ((cn + (hcol[(size_t)(n - kk) * cm] + len[(size_t)kk * cm + f])) + wf) == best;
+                if (kk <= lim) hit = ((cn + (hcol[n - kk] + len[(size_t)kk * cm + f])) + wf) == best;
                 const unsigned long long m = __ballot(hit);
                 const int slot = round % 3;
                 if (lane == 0 && m) atomicMin(&sh_kmin[slot], (unsigned)(kb + w * 64 + __ffsll(m)));
@@ -825,6 +854,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 }
             }
         }
+        SMM_BT_STAMP(bt_b);
         if (k < 1 || k > kmax || c < 0 || c >= C) {           // NaN / inf-inf in the inputs: stop, flag, never spin
             if (threadIdx.x == 0) atomicExch(a.err, 1);
             break;
@@ -837,7 +867,14 @@ smm_viterbi_kernel(SmmDpArgs a)
         ++nseg;
         n = s;
         to = c;
+        SMM_BT_STAMP(bt_c);
     }
+#ifdef SMM_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err);
+        pp[40] = bt_a; pp[41] = bt_b; pp[42] = bt_c; pp[43] = (unsigned long long)nseg;
+    }
+#endif
     if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg;
 }
 

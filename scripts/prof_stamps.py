@@ -36,6 +36,9 @@ def run(b, T, C, K):
     for w in range(16):
         if pp[8 + w] or pp[24 + w]:
             print("   wave %2d  busy %6.0f  barrier %6.0f" % (w, pp[8 + w] / nblk, pp[24 + w] / nblk))
+    if pp[43]:
+        print("   back-trace of workgroup 0: %d segments; cycles per segment: phase A %.0f, phase B %.0f, labels %.0f"
+              % (pp[43], pp[40] / pp[43], pp[41] / pp[43], pp[42] / pp[43]))
     sys.stdout.flush()
 
 

@@ -128,6 +128,47 @@ def test_viterbi_pair_mode_mixed_grid(monkeypatch):
     check(p, out, spans, v)
 
 
+def _rescore(p, i, spans_row):
+    """Score of a span encoding under the factored model, summed independently in numpy (fp64)."""
+    c, t = p['c'], int(p['lengths'][i])
+    starts = [n for n in range(t) if spans_row[n] >= 0]
+    bounds = starts + [t]
+    total, prev = 0.0, None
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        lab = int(spans_row[s])
+        total += p['elp'][i, s:e, lab].sum() + p['lens'][e - s, lab]
+        total += p['init'][lab] if prev is None else p['trans'][lab, prev]
+        prev = lab
+    total += 0.0 if p['endpen'] is None else p['endpen'][i, prev]
+    return total
+
+
+@pytest.mark.parametrize('shape,pairs', [((2, 10000, 20, 1024), None), ((2, 10000, 20, 1024), '0'), ((3, 14000, 21, 1024), None),
+                                         ((64, 2048, 16, 256), None)])
+def test_full_size_bit_exact_and_properties(shape, pairs, monkeypatch):
+    """BASELINE.json's shapes at full size (cfg1: T = 10 000, 20 states, L = 1024; cfg3's longest: T = 14 000, 21 states;
+    cfg2: 64 x 2048, 16 states, L = 256): bit-exact against the C twin (a fraction of a second per video), plus
+    properties that do not need an oracle -- the decoded path re-scores to the reported optimum, labels and spans
+    agree, a second run and the one-CU / two-CU splits give identical bits."""
+    b, tmax, c, k = shape
+    if pairs is not None:
+        monkeypatch.setenv('SMM_PAIRS', pairs)
+    p = make_problem(hash(shape) % 1000 + 17, b, tmax, c, k, ends=True, scale=1.5)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    for i in range(min(b, 3)):
+        np.testing.assert_allclose(_rescore(p, i, out['spans'][i]), out['best'][i], rtol=1e-12)
+    again = run_gpu(p)
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], again[key])
+    if k > 512:
+        monkeypatch.setenv('SMM_PAIRS', '0' if pairs is None else str(b))
+        other = run_gpu(p)
+        for key in ('best', 'spans', 'labels', 'n_segs'):
+            np.testing.assert_array_equal(out[key], other[key])
+
+
 def test_viterbi_22_23_states_ride_in_pairs():
     """More than 21 states at K > 512 do not fit one 8-wave workgroup's registers: such videos are always decoded by a
     leader / follower pair, next to single workgroups for the other tasks of the same launch (two parameter groups)."""

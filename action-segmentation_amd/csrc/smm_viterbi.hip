@@ -70,6 +70,9 @@
 #ifndef SMM_D
 #define SMM_D 1
 #endif
+#ifndef SMM_B8_MAX_R
+#define SMM_B8_MAX_R 0   // (experiment: blocks of 8 positions for rings of up to 64 * this many slots; measured 5-9 % slower)
+#endif
 
 // wave-level lexicographic arg-max: larger val first, then smaller k, then smaller c
 __device__ __forceinline__ void smm_best3(double &v, int &k, int &c, double v2, int k2, int c2)
@@ -891,7 +894,7 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
 {
     if (spw != SPW || nw != NW) return 0;
     // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
-    constexpr int B = (NW == 16 && R >= 8) ? 2 : SMM_B;
+    constexpr int B = (NW == 16 && R >= 8) ? 2 : ((R <= SMM_B8_MAX_R && NW == 8) ? 8 : SMM_B);
     if constexpr (R == 16 && NW == 8 && B == 4 && SMM_D == 1) {
         if (a.n_pairs > 0) {                                     // pairs first: a.b + n_pairs workgroups
             const dim3 grid(a.b + a.n_pairs);

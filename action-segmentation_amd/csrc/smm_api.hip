@@ -110,7 +110,8 @@ struct Staged {
 // Two-CU pairs for the longest videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the time of its longest
 // videos while other CUs idle; a paired video runs ~1.7x faster on two CUs.  Cost model in ns per frame (measured on
 // MI355X at K = 1024): one CU: the most loaded SIMD's states x 73, at least the chain wave's 230; two CUs: the chain
-// wave's latency, 265 (<= 16 states) or 355 (its transition step folds 16 sources per half-wave instead of 8).
+// wave's latency, 265 (<= 16 states) or 355 (its transition step folds 12 sources per half-wave instead of 8; 22..23
+// states measure ~400, but pricing them so made the simulated choices worse on the corpora tried).
 // n_pairs = the count (all pairs within the first wave of workgroups: 2 n_pairs <= CUs, so leader and follower are
 // co-resident) that minimises the simulated makespan of a longest-first list schedule.
 static double frame_ns_single(int c)
@@ -148,7 +149,10 @@ static int choose_pairs(const SmmVideo *hv, int32_t *order, const int32_t *n_sta
     if (c_need > 21 && forced == 0) return 0;                               // pairing switched off: 12-wave configuration
     const int cap = std::max(0, std::min(SMM_MAX_PAIRS, n_cu / 2) - (int)must.size());
     const int eligible = std::min((int)opt.size(), cap);
-    auto pair_ns = [&](int32_t v) { return hv[v].T * (n_states[hv[v].group] > 16 ? 355.0 : 265.0); };
+    auto pair_ns = [&](int32_t v) {
+        const int c = n_states[hv[v].group];
+        return hv[v].T * (c > 16 ? 355.0 : 265.0);
+    };
     auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(n_states[hv[v].group]); };
     int best_n = 0;
     if (forced >= 0) {

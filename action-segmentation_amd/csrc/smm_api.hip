@@ -67,8 +67,8 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
     p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
-    p.o_pflags = p.o_err + 512;     // error word + diagnostic counters, then 2 counters per leader / follower pair
-    p.meta_bytes = p.o_pflags + align_up(sizeof(int32_t) * 2 * (size_t)std::min(s->b, SMM_MAX_PAIRS), 256);
+    p.o_pflags = p.o_err + 512;     // error word + diagnostic counters, then 4 counters per leader / follower gang
+    p.meta_bytes = p.o_pflags + align_up(sizeof(int32_t) * 4 * (size_t)std::min(s->b, SMM_MAX_PAIRS), 256);
     size_t h = 0;
     for (int i = 0; i < s->b; ++i) h += 8 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;
@@ -110,8 +110,7 @@ struct Staged {
 // Two-CU pairs for the longest videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the time of its longest
 // videos while other CUs idle; a paired video runs ~1.7x faster on two CUs.  Cost model in ns per frame (measured on
 // MI355X at K = 1024): one CU: the most loaded SIMD's states x 73, at least the chain wave's 230; two CUs: the chain
-// wave's latency, 265 (<= 16 states) or 355 (its transition step folds 12 sources per half-wave instead of 8; 22..23
-// states measure ~400, but pricing them so made the simulated choices worse on the corpora tried).
+// wave's latency: 265 on two CUs (<= 16 states), 300 on three CUs (more states: two followers).
 // n_pairs = the count (all pairs within the first wave of workgroups: 2 n_pairs <= CUs, so leader and follower are
 // co-resident) that minimises the simulated makespan of a longest-first list schedule.
 static double frame_ns_single(int c)
@@ -122,17 +121,21 @@ static double frame_ns_single(int c)
     return std::max(230.0, 73.0 * load) + 5.0;
 }
 
-// Reorders `order` (most work first on entry) into [paired videos | single videos], both most work first, and returns
-// the number of pairs.  Videos with more than 21 states MUST be paired (a single 8-wave workgroup holds 21 rings; a
-// pair's leader + follower hold 23): *big_ok says whether all of them are (else the caller falls back to the 12-wave
-// configuration, without pairs).  Optional pairs: the n most expensive eligible videos, n chosen by simulation.
-static int choose_pairs(const SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need,
-                        bool *big_ok)
+// Reorders `order` (most work first on entry) into [gang videos | single videos], both most work first, sets
+// SmmVideo::nfol of the gang videos (1: leader + follower on two CUs, 2: leader + two followers on three) and returns
+// the number of gangs.  Videos with more than 21 states MUST ride in a gang (a single 8-wave workgroup holds 21
+// rings): *big_ok says whether all of them do (else the caller falls back to the 12-wave configuration, without
+// gangs).  Optional gangs: the n most expensive eligible videos, the first n3 of them (above 16 states) as triples;
+// (n, n3) chosen by simulating a list schedule in grid order.  Cost model, ns per frame (measured at K = 1024): one
+// CU: the most loaded SIMD's states x 73, at least the chain wave's 230; pair: 265 (<= 16 states: the chain wave's
+// latency), 355 above (isolated measurements say 375..405, but the simulated choices are better with 355); triple: 300.
+static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need, bool *big_ok)
 {
     *big_ok = false;
-    int forced = -1;
+    int forced = -1, forced3 = -1;
     if (const char *e = std::getenv("SMM_PAIRS")) forced = std::atoi(e);
-    if (kp_max <= 512 || c_need > 23 || std::getenv("SMM_NW")) return 0;   // pair mode exists for 1024-slot rings, 8 waves
+    if (const char *e = std::getenv("SMM_TRIPLES")) forced3 = std::atoi(e);
+    if (kp_max <= 512 || c_need > 23 || std::getenv("SMM_NW")) return 0;   // gangs exist for 1024-slot rings, 8 waves
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
@@ -143,72 +146,94 @@ static int choose_pairs(const SmmVideo *hv, int32_t *order, const int32_t *n_sta
         if (c > 21) must.push_back(order[i]);
         else if ((forced > 0 || (v.T >= 1024 && v.kp >= 256 && c >= 4)) && opt.size() == (size_t)(i - (int)must.size()))
             opt.push_back(order[i]);
-        else rest.push_back(order[i]);                                      // (optional pairs: a prefix of the <= 21-state order)
+        else rest.push_back(order[i]);                                      // (optional gangs: a prefix of the <= 21-state order)
     }
     if ((int)must.size() > SMM_MAX_PAIRS) return 0;
-    if (c_need > 21 && forced == 0) return 0;                               // pairing switched off: 12-wave configuration
+    if (c_need > 21 && forced == 0) return 0;                               // gangs switched off: 12-wave configuration
     const int cap = std::max(0, std::min(SMM_MAX_PAIRS, n_cu / 2) - (int)must.size());
     const int eligible = std::min((int)opt.size(), cap);
-    auto pair_ns = [&](int32_t v) {
-        const int c = n_states[hv[v].group];
-        return hv[v].T * (c > 16 ? 355.0 : 265.0);
+    auto states = [&](int32_t v) { return n_states[hv[v].group]; };
+    auto gang_ns = [&](int32_t v, int nfol) {
+        const int c = states(v);
+        return hv[v].T * (nfol == 2 ? 300.0 : (c > 16 ? 355.0 : 265.0));
     };
-    auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(n_states[hv[v].group]); };
-    int best_n = 0;
+    auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(states(v)); };
+    // the gang list for (n optional gangs, n3 triples): must + opt[0..n), most expensive first; the first n3 of its
+    // videos above 16 states become triples
+    std::vector<int32_t> gangs;
+    std::vector<int> nf;
+    auto build = [&](int n, int n3) {
+        gangs.assign(must.begin(), must.end());
+        gangs.insert(gangs.end(), opt.begin(), opt.begin() + n);
+        std::stable_sort(gangs.begin(), gangs.end(), [&](int32_t x, int32_t y) { return gang_ns(x, 1) > gang_ns(y, 1); });
+        nf.assign(gangs.size(), 1);
+        for (size_t i = 0; i < gangs.size() && n3 > 0; ++i)
+            if (states(gangs[i]) > 16) { nf[i] = 2; --n3; }
+    };
+    std::vector<double> cu(n_cu);
+    auto simulate = [&](int n) {                                             // list schedule in grid order
+        std::fill(cu.begin(), cu.end(), 0.0);
+        std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+        for (size_t i = 0; i < gangs.size(); ++i) {                           // the 2 or 3 earliest-free CUs
+            const int m = 1 + nf[i];
+            double t0 = 0.0;
+            for (int q = 0; q < m; ++q) {
+                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+                t0 = std::max(t0, cu.back());
+                cu.pop_back();
+            }
+            for (int q = 0; q < m; ++q) {
+                cu.push_back(t0 + gang_ns(gangs[i], nf[i]));
+                std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+            }
+        }
+        auto run_single = [&](int32_t v) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += single_ns(v);
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+        };
+        for (size_t i = n; i < opt.size(); ++i) run_single(opt[i]);
+        for (int32_t v : rest) run_single(v);
+        return *std::max_element(cu.begin(), cu.end());
+    };
+    int best_n = 0, best_n3 = 0;
     if (forced >= 0) {
         best_n = std::min(std::min(forced, (int)opt.size()), SMM_MAX_PAIRS - (int)must.size());
+        best_n3 = forced3 >= 0 ? forced3 : 0;
     } else {
         double best_t = 1e300;
-        std::vector<double> cu(n_cu);
-        // (host time is on the caller's critical path: a handful of candidate counts, ~b heap operations each)
+        // (host time is on the caller's critical path: a handful of candidates, ~b heap operations each)
+        static const int n3s[] = {0, 1, 2, 4, 8, 16, 32};
         for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
-            // list schedule in grid order: pairs (two earliest-free CUs each) in front, then one CU per video
-            std::fill(cu.begin(), cu.end(), 0.0);
-            std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-            auto run_pair = [&](int32_t v) {
-                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-                const double t0 = cu.back(); cu.pop_back();
-                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-                const double t1 = std::max(t0, cu.back()) + pair_ns(v);
-                cu.back() = t1; std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-                cu.push_back(t1); std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-            };
-            auto run_single = [&](int32_t v) {
-                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-                cu.back() += single_ns(v);
-                std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-            };
-            size_t im = 0;
-            int io = 0;
-            while (im < must.size() || io < n) {                             // merged by cost, like the final order
-                if (io >= n || (im < must.size() && pair_ns(must[im]) >= pair_ns(opt[io]))) run_pair(must[im++]);
-                else run_pair(opt[io++]);
+            for (int n3 : n3s) {
+                // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few
+                // videos, CUs to spare); on a full GPU their third CU costs the one-CU videos more than it gains
+                // (measured on cfg3: 32 pairs 5.0 ms, 32 triples 5.4 ms)
+                if (n3 > n + (int)must.size() || (n3 > 0 && b + n + (int)must.size() + n3 > n_cu)) continue;
+                build(n, n3);
+                const double t = simulate(n);
+                if (std::getenv("SMM_VERBOSE"))
+                    std::fprintf(stderr, "libsmmdp:   %d optional gangs, %d triples -> %.3f ms predicted\n", n, n3, t * 1e-6);
+                if (t < best_t * 0.98) { best_t = t; best_n = n; best_n3 = n3; }   // more gangs only for a clear gain
             }
-            for (size_t i = n; i < opt.size(); ++i) run_single(opt[i]);
-            for (int32_t v : rest) run_single(v);
-            const double t = *std::max_element(cu.begin(), cu.end());
-            if (std::getenv("SMM_VERBOSE")) std::fprintf(stderr, "libsmmdp:   %d optional pairs -> %.3f ms predicted\n", n, t * 1e-6);
-            if (t < best_t * 0.97) { best_t = t; best_n = n; }               // pair only for a clear gain
         }
     }
+    build(best_n, best_n3);
     if (std::getenv("SMM_VERBOSE"))
-        std::fprintf(stderr, "libsmmdp: %d videos, %zu with > 21 states (always paired), %d optional pairs of %d eligible, %d CUs\n",
-                     b, must.size(), best_n, eligible, n_cu);
-    // new order: pairs (most expensive first), then the singles in their old relative order
-    std::vector<int32_t> pairs(must);
-    pairs.insert(pairs.end(), opt.begin(), opt.begin() + best_n);
-    std::stable_sort(pairs.begin(), pairs.end(), [&](int32_t x, int32_t y) { return pair_ns(x) > pair_ns(y); });
+        std::fprintf(stderr, "libsmmdp: %d videos, %zu with > 21 states (always in a gang), %d optional gangs of %d eligible, %d triples, %d CUs\n",
+                     b, must.size(), best_n, eligible, best_n3, n_cu);
+    // new order: gangs (most expensive first), then the singles in their old relative order
     std::vector<int32_t> singles;
     {
-        std::vector<char> paired(b, 0);
-        for (int32_t v : pairs) paired[v] = 1;
+        std::vector<char> in_gang(b, 0);
+        for (size_t i = 0; i < gangs.size(); ++i) { in_gang[gangs[i]] = 1; hv[gangs[i]].nfol = nf[i]; }
         for (int i = 0; i < b; ++i)
-            if (!paired[order[i]]) singles.push_back(order[i]);
+            if (!in_gang[order[i]]) singles.push_back(order[i]);
     }
-    std::copy(pairs.begin(), pairs.end(), order);
-    std::copy(singles.begin(), singles.end(), order + pairs.size());
+    std::copy(gangs.begin(), gangs.end(), order);
+    std::copy(singles.begin(), singles.end(), order + gangs.size());
     *big_ok = true;
-    return (int)pairs.size();
+    return (int)gangs.size();
 }
 
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
@@ -246,6 +271,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         hv[i].T = (int32_t)t;
         hv[i].group = g;
         hv[i].kp = k;
+        hv[i].nfol = 0;
         hoff += 8 * (size_t)s->c_max * (size_t)(t + 1);
         kp_max = std::max(kp_max, k);
     }

@@ -14,7 +14,7 @@ struct SmmVideo {
     int32_t T;           // frames
     int32_t group;       // parameter group
     int32_t kp;          // usable segment lengths are 1..kp-1   (min(K, Tmax of the reference batch))
-    int32_t pad;
+    int32_t nfol;        // Viterbi gangs (smm_viterbi.hip, PAIR mode): follower workgroups of this video, 1 or 2 (0: none)
 };
 
 struct SmmDpArgs {

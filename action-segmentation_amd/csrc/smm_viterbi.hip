@@ -196,8 +196,8 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 //   follower workgroup  8 pusher waves for the long range of the other states.
 // A long-range candidate for position n has a source <= n - 128, so the follower may lag the chain by ~100 positions:
 // it reads h rows from the history the leader writes anyway and returns A'_long rows through a fourth history array,
-// SMM_BF positions per exchange.  Progress counters in the workspace order the two (pair_flags[2i] = h rows published,
-// [2i+1] = A'_long rows published).  Exchanged data and counters use agent-scope (sc1) loads and stores -- the per-XCD
+// SMM_BF positions per exchange.  Progress counters in the workspace order them (pair_flags[4i] = h rows published,
+// [4i+1], [4i+2] = A'_long rows published by follower 0, 1).  Exchanged data and counters use agent-scope (sc1) loads and stores -- the per-XCD
 // L2s are not coherent with each other -- each producer drains its own stores (vmcnt(0)) before it bumps the counter.
 // Every wait is bounded: a partner that never shows up (the two workgroups are co-resident when the grid's first
 // wave of workgroups holds all pairs, which the host guarantees for in-order dispatch) sets error word 2 instead of
@@ -206,15 +206,31 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 #define SMM_BF 16
 #define SMM_SPIN_LIMIT (1 << 22)
 
-__device__ __forceinline__ int smm_pair_cl(int C)
+// Who owns the long range of which states (SmmVideo::nfol followers, chosen by the host).  ONE follower (a pair) takes
+// states cl .. C-1; the leader, whose SIMDs are busy with the chain wave and the short range of every state, keeps a
+// few (cl) so that the follower's SIMDs hold at most 3 rings each where possible.  TWO followers (a triple) split all
+// states: above 16 states a pair leaves the leader's SIMDs the bottleneck (two long rings next to six short ones),
+// the triple is bound by the chain wave alone -- 1.2x faster for 1.25x the CU-time, so only the videos on the
+// launch's critical path get one.
+__device__ __forceinline__ int smm_pair_cl(int C, int nfol)
 {
-    // The leader's SIMDs are already busy with the chain wave and the short range of every state: it keeps a few
-    // long-range states so that the follower's SIMDs hold at most 3 rings each (12 states) where possible, and never
-    // more than the follower's capacity (8 waves x 2 rings).
+    if (nfol == 2) return 0;
     int cl = C > 12 ? C - 12 : 0;
     if (cl > 5) cl = 5;
-    if (C - cl > 16) cl = C - 16;                             // 22..23 states: 6..7 (the only way such a video runs here)
+    if (C - cl > 16) cl = C - 16;                             // 22..23 states with one follower: 6..7
     return cl;
+}
+// states c0 .. c0+nf-1 of follower f
+__device__ __forceinline__ void smm_follower_share(int C, int nfol, int f, int &c0, int &nf)
+{
+    if (nfol == 2) {
+        const int h = (C + 1) / 2;
+        c0 = f ? h : 0;
+        nf = f ? C - h : h;
+    } else {
+        c0 = smm_pair_cl(C, 1);
+        nf = f ? 0 : C - c0;
+    }
 }
 
 __device__ __forceinline__ double smm_ld_agent(const double *p)
@@ -244,18 +260,20 @@ __device__ __forceinline__ bool smm_wait_progress(const int32_t *ctr, int need, 
 // Follower workgroup of a pair: 8 pusher waves, wave w owns states cl + w and cl + w + 8 (long range only).
 // Blocks of SMM_BF sources.  Wave 0 fetches the h rows of the next block while the block is pushed (registers, then LDS);
 // wave 4 stores the block's A' rows and publishes the previous block's once its stores have drained.
-__device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo &mv, int C, int pair)
+__device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo &mv, int C, int pair, int fidx)
 {
     constexpr int R = 16, RING = 1024, BF = SMM_BF, KL = SMM_KS + 1;
     constexpr int NX = BF * 16 / 64;                          // row elements per lane of the moving waves (nf <= 16)
     const int T = mv.T, cm = a.c_max, kp = mv.kp, g = mv.group;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int cl = smm_pair_cl(C), nf = C - cl;
+    int cl, nf;                                               // this follower's states cl .. cl+nf-1
+    smm_follower_share(C, mv.nfol, fidx, cl, nf);
+    if (nf <= 0) return;                                      // (the third workgroup of a gang whose video needs one follower)
     const double *len = a.len + (size_t)g * a.k_rows * cm;
     double *hh = a.hist + mv.hist_off + (size_t)cm * (T + 1);
     double *along = a.hist + mv.hist_off + (size_t)3 * cm * (T + 1);
-    int32_t *prog_h = a.pair_flags + 2 * pair, *prog_a = prog_h + 1;
+    int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1 + fidx;
     __shared__ __attribute__((aligned(16))) double f_h[2][BF][SMM_MAX_STATES_DEV];
     __shared__ __attribute__((aligned(16))) double f_a[2][BF][SMM_MAX_STATES_DEV];
 
@@ -357,7 +375,8 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
 // B   positions per hand-over block; D = 1: pushers lag one more source (see smm_ring_block); the chain wave evaluates
 //     lengths 1..2B+D-1 itself
-// PAIR 1: the first 2*a.n_pairs workgroups are leader / follower pairs (R = 16, 8 waves only; see PAIR mode above)
+// PAIR 1: the first 3*a.n_pairs workgroups are gangs of leader / follower 0 / follower 1 (R = 16, 8 waves only; see
+//         PAIR mode above; follower 1 returns at once when the video needs one follower)
 template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
@@ -371,21 +390,21 @@ smm_viterbi_kernel(SmmDpArgs a)
     // role: 0 one workgroup per video, 1 leader, 2 follower of pair blockIdx.x / 2
     int role = 0, vsel = blockIdx.x;
     if (PAIR) {
-        if ((int)blockIdx.x < 2 * a.n_pairs) { role = 1 + (blockIdx.x & 1); vsel = blockIdx.x >> 1; }
-        else vsel = blockIdx.x - a.n_pairs;
+        if ((int)blockIdx.x < 3 * a.n_pairs) { role = 1 + blockIdx.x % 3; vsel = blockIdx.x / 3; }   // gang: leader, follower 0, 1
+        else vsel = blockIdx.x - 2 * a.n_pairs;
     }
-    const int pair = blockIdx.x >> 1;
+    const int pair = blockIdx.x / 3;
     const int vid = a.order[vsel];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
     const int g = mv.group;
     const int C = a.n_states[g];
-    if (PAIR && role == 2) {
-        if (T > 0) smm_follower(a, mv, C, pair);
+    if (PAIR && role >= 2) {
+        if (T > 0) smm_follower(a, mv, C, pair, role - 2);
         return;
     }
     const bool lead = PAIR && role == 1;
-    const int cl = lead ? smm_pair_cl(C) : 0;                 // leader: long-range states it keeps
+    const int cl = lead ? smm_pair_cl(C, mv.nfol) : 0;        // leader: long-range states it keeps
     const int cm = a.c_max;
     const int kp = mv.kp;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: scalar branches
@@ -586,7 +605,8 @@ smm_viterbi_kernel(SmmDpArgs a)
             mine[q] = lo[q] >= 0 && e % cm >= cl && e % cm < C;
         }
         double *along = hgam + (size_t)cm * (T + 1);                       // fourth history array: A'_long rows of the follower
-        int32_t *prog_h = a.pair_flags + 2 * pair, *prog_a = prog_h + 1;
+        int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1;  // [1], [2]: follower 0, follower 1
+        const bool two = mv.nfol == 2;
         const int64_t e_last = (int64_t)T * cm - 1, a_last = (int64_t)(T + 1) * cm - 1;
         // Movers: every wave waits only for what it issued TWO blocks ago (nothing younger of its own is in flight),
         // so the hipcc-inserted vmcnt(0) costs nothing.  Loaders: wave 4 on even blocks, wave 7 on odd blocks -- at
@@ -597,7 +617,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         const int stpar = (w == 5) ? 0 : ((w == 6) ? 1 : -1);
         double pre[NE], pal[NE];
         bool alive = true;
-        int seen = 0;
+        int seen = 0, seen1 = 0;
         if (ldpar >= 0) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
@@ -640,7 +660,11 @@ smm_viterbi_kernel(SmmDpArgs a)
                         if (mine[q]) dsa[lo[q]] = pal[q];
                     }
                     // fetch block j+3: elp rows, and the follower's A' rows once it has published them
-                    if (lane == 0) alive = smm_wait_progress(prog_a, ((j + 4) * B < T) ? (j + 4) * B : T, seen, a.err, alive);
+                    if (lane == 0) {
+                        const int need = ((j + 4) * B < T) ? (j + 4) * B : T;
+                        alive = smm_wait_progress(prog_a, need, seen, a.err, alive);
+                        if (two) alive = smm_wait_progress(prog_a + 1, need, seen1, a.err, alive);
+                    }
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
                         const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
@@ -780,7 +804,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     // sh_gam holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
     if (PAIR && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
-        __hip_atomic_store(a.pair_flags + 2 * pair, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.pair_flags + 4 * pair, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w == 0) {
         double f = SMM_NEG_INF;
         if (lane <= C) {
@@ -896,8 +920,8 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
     // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
     constexpr int B = (NW == 16 && R >= 8) ? 2 : ((R <= SMM_B8_MAX_R && NW == 8) ? 8 : SMM_B);
     if constexpr (R == 16 && NW == 8 && B == 4 && SMM_D == 1) {
-        if (a.n_pairs > 0) {                                     // pairs first: a.b + n_pairs workgroups
-            const dim3 grid(a.b + a.n_pairs);
+        if (a.n_pairs > 0) {                                     // gangs of 3 workgroups first: a.b + 2 n_pairs workgroups
+            const dim3 grid(a.b + 2 * a.n_pairs);
             if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
             else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
             else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);

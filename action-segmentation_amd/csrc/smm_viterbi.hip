@@ -903,6 +903,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
 #endif
     if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg;
+#ifdef SMM_PROFILE_END   // diagnostic build: when did each video's (leader) workgroup finish?  (100 MHz wall clock into best[])
+    if (a.best && threadIdx.x == 0) a.best[vid] = (double)wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch

@@ -43,6 +43,14 @@ def run(b, T, C, K):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'load':
+        # leader of gang 0 on a full GPU: pair vs triple
+        for b, t in ((250, 4096), (8, 14000)):
+            for tr in (0, 8):
+                os.environ['SMM_PAIRS'] = '8'; os.environ['SMM_TRIPLES'] = str(tr)
+                print('b', b, 'SMM_PAIRS 8 SMM_TRIPLES', tr)
+                run(b, t, 21, 1024)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'pair':
         for c in (21, 19, 17, 15, 13, 11):
             for n in (0, 64):

@@ -189,18 +189,20 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PAIR mode: a long video on TWO CUs.  The time of a corpus is the time of its longest videos, one CU each, while
-// other CUs idle; a video cannot be cut along T, but its lattice can be cut along the segment LENGTH:
-//   leader workgroup    chain wave + pushers for the SHORT range K0 < k <= 127 of every state (128-slot rings) and for
-//                       the LONG range 128 <= k <= kp-1 of the first cl states;
-//   follower workgroup  8 pusher waves for the long range of the other states.
-// A long-range candidate for position n has a source <= n - 128, so the follower may lag the chain by ~100 positions:
+// PAIR mode: a long video on TWO or THREE CUs (a "gang" of workgroups).  The time of a corpus is the time of its longest
+// videos, one CU each, while other CUs idle; a video cannot be cut along T, but its lattice can be cut along the segment
+// LENGTH:
+//   leader workgroup     chain wave + pushers for the SHORT range K0 < k <= 127 of every state (128-slot rings) and,
+//                        with one follower, for the LONG range 128 <= k <= kp-1 of the first cl states;
+//   follower workgroups  8 pusher waves each for the long range of the other states (one follower, or two that split
+//                        all states between them).
+// A long-range candidate for position n has a source <= n - 128, so a follower may lag the chain by ~100 positions:
 // it reads h rows from the history the leader writes anyway and returns A'_long rows through a fourth history array,
 // SMM_BF positions per exchange.  Progress counters in the workspace order them (pair_flags[4i] = h rows published,
-// [4i+1], [4i+2] = A'_long rows published by follower 0, 1).  Exchanged data and counters use agent-scope (sc1) loads and stores -- the per-XCD
-// L2s are not coherent with each other -- each producer drains its own stores (vmcnt(0)) before it bumps the counter.
-// Every wait is bounded: a partner that never shows up (the two workgroups are co-resident when the grid's first
-// wave of workgroups holds all pairs, which the host guarantees for in-order dispatch) sets error word 2 instead of
+// [4i+1], [4i+2] = A'_long rows published by follower 0, 1).  Exchanged data and counters use agent-scope (sc1) loads
+// and stores -- the per-XCD L2s are not coherent with each other -- and each producer drains its own stores (vmcnt(0))
+// before it bumps the counter.  Every wait is bounded: a partner that never becomes resident (with in-order dispatch
+// of the grid at most one leader at a time waits for the CU its follower is about to get) sets error word 2 instead of
 // hanging.  max is exact and the candidates are the same expressions, so the result is bit-identical to one CU's.
 #define SMM_KS 127        // short range: K0 < k <= 127 (leader, 128-slot rings); long range: 128 <= k <= kp-1
 #define SMM_BF 16

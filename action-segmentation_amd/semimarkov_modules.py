@@ -369,6 +369,37 @@ class SemiMarkovModule(nn.Module):
             inv_var=(1.0 / var).contiguous(),
             class_map=torch.tensor(ids + [self.n_classes], dtype=torch.int64, device=dev))
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_table_cache', None)          # device tensors derived from the parameters: rebuilt on demand
+        return state
+
+    def _decode_tables(self, valid_classes, device):
+        """factor_tables for decoding (no gradient), cached per class set: the reference decodes batch after batch with
+        the same few class sets, and building the tables is a dozen small torch ops (half of a small batch's latency).
+        The key includes the parameters' version counters, so any in-place update (an optimiser step, load_state_dict,
+        fit_supervised) invalidates the entry."""
+        key = (None if valid_classes is None else tuple(int(v) for v in valid_classes), str(device), self.max_k,
+               tuple((p.data_ptr(), p._version) for p in (self.poisson_log_rates, self.gaussian_means, self.gaussian_cov,
+                                                         self.transition_logits, self.init_logits)),
+               self._constraint_key())
+        cache = self.__dict__.setdefault('_table_cache', {})
+        tab = cache.get(key)
+        if tab is None:
+            if len(cache) > 64:
+                cache.clear()
+            with torch.no_grad():
+                tab = self.factor_tables(valid_classes, device)
+            cache[key] = tab
+        return tab
+
+    def _constraint_key(self):
+        """Identity of everything besides the five parameters that factor_tables reads."""
+        ic = getattr(self, 'init_constraints', None)
+        tc = getattr(self, 'transition_constraints', None)
+        return (None if ic is None else (ic.data_ptr(), ic._version), None if tc is None else (tc.data_ptr(), tc._version),
+                id(getattr(self, 'merge_classes', None)), bool(getattr(self, 'allow_self_transitions', True)))
+
     def _endpen(self, valid_classes, additional_allowed_ends_per_instance, b, c, device):
         ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
         if ends is None:
@@ -416,8 +447,7 @@ class SemiMarkovModule(nn.Module):
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
         assert int(lengths_host.max()) == tmax, "one instance must span the padded length (padding_colate)"
-        with torch.no_grad():
-            tab = self.factor_tables(valid_classes, dev)
+        tab = self._decode_tables(valid_classes, dev)
         c = tab['init'].numel()
         k_rows = tab['len'].size(0)
         batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
@@ -438,8 +468,7 @@ class SemiMarkovModule(nn.Module):
     def prepare_packed(self, pc):
         """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns."""
         dev = pc.x.device
-        with torch.no_grad():
-            tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
+        tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
         n_states = [int(t['init'].numel()) for t in tabs]
         cm, d, g = max(n_states), pc.x.size(1), len(tabs)
         k_rows = tabs[0]['len'].size(0)

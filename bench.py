@@ -95,7 +95,7 @@ def cpu_baseline(data, model, pc):
     def run(t):
         t0 = time.perf_counter()
         with torch.no_grad():
-            O.viterbi(p, feats_all[:t].unsqueeze(0), torch.tensor([t]), smp['task_indices'])
+            O.viterbi(p, feats_all[:t].unsqueeze(0), torch.tensor([t]), smp['task_indices'])   # (current smp / feats_all)
         return time.perf_counter() - t0
 
     # bounded sample: cost ~ t * min(K, t) * C^2; calibrate on 192 frames, then aim at ~15 s and <= 2 GB of potentials
@@ -105,12 +105,23 @@ def cpu_baseline(data, model, pc):
     t = int(min(feats_all.shape[0], 2.0e9 / (4.0 * k_all * (c + 1) ** 2), max(k_all + 64, 15.0 / (per_cell * k_all))))
     while t > 64 and per_cell * t * min(k_all, t) > 40.0:
         t //= 2
-    dt = run(t)
-    feats = feats_all[:t].unsqueeze(0)
-    return {"value": t / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "first %d frames of video %s (C=%d, K=%d, D=%d): dense b x N x K x C x C fp32 potentials + "
-                      "sequential max-DP with back-pointers (oracle/dense_ref.py), %.1f s" % (t, name, c, m.max_k,
-                                                                                            feats.shape[-1], dt)}
+    # about 12 s of CPU work: the same prefix length on successive videos (one video's potentials at a time in memory)
+    keys = sorted(data._videos)
+    frames_done, dt, n_done = 0, 0.0, 0
+    for (tk, nm) in keys:
+        smp = data._videos[(tk, nm)]
+        feats_all = smp['features'].cpu().float()
+        cv = len(smp['task_indices'])
+        tt = int(min(t, feats_all.shape[0], 2.0e9 / (4.0 * k_all * (cv + 1) ** 2)))
+        dt += run(tt)
+        frames_done += tt
+        n_done += 1
+        if dt > 12.0:
+            break
+    return {"value": frames_done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "first <= %d frames of each of %d videos (C=%d.., K=%d, D=%d): dense b x N x K x C x C fp32 "
+                      "potentials + sequential max-DP with back-pointers (oracle/dense_ref.py), %.1f s in all"
+                      % (t, n_done, c, m.max_k, feats_all.shape[-1], dt)}
 
 
 def cpu_factored(pc, model, max_videos=8):

@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the two-CU PAIR mode (leader / follower workgroups exchanging rows through HBM with
+"""Randomised parity sweeps.  First: the two-CU PAIR mode (leader / follower workgroups exchanging rows through HBM with
 progress counters): many shapes in one process, every video forced into a pair, bit-exact against the C twin.
 A visibility or ordering bug in the exchange shows up here as a sporadic mismatch."""
 import numpy as np
@@ -40,3 +40,23 @@ def test_pair_mode_repeated_launches_are_identical(monkeypatch):
         out = run_gpu(p)
         for key in ('best', 'spans', 'labels', 'n_segs'):
             np.testing.assert_array_equal(out[key], ref[key])
+
+
+@pytest.mark.parametrize('chunk', range(5))
+def test_random_shapes_all_ring_sizes(chunk, monkeypatch):
+    """The same sweep over every ring size (K from 2 to 1024), 1..32 states, ragged batches, automatic gang choice:
+    whichever kernel configuration the dispatcher picks must reproduce the C twin bit for bit."""
+    monkeypatch.delenv('SMM_PAIRS', raising=False)
+    g = np.random.default_rng(7000 + chunk)
+    for it in range(12):
+        k = int(g.choice([2, 3, 7, 20, 64, 65, 100, 128, 200, 256, 300, 512, 513, 800, 1024]))
+        c = int(g.integers(1, 33))
+        if k > 512 and c > 23:
+            c = int(g.integers(1, 24))                          # (24+ states at K > 512: the spilling path has its own test)
+        b = int(g.integers(1, 9))
+        tmax = int(g.integers(max(2, min(k, 40)), 1500 if k > 512 else 700))
+        p = make_problem(int(g.integers(0, 10 ** 6)), b, tmax, c, k, ends=bool(g.integers(0, 2)),
+                         scale=float(g.choice([0.5, 3.0])), min_len=int(g.integers(1, 40)))
+        out = run_gpu(p)
+        spans, v = run_oracle(p)
+        check(p, out, spans, v)

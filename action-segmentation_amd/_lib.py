@@ -3,7 +3,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsmmdp.so")
+LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(HERE, "libsmmdp.so")   # (override: diagnostic builds only)
 
 SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",

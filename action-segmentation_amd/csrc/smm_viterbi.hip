@@ -217,9 +217,12 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
 __device__ __forceinline__ int smm_pair_cl(int C, int nfol)
 {
     if (nfol == 2) return 0;
+    // measured (T = 4096, 64 pairs): up to 16 states the follower's SIMDs should hold at most 3 rings each (cl = C - 12);
+    // above, the follower is full anyway and the leader -- two long rings on a SIMD already cost more than the chain
+    // wave's time -- keeps as few as the follower's capacity of 16 allows, at least 3 (one per SIMD)
     int cl = C > 12 ? C - 12 : 0;
-    if (cl > 5) cl = 5;
-    if (C - cl > 16) cl = C - 16;                             // 22..23 states with one follower: 6..7
+    if (C > 16 && cl > 3) cl = 3;
+    if (C - cl > 16) cl = C - 16;                             // 20..23 states with one follower: 4..7
     return cl;
 }
 // states c0 .. c0+nf-1 of follower f

@@ -23,6 +23,10 @@ def probe(b, T, C, K, cmax=None, reps=3):
         ts.append(e0.elapsed_time(e1))
     ms = min(ts)
     print(f"b={b} T={T} C={C} K={K} pairs={os.environ.get('SMM_PAIRS','auto')}: {ms:.3f} ms  ns/frame/video={ms*1e6/T:.0f}", flush=True)
+if os.environ.get('SMM_PAIRS'):
+    for c in (13, 15, 16, 17, 19, 20, 21):       # forced gangs: SMM_PAIRS / SMM_TRIPLES from the environment
+        probe(64, 4096, c, 1024)
+    sys.exit(0)
 for c in (21, 22, 23):
     for pairs in ('0', None):
         if pairs is None:

@@ -107,18 +107,15 @@ struct Staged {
     bool pairs_cover_big;  // every video with more than 21 states is among them
 };
 
-// Two-CU pairs for the longest videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the time of its longest
-// videos while other CUs idle; a paired video runs ~1.7x faster on two CUs.  Cost model in ns per frame (measured on
-// MI355X at K = 1024): one CU: the most loaded SIMD's states x 73, at least the chain wave's 230; two CUs: the chain
-// wave's latency: 265 on two CUs (<= 16 states), 300 on three CUs (more states: two followers).
-// n_pairs = the count (all pairs within the first wave of workgroups: 2 n_pairs <= CUs, so leader and follower are
-// co-resident) that minimises the simulated makespan of a longest-first list schedule.
+// Gangs of two or three CUs for the most expensive videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the
+// time of its longest videos while other CUs idle; choose_pairs() below picks which videos ride in gangs by simulating a
+// longest-first list schedule with a measured cost model (ns per frame, see there).  frame_ns_single: one CU.
 static double frame_ns_single(int c)
 {
     int nv[7];
     for (int r = 0; r < 7; ++r) nv[r] = c > r ? (c - r + 6) / 7 : 0;
     const int load = std::max(std::max(nv[0] + nv[4], nv[1] + nv[5]), nv[2] + nv[3]);
-    return std::max(230.0, 73.0 * load) + 5.0;
+    return std::max(310.0, 73.0 * load) + 15.0;
 }
 
 // Reorders `order` (most work first on entry) into [gang videos | single videos], both most work first, sets
@@ -126,9 +123,9 @@ static double frame_ns_single(int c)
 // the number of gangs.  Videos with more than 21 states MUST ride in a gang (a single 8-wave workgroup holds 21
 // rings): *big_ok says whether all of them do (else the caller falls back to the 12-wave configuration, without
 // gangs).  Optional gangs: the n most expensive eligible videos, the first n3 of them (above 16 states) as triples;
-// (n, n3) chosen by simulating a list schedule in grid order.  Cost model, ns per frame (measured at K = 1024): one
-// CU: the most loaded SIMD's states x 73, at least the chain wave's 230; pair: 265 (<= 16 states: the chain wave's
-// latency), 355 above (isolated measurements say 375..405, but the simulated choices are better with 355); triple: 300.
+// (n, n3) chosen by simulating a list schedule in grid order.  Cost model, ns per frame including the back-trace
+// (measured at K = 1024, T = 4096, 64 videos at a time): one CU: the most loaded SIMD's states x 73, at least 310,
+// + 15; pair: 265 (<= 15 states), 320 (16), 360 (17..23); triple: 325.
 static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need, bool *big_ok)
 {
     *big_ok = false;
@@ -155,7 +152,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     auto states = [&](int32_t v) { return n_states[hv[v].group]; };
     auto gang_ns = [&](int32_t v, int nfol) {
         const int c = states(v);
-        return hv[v].T * (nfol == 2 ? 300.0 : (c > 16 ? 355.0 : 265.0));
+        return hv[v].T * (nfol == 2 ? 325.0 : (c > 16 ? 360.0 : (c > 15 ? 320.0 : 265.0)));
     };
     auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(states(v)); };
     // the gang list for (n optional gangs, n3 triples): must + opt[0..n), most expensive first; the first n3 of its

@@ -85,9 +85,32 @@ class BatchSampler(Sampler):
         return len(self.batches)
 
 
-def make_data_loader(args, datasplit, shuffle, batch_by_task, batch_size=1):
+def batch_cost(datasplit, keys, max_k):
+    """~ DP work of one single-task batch: sum over its videos of T * ((K-1) * C + C^2) lattice cells."""
+    cost = 0.0
+    for key in keys:
+        smp = datasplit[key]
+        if smp is None:
+            continue
+        t = int(smp['features'].shape[0])
+        c = len(smp['task_indices']) if smp.get('task_indices') is not None else datasplit.corpus.n_classes
+        cost += t * ((min(max_k, t + 1) - 1) * c + c * c)
+    return cost
+
+
+def make_data_loader(args, datasplit, shuffle, batch_by_task, batch_size=1, shard=None):
+    """``shard=(rank, world)``: keep only this rank's share of the batches (whole single-task batches, so the one
+    batch-dependent quantity of the reference -- K clipped to the batch's padded length -- is unchanged; greedy
+    longest-processing-time assignment on the DP work, the same on every rank without communication)."""
+    sampler = datasplit.batch_sampler(batch_size, batch_by_task, shuffle)
+    if shard is not None and shard[1] > 1:
+        from .distributed import shard_batches
+        assert not shuffle, "shards are cut from the deterministic batch order"
+        max_k = getattr(args, 'sm_max_span_length', None) or 1
+        costs = [batch_cost(datasplit, keys, max_k) for keys in sampler.batches]
+        sampler.batches = [sampler.batches[i] for i in shard_batches(sampler.batches, costs, shard[0], shard[1])]
     return DataLoader(datasplit, num_workers=getattr(args, 'workers', 0), collate_fn=padding_colate,
-                      batch_sampler=datasplit.batch_sampler(batch_size, batch_by_task, shuffle))
+                      batch_sampler=sampler)
 
 
 class PackedCorpus:

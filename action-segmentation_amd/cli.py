@@ -74,15 +74,90 @@ def optimal_assignment_for(args):
     return not ('train' in args.sm_constrain_with_narration or 'test' in args.sm_constrain_with_narration)
 
 
-def evaluate(model, data, name, args=None):
-    """main.py:126-160 ``test``: decode, then the per-task statistics of ``accuracy_corpus`` summed over tasks."""
+def _reduce():
+    """Summation over the ranks of a torchrun job for the evaluation counters (None for one process)."""
+    from . import distributed
+    return distributed.all_reduce_tensor if distributed.active() else None
+
+
+def evaluate(model, data, name, args=None, verbose=True):
+    """main.py:125-160 ``test``: decode, then the per-task statistics of ``accuracy_corpus`` summed over tasks.
+    Under torchrun every rank decodes its shard of the videos and the counters are all-reduced (RCCL) first."""
     preds = model.predict(data)
     by_task = accuracy_corpus(data, preds, optimal_assignment_for(args) if args is not None else False,
-                              seed=getattr(args, 'seed', 0) if args is not None else 0)
+                              seed=getattr(args, 'seed', 0) if args is not None else 0, reduce=_reduce())
     stats = summarise(by_task, STAT_KEYS, prefix=name + '_')
-    print(', '.join(STAT_KEYS))
-    print(', '.join('%.4f' % stats[name + '_' + k] for k in STAT_KEYS))
+    if verbose:
+        print(', '.join(STAT_KEYS))
+        print(', '.join('%.4f' % stats[name + '_' + k] for k in STAT_KEYS))
     return preds, stats
+
+
+def train(args, train_data, dev_data, split_name, verbose=False, train_sub_data=None):
+    """main.py:163-264: fit with a per-epoch callback that decodes train (or a train subset) and -- every
+    ``--dev_decode_frequency`` epochs -- dev, keeps a ``pickle.dumps`` snapshot of the model per epoch, writes
+    ``<out>/<split>_epoch-N.pkl`` every 5 epochs, and finally selects the best snapshot: best dev MoF for supervised
+    training (early stopping on dev), lowest training loss for unsupervised training.  The closed-form supervised fit
+    has no epochs and never calls back (semimarkov.py:165-171); its model is returned as is."""
+    model = CLASSIFIERS[args.classifier].from_args(args, train_data)
+    use_labels = args.training == 'supervised'
+    early_stopping_on_dev = use_labels
+    models_by_epoch, dev_mof_by_epoch, stats_by_epoch = {}, {}, {}
+    rank0 = int(os.environ.get('RANK', 0)) == 0
+
+    def callback_fn(epoch, stats):
+        stats_by_epoch[epoch] = stats
+        name = 'train_subset' if train_sub_data is not None else 'train'
+        split_stats = [evaluate(model, train_sub_data if train_sub_data is not None else train_data, name, args,
+                                verbose=verbose)[1]]
+        dev_stats = None
+        if epoch == -1 or epoch % args.dev_decode_frequency == 0:
+            dev_stats = evaluate(model, dev_data, 'dev', args, verbose=verbose)[1]
+            split_stats.append(dev_stats)
+        log = '%s\tepoch %2d' % (split_name, epoch)
+        for stat, value in stats.items():
+            log += ('\t%s %.4f' % (stat, value)) if isinstance(value, float) else ('\t%s %s' % (stat, value))
+        for st in split_stats:
+            log += '\n' + ''.join(' %s %.4f' % (k, v) for k, v in sorted(st.items()))
+        if rank0:
+            print(log)
+        models_by_epoch[epoch] = pickle.dumps(model)
+        if dev_stats is not None:
+            dev_mof_by_epoch[epoch] = dev_stats['dev_mof']
+        if args.model_output_path and epoch % 5 == 0 and rank0:
+            os.makedirs(args.model_output_path, exist_ok=True)
+            fname = os.path.join(args.model_output_path, '%s_epoch-%d.pkl' % (split_name, epoch))
+            print("writing model to %s" % fname)
+            with open(fname, 'wb') as f:
+                pickle.dump(model, f)
+
+    model.fit(train_data, use_labels=use_labels, callback_fn=callback_fn)
+    if early_stopping_on_dev and dev_mof_by_epoch:
+        best_epoch, best_mof = max(dev_mof_by_epoch.items(), key=lambda t: t[1])
+        if rank0:
+            print("best dev mof %.4f in epoch %d" % (best_mof, best_epoch))
+        best = pickle.loads(models_by_epoch[best_epoch])
+    elif stats_by_epoch and 'train_loss' in next(iter(stats_by_epoch.values())):
+        best_epoch, best_stats = min(stats_by_epoch.items(), key=lambda t: t[1]['train_loss'])
+        if rank0:
+            print("best train loss %.4f in epoch %d" % (best_stats['train_loss'], best_epoch))
+        best = pickle.loads(models_by_epoch[best_epoch])
+    else:
+        best = model
+    train.last_history = dict(stats_by_epoch=stats_by_epoch, dev_mof_by_epoch=dev_mof_by_epoch)
+    if best is not model and args.cuda:
+        best.model.cuda()
+    if args.model_output_path and rank0:
+        os.makedirs(args.model_output_path, exist_ok=True)
+        fname = make_model_path(args.model_output_path, split_name)
+        print("writing model to %s" % fname)
+        with open(fname, 'wb') as f:
+            pickle.dump(best, f)
+    return best
+
+
+def make_model_path(path, split_name):
+    return path if path.endswith('.pkl') else os.path.join(path, '%s.pkl' % split_name)
 
 
 def main(argv=None):
@@ -95,31 +170,25 @@ def main(argv=None):
                          % (args.dataset, '|'.join(synth.CONFIGS)))
     if not args.cuda:
         raise SystemExit("--cuda is required: the semi-Markov path has no CPU back-end in this build")
+    from . import distributed
+    distributed.init()                                      # torchrun: one rank per GPU, decode sharded by video
     cfg_name = args.dataset.split(':', 1)[1]
+    split_name = 'synthetic'
     torch.manual_seed(args.seed)
     dev = torch.device('cuda', torch.cuda.current_device())
-    train = synth.SynthDatasplit(cfg_name, seed=args.seed, device=dev)
-    test = synth.SynthDatasplit(cfg_name, seed=args.seed, video_seed=1, device=dev)          # same label space
+    train_data = synth.SynthDatasplit(cfg_name, seed=args.seed, device=dev)
+    test_data = synth.SynthDatasplit(cfg_name, seed=args.seed, video_seed=1, device=dev)     # same label space
     if args.model_input_path:
-        with open(os.path.join(args.model_input_path, 'synthetic.pkl'), 'rb') as f:
+        with open(make_model_path(args.model_input_path, split_name), 'rb') as f:
             model = pickle.load(f)
         model.args = args
         model.model.args = args
         model.model.cuda()
         model.model.eval()
     else:
-        model = CLASSIFIERS[args.classifier].from_args(args, train)
-        history = []
-        model.fit(train, use_labels=(args.training == 'supervised'),
-                  callback_fn=lambda epoch, stats: history.append((epoch, stats)))
-        for epoch, stats in history:
-            print('epoch %d: %s' % (epoch, stats))
-        if args.model_output_path:
-            os.makedirs(args.model_output_path, exist_ok=True)
-            with open(os.path.join(args.model_output_path, 'synthetic.pkl'), 'wb') as f:
-                pickle.dump(model, f)
-    evaluate(model, train, 'train', args)
-    preds, stats = evaluate(model, test, 'test', args)
+        model = train(args, train_data, test_data, split_name)
+    evaluate(model, train_data, 'train', args)
+    preds, stats = evaluate(model, test_data, 'test', args)
     if args.prediction_output_path:
         os.makedirs(args.prediction_output_path, exist_ok=True)
         for video, pred in preds.items():

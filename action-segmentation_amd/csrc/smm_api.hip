@@ -42,6 +42,29 @@ extern "C" int smm_device_count(void)
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------ metadata upload
+struct SmmMetaChunk { uint32_t w[512]; };
+
+__global__ void __launch_bounds__(512) smm_meta_upload_kernel(SmmMetaChunk c, uint32_t *dst, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.w[threadIdx.x];
+}
+
+int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream)
+{
+    const size_t words = (bytes + 3) / 4;                    // (every destination is padded to 256 B by the planners)
+    const unsigned char *src = static_cast<const unsigned char *>(src_host);
+    for (size_t off = 0; off < words; off += 512) {
+        SmmMetaChunk c;
+        const size_t n = std::min<size_t>(512, words - off);
+        const size_t nb = std::min<size_t>(n * 4, bytes - off * 4);
+        std::memset(&c, 0, sizeof(c));
+        std::memcpy(c.w, src + off * 4, nb);
+        hipLaunchKernelGGL(smm_meta_upload_kernel, dim3(1), dim3(512), 0, stream, c, static_cast<uint32_t *>(dst_dev) + off, (int)n);
+    }
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ planning
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -281,8 +304,10 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
 
     char *base = static_cast<char *>(ws);
-    // pageable source: the runtime copies it out before returning, so `host` may die with this frame
-    SMM_HIP(hipMemcpyAsync(base, host.data(), p.meta_bytes, hipMemcpyHostToDevice, stream));
+    // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream);
+    // the error word and the gang counters behind them start at zero
+    SMM_HIP((hipError_t)smm_upload_meta(base, host.data(), p.o_err, stream));
+    SMM_HIP(hipMemsetAsync(base + p.o_err, 0, p.meta_bytes - p.o_err, stream));
     out->videos = reinterpret_cast<SmmVideo *>(base);
     out->order = reinterpret_cast<int32_t *>(base + p.o_order);
     out->n_states = reinterpret_cast<int32_t *>(base + p.o_nstates);
@@ -503,7 +528,7 @@ extern "C" int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host
     a.beta = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c));
     a.bp_from = reinterpret_cast<uint8_t *>(base + dense_off(cur, (size_t)b * n1 * k * c));
     a.bp_k = reinterpret_cast<uint16_t *>(base + dense_off(cur, sizeof(uint16_t) * (size_t)b * (n1 + 1) * c));
-    SMM_HIP(hipMemcpyAsync(dlen, lengths_host, sizeof(int64_t) * b, hipMemcpyHostToDevice, hs));
+    SMM_HIP((hipError_t)smm_upload_meta(dlen, lengths_host, sizeof(int64_t) * b, hs));
     a.edge = scores; a.lengths = dlen; a.v = v; a.spans = spans;
     a.b = b; a.n1 = n1; a.k = k; a.c = c;
     smm_launch_dense(a, semiring != 0, hs);

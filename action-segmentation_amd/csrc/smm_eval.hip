@@ -20,6 +20,7 @@
 
 #include "../../include/smmdp.h"
 #include "smm_device.h"
+#include "smm_launch.h"
 
 #define SMM_EVAL_THREADS 256
 #define SMM_EVAL_CHUNK 4096          // frames per workgroup of the confusion kernel
@@ -313,8 +314,8 @@ static int ev_stage(const smm_eval_shape *s, const int64_t *lengths, const int64
         off += 4 * (size_t)(lengths[i] + 1);
     }
     char *base = static_cast<char *>(ws);
-    // pageable source: copied out before the call returns
-    if (hipMemcpyAsync(base, hv.data(), sizeof(SmmEvalVideo) * s->b, hipMemcpyHostToDevice, stream) != hipSuccess)
+    // through kernel arguments: no pageable host-to-device copy, the host never waits for the stream (smm_launch.h)
+    if (smm_upload_meta(base, hv.data(), sizeof(SmmEvalVideo) * s->b, stream) != (int)hipSuccess)
         return SMM_ERR_HIP;
     std::memset(a, 0, sizeof(*a));
     a->videos = reinterpret_cast<const SmmEvalVideo *>(base);

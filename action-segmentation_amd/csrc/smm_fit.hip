@@ -16,6 +16,7 @@
 
 #include "../../include/smmdp.h"
 #include "smm_device.h"
+#include "smm_launch.h"
 
 #define SMM_FIT_ROWS 1024        // frames per workgroup of the class-sum kernel (256 per wave)
 #define SMM_FIT_UNROLL 8
@@ -183,7 +184,7 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
     char *base = static_cast<char *>(ws);
     const size_t o_err = (sizeof(SmmFitVideo) * (size_t)b + 63) / 64 * 64;
 #define SMM_FIT_HIP(call) do { if ((call) != hipSuccess) return SMM_ERR_HIP; } while (0)
-    SMM_FIT_HIP(hipMemcpyAsync(base, hv.data(), sizeof(SmmFitVideo) * b, hipMemcpyHostToDevice, stream));
+    SMM_FIT_HIP((hipError_t)smm_upload_meta(base, hv.data(), sizeof(SmmFitVideo) * b, stream));
     SMM_FIT_HIP(hipMemsetAsync(base + o_err, 0, 64, stream));
     const size_t n = (size_t)n_classes;
     SMM_FIT_HIP(hipMemsetAsync(sum_x, 0, sizeof(double) * n * d, stream));

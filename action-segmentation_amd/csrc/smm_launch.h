@@ -16,6 +16,11 @@ struct SmmEmArgs {
     int32_t d, c_max, b;
 };
 
+// Host metadata -> device, stream-ordered, WITHOUT a host-to-device copy: the bytes travel in the kernel-argument
+// segment of tiny copy kernels (2 KB per launch).  A hipMemcpyAsync from pageable host memory makes the host wait until
+// the stream has drained (and cannot be captured into a hipGraph); this does neither.  Returns a hipError_t as int.
+int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream);
+
 void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, int64_t total_frames, hipStream_t stream);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group

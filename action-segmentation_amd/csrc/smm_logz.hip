@@ -7,58 +7,145 @@
 //     beta[n][to] = LSE_c ( gamma[n][c] + trans[to][c] ),           h = beta - cumE,
 //     logZ = LSE over the last position's labels (EOS via endpen, real labels with the -1e9 of em+[T]).
 //
-// Same wave roles as the Viterbi kernel (one chain wave, lane = state; pusher waves owning SPW states with the
-// K-proportional work in registers; one barrier per frame).  What changes is the accumulator: a ring slot keeps an
-// ONLINE log-sum-exp  (m = running max in fp64, s = sum of exp(x - m) in fp32)  so that nothing can overflow although
-// h[s][c] drifts by tens of nats per frame.  Per lattice cell: x = h + len (fp64), d = x - m (fp64 -> fp32),
-// e = exp(-|d|) (one v_exp_f32), s = d > 0 ? s*e + 1 : s + e, m = max(m, x): one transcendental per cell.
-// fp32 sums of <= 4096 terms in (0, 1] give log s to ~1e-6 absolute; the tolerance of the path is 1e-4 RELATIVE on
-// logZ ~ 1e5..1e6.
+// Kernel v2: the structure of the Viterbi kernel's generation 4 (smm_viterbi.hip) -- one chain wave (lane = state)
+// that owns the serial part and evaluates the K0 = 2B shortest segment lengths itself, pusher waves that own the
+// K-proportional work in register-resident rings, hand-over in BLOCKS of B positions with one barrier per block, HBM
+// traffic (elp prefetch, history stores) moved block-wise by one pusher wave -- with a ring slot made for the log
+// semiring:
+//
+//   A slot keeps its running sum as  S * 2^M  relative to a per-state reference:  M an INTEGER-valued fp32 exponent,
+//   S an fp32 sum, the length score L of the slot as fp32 in log2 units (3 registers per slot; Viterbi: 4).  Per state
+//   the wave keeps ref = ceil(running max of h * log2 e), an integer-valued double.  A block of B sources is folded into
+//   a slot at once (the "online softmax" of B candidates):
+//       t_i = c0_i + L_i           c0_i = (float)(h_i * log2 e - ref)  (wave-uniform, <= 0 up to rounding)
+//       M'  = max(M, ceil(max_i t_i));     S' = S * 2^(M - M') + sum_i 2^(t_i - M')
+//   = B adds, B/2 max3, B subs, B+1 v_exp_f32, B adds and 4 more per slot and block: ~33 issue cycles per lattice
+//   cell at B = 4 against ~55 for the per-cell fp64 online log-sum-exp of kernel v1, and nothing spills at 21..28
+//   states x 1024 slots.  When ref moves up by D (an integer) every slot's M moves down by D: integer arithmetic in
+//   fp32, exact, so exponents never drift however long a slot lives.
+//
+//   Accuracy.  S' is a sum of at most 1024 terms in (0, 1] plus rescalings by powers of two (exact): relative error
+//   <= 1024 * 2^-24 worst case, ~2^-21 typically (1e-6 in log space).  A candidate's exponent t_i is rounded to fp32:
+//   absolute error 2^-24 |t_i| log2-units, i.e. 4e-8 x (how far the candidate lies below the state's running
+//   maximum + |its length score|) nats -- 2e-5 nats for a candidate 500 nats down, which is also what kernel v1's fp32
+//   copy of the length table cost.  Candidates that carry posterior mass sit within a few hundred nats of the
+//   reference; candidates thousands of nats down are rounded coarsely and weigh e^-1000.  The
+//   tolerance of the path is 1e-4 RELATIVE on logZ ~ 1e5 and 1e-4 on posteriors; the tests hold 1e-6 / 2e-5.
 #include "smm_device.h"
 #include "smm_launch.h"
 #include "../../include/smmdp.h"
 
 #define SMM_LOG2E 1.4426950408889634
 #define SMM_LN2 0.6931471805599453
-#define SMM_MASKED (-1e300)      // "never": finite so that (-inf) - (-inf) cannot happen in x - m
-#define SMM_MASKED_F (-3.0e38f)  // the same for the fp32 copy of the length table kept in the rings
+#define SMM_M_EMPTY (-1e30f)     // exponent of an empty slot (finite: M - M' must never be inf - inf)
 
-__device__ __forceinline__ float smm_exp_neg_abs(float d)   // exp(-|d|)
-{
-    return __builtin_amdgcn_exp2f(-fabsf(d) * (float)SMM_LOG2E);
-}
+#ifndef SMM_LZ_B
+#define SMM_LZ_B 4               // positions per hand-over block
+#endif
 
-// online LSE update of (m, s) with x
-__device__ __forceinline__ void smm_lse_push(double &m, float &s, double x)
-{
-    const float d = (float)(x - m);
-    const float e = smm_exp_neg_abs(d);
-    const bool gt = d > 0.f;
-    s = fmaf(s, gt ? e : 1.f, gt ? 1.f : e);
-    m = smm_fmax(m, x);
-}
-
-// value of an accumulator: m + log(s)   (s >= 1 whenever anything finite was pushed)
-__device__ __forceinline__ double smm_lse_value(double m, float s)
-{
-    return m + (double)(__builtin_amdgcn_logf(s) * (float)SMM_LN2);
-}
+__device__ __forceinline__ float smm_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // log(exp(a) + exp(b)) for doubles of any magnitude, transcendental part in fp32
 __device__ __forceinline__ double smm_lse2(double a, double b)
 {
     const double mx = smm_fmax(a, b);
     const float d = (float)(a - b);
-    const float t = __builtin_amdgcn_logf(1.f + smm_exp_neg_abs(d)) * (float)SMM_LN2;
+    const float t = __builtin_amdgcn_logf(1.f + smm_exp2f(-fabsf(d) * (float)SMM_LOG2E)) * (float)SMM_LN2;
     return (mx == SMM_NEG_INF) ? mx : mx + (double)t;
 }
 
-template <int R, int SPW, int NW, int HF>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, NW / 4)))
-smm_logz_kernel(SmmDpArgs a, double *logz)
+// One block (B sources) of one state's ring.  Same slot / register / rotation scheme as smm_ring_block of the Viterbi
+// kernel: push step t = s + B - 1, u = t mod R; logical length register r lives in physical register (r - u) mod R and
+// one register crosses lanes per step.  The B candidates of a slot are gathered first (register aliases, no copies:
+// the loops are unrolled) and folded in together.
+template <int R, int B>
+__device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R], float (&L)[R], double &ref, double &hd,
+                                                   const double *h_blk, double *a_blk, int j, int jj, int lane)
 {
     constexpr int RING = 64 * R;
+    double src[B];
+    {
+        double hv[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
+        src[0] = hd;                                       // D = 1: the last row of the block before
+#pragma unroll
+        for (int i = 1; i < B; ++i) src[i] = hv[i - 1];
+        hd = hv[B - 1];
+    }
+    // reference of the state: integer-valued, only ever moves up
+    double hm = src[0];
+#pragma unroll
+    for (int i = 1; i < B; ++i) hm = smm_fmax(hm, src[i]);
+    const double nr = smm_fmax(ref, __builtin_ceil(hm * SMM_LOG2E));
+    const float dlt = (float)(nr - ref);
+    ref = nr;
+    float c0[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) c0[i] = (float)(src[i] * SMM_LOG2E - nr);
+    // the length score every slot sees at each of the B steps, and the rotation of the ring
+    float Ls[B][R];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+        const int u = (jj * B + i) % R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) Ls[i][r] = L[(r - u + R) % R];
+        L[(2 * R - 1 - u) % R] = smm_wave_ror1f(L[(2 * R - 1 - u) % R]);
+    }
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        const float mr = M[r] - dlt;                       // (an empty slot stays at -1e30)
+        float t[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) t[i] = c0[i] + Ls[i][r];
+        float tm = t[0];
+#pragma unroll
+        for (int i = 1; i < B; ++i) tm = fmaxf(tm, t[i]);
+        const float mn = fmaxf(mr, __builtin_ceilf(tm));
+        float acc = S[r] * smm_exp2f(mr - mn);
+#pragma unroll
+        for (int i = 0; i < B; ++i) acc += smm_exp2f(t[i] - mn);
+        M[r] = mn;
+        S[r] = acc;
+    }
+    // hand A' of block j+1 to the chain wave (nats, fp64) and clear those slots
+    auto hand = [&](int r, double *dst) {
+        const float lg = __builtin_amdgcn_logf(S[r]);      // log2; -inf for an empty slot
+        *dst = (S[r] > 0.f) ? (ref + (double)(M[r] + lg)) * SMM_LN2 : SMM_NEG_INF;
+        M[r] = SMM_M_EMPTY;
+        S[r] = 0.f;
+    };
+    if constexpr (R % B == 0) {
+        if (lane == (((j + 1) * B) & (RING - 1)) / R) {
+#pragma unroll
+            for (int i = 0; i < B; ++i) hand(((jj + 1) * B + i) % R, &a_blk[i * SMM_MAX_STATES_DEV]);
+        }
+    } else if constexpr (B % R == 0) {
+        const int d = lane - (((j + 1) * B) & (RING - 1)) / R;
+        if (d >= 0 && d < B / R) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) hand(r, &a_blk[(d * R + r) * SMM_MAX_STATES_DEV]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            if (lane == (((j + 1) * B + i) & (RING - 1)) / R) hand(((jj + 1) * B + i) % R, &a_blk[i * SMM_MAX_STATES_DEV]);
+        }
+    }
+}
+
+// R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
+// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
+template <int R, int SPW, int NW, int HF>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
+smm_logz_kernel(SmmDpArgs a, double *logz)
+{
+    constexpr int B = SMM_LZ_B;
+    constexpr int K0 = 2 * B;                              // segment lengths the chain wave evaluates itself (D = 1)
     constexpr int NP = NW - 1;
+    constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
+    constexpr int MQ = 4 * B;                              // chain wave: h[n] of the last MQ > K0 positions, slot n mod MQ
+    constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
     const int vid = a.order[blockIdx.x];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T;
@@ -76,110 +163,265 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
     // bwd (a.flags bit 1): the same recursion on the time-reversed video with the transposed transition table gives
     // the backward messages (see smm_logz_bwd.hip); its history goes to the second half of the video's block.
+    // no_eos (a.flags bit 3): add_eos=False of the reference (modules:494-505): T counts the frames BEFORE the last one;
+    // the video closes with a transition into the label of frame T, which only emits (no length score, no EOS).
     const bool bwd = (a.flags & 2) != 0;
+    const bool no_eos = (a.flags & 8) != 0;
     double *hcum = a.hist + mv.hist_off + (bwd ? (size_t)3 * cm * (T + 1) : 0);   // [T+1][cm]  cumE[n][c]
     double *hh = hcum + (size_t)cm * (T + 1);             // [T+1][cm]  h[n][c]   (log-weight of "a span of c starts at n" - cumE)
     double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c] (log-weight of "a span of c ends at n")
 
-    __shared__ __attribute__((aligned(16))) double sh_am[2][SMM_MAX_STATES_DEV];    // A'[n][c] max part   pushers -> chain
-    __shared__ float sh_as[2][SMM_MAX_STATES_DEV];                                  // A'[n][c] sum part
-    __shared__ __attribute__((aligned(16))) double sh_h[2][SMM_MAX_STATES_DEV];     // h[n][c]  chain -> pushers
-    __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];      // gamma[n][.] chain-private broadcast
-    __shared__ __attribute__((aligned(16))) double sh_elp[2][64 * SMM_MAX_STATES_DEV];
+    // block q = positions qB+1 .. (q+1)B, buffer q & 1
+    __shared__ __attribute__((aligned(16))) double sh_apart[2][B][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
+    __shared__ __attribute__((aligned(16))) double sh_h[2][B][SMM_MAX_STATES_DEV];       // h[n][c]    chain -> pushers, HBM
+    __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
+    __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
+    __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
+    __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
+    __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
+    __shared__ double sh_h0[SMM_MAX_STATES_DEV];
 
     if (T <= 0) return;
+    // frame of the (possibly time-reversed) video behind position n-1 .. : row i of the DP <-> frame fr(i)
+    auto frame_of = [&](int i) { return bwd ? T - 1 - i : i; };
     if (threadIdx.x < SMM_MAX_STATES_DEV) {
         const int c = threadIdx.x;
         // start weights: forward = init; backward = weight of "the video ends after a span of c":
-        // LSE(endpen[c], LSE_to(trans[to][c]) - 1e9)  (a.trans is the transposed table in that mode: row c)
-        double h0 = 0.0;
+        //   EOS:    LSE(endpen[c], LSE_to(trans[to][c]) - 1e9)      (a.trans is the transposed table in that mode: row c)
+        //   no EOS: LSE_to(trans[to][c] + elp[T][to])
+        double h0 = SMM_NEG_INF;
         if (c < C) {
             if (!bwd) {
                 h0 = init[c];
+            } else if (no_eos) {
+                for (int t2 = 0; t2 < C; ++t2) h0 = smm_lse2(h0, trans[(size_t)c * cm + t2] + elp[(size_t)T * cm + t2]);
             } else {
                 double alt = SMM_NEG_INF;
                 for (int t2 = 0; t2 < C; ++t2) alt = smm_lse2(alt, trans[(size_t)c * cm + t2]);
                 h0 = smm_lse2(endpen ? endpen[c] : 0.0, alt + SMM_BIG_NEG);
             }
         }
-        sh_h[0][c] = h0;
-        sh_h[1][c] = 0.0;
-        sh_am[0][c] = SMM_NEG_INF; sh_am[1][c] = SMM_NEG_INF;
-        sh_as[0][c] = 0.f; sh_as[1][c] = 0.f;
+        sh_h0[c] = h0;
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            sh_apart[0][i][c] = SMM_NEG_INF;              // block 0 needs no pusher source
+            sh_apart[1][i][c] = SMM_NEG_INF;
+            sh_h[0][i][c] = SMM_NEG_INF;
+            sh_h[1][i][c] = (i == B - 1) ? h0 : SMM_NEG_INF;     // "block -1": only position 0 exists
+            sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)frame_of(i) * cm + c] : 0.0;    // block 0
+        }
         sh_gam[c] = SMM_NEG_INF;
         if (c < C) { hcum[c] = 0.0; hh[c] = h0; }
     }
-    {
-        const int nfr = (T < 64) ? T : 64;
-        for (int i = threadIdx.x; i < nfr * cm; i += blockDim.x) {
-            const int j = i / cm, c = i - j * cm;
-            sh_elp[0][i] = elp[(size_t)(bwd ? T - 1 - j : j) * cm + c];
-        }
-    }
     __syncthreads();
 
+    constexpr int NE = (B * SMM_MAX_STATES_DEV + 63) / 64;   // block elements per lane of the mover
+    const int J = (T + B - 1) / B;                         // blocks; one barrier each, in every wave
     if (w == 0) {
         // ============================================================================ chain wave (lane = state)
         __builtin_amdgcn_s_setprio(3);
         const int to = lane & 31, half = lane >> 5;
         const bool live = to < C;
-        double tr[HF];
+        double tr[HF];                                    // trans[to][half*HF + i]
 #pragma unroll
         for (int i = 0; i < HF; ++i) {
             const int f = half * HF + i;
             tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
         }
-        const double len1 = (live && kp >= 2) ? len[(size_t)cm + to] : SMM_NEG_INF;
+        double lk[K0 + 1];                                // len[k][to], k = 1..K0
+#pragma unroll
+        for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
+        double hq[MQ];                                    // h[n][to], slot n mod MQ
+#pragma unroll
+        for (int i = 0; i < MQ; ++i) hq[i] = SMM_NEG_INF;
+        hq[0] = live ? sh_h0[to] : SMM_NEG_INF;
         double cum = 0.0;
-        double hcur = live ? sh_h[0][to] : SMM_NEG_INF;
-        double enext = live ? sh_elp[0][to] : 0.0;
-        for (int n = 0; n < T; ++n) {
-            const double ecurv = enext;
-            const int nn = n + 1;
-            enext = (live && nn < T) ? sh_elp[(nn >> 6) & 1][(nn & 63) * cm + to] : 0.0;
-            // A[nn] = LSE( sources <= n-1 (from the pushers), source n with k = 1 (own registers) )
-            const double am = sh_am[nn & 1][to];
-            const float as = sh_as[nn & 1][to];
-            const double apart = (as > 0.f) ? smm_lse_value(am, as) : SMM_NEG_INF;
-            const double acc = smm_lse2(apart, hcur + len1);
-            cum = cum + ecurv;
-            const double gm = cum + acc;
-            if (half == 0 && live) {
-                sh_gam[to] = gm;
-                hgam[(size_t)nn * cm + to] = gm;
-                hcum[(size_t)nn * cm + to] = cum;
-            }
-            if (nn < T) {
-                // beta[to] = LSE_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
-                const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
-                double v[HF];
-                double mx = SMM_NEG_INF;
+        // both halves compute every position; the upper half stores to a junk array (no exec juggling on the serial path)
+        double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
+        double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
+        double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
+        double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
+        constexpr int UC = MQ / B;                        // blocks per unrolled chain iteration (UC*B % MQ == 0, UC even)
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
+        for (int j0 = 0; j0 < J; j0 += UC) {
 #pragma unroll
-                for (int q = 0; q < HF / 2; ++q) {
-                    const double2 gv = gp[q];
-                    v[2 * q] = gv.x + tr[2 * q];
-                    v[2 * q + 1] = gv.y + tr[2 * q + 1];
-                    mx = smm_fmax(mx, smm_fmax(v[2 * q], v[2 * q + 1]));
-                }
-                mx = smm_max_halves(mx);                    // common reference of both halves
-                float s = 0.f;
-                const double ref = (mx == SMM_NEG_INF) ? 0.0 : mx;
+            for (int jj = 0; jj < UC; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                double ap[B], ev[B];
 #pragma unroll
-                for (int i = 0; i < HF; ++i) s += __builtin_amdgcn_exp2f((float)(v[i] - ref) * (float)SMM_LOG2E);
-                s += __shfl_xor(s, 32);
-                const double beta = (mx == SMM_NEG_INF) ? mx : mx + (double)(__builtin_amdgcn_logf(s) * (float)SMM_LN2);
-                hcur = beta - cum;
-                if (half == 0 && live) {
-                    sh_h[nn & 1][to] = hcur;
-                    hh[(size_t)nn * cm + to] = hcur;
+                for (int i = 0; i < B; ++i) {
+                    ap[i] = sh_apart[jj & 1][i][to];
+                    ev[i] = sh_e[jj & 1][i][to];
                 }
+                // Everything of a position that does not depend on h[n-1] -- the pushers' A' and the candidates
+                // k = 2..K0 -- is folded into (pm, ps) ahead of the serial path: A = LSE(that, h[n-1] + len[1]).
+                auto partial = [&](int i, double &pm, float &ps) {
+                    double x[K0 + 1];
+#pragma unroll
+                    for (int k = 2; k <= K0; ++k) x[k] = hq[(jj * B + 1 + i - k + 4 * MQ) % MQ] + lk[k];
+                    pm = ap[i];
+#pragma unroll
+                    for (int k = 2; k <= K0; ++k) pm = smm_fmax(pm, x[k]);
+                    const double rf = (pm == SMM_NEG_INF) ? 0.0 : pm;
+                    ps = smm_exp2f((float)(ap[i] - rf) * (float)SMM_LOG2E);
+#pragma unroll
+                    for (int k = 2; k <= K0; ++k) ps += smm_exp2f((float)(x[k] - rf) * (float)SMM_LOG2E);
+                };
+                double pm;
+                float ps;
+                partial(0, pm, ps);
+                double cumn = cum + ev[0];
+#pragma unroll
+                for (int i = 0; i < B; ++i) {
+                    const int n = j * B + 1 + i;           // position; n mod MQ == (jj*B + 1 + i) mod MQ
+                    if (n > T) break;
+                    // A[n] = LSE( (pm, ps), h[n-1] + len[1] )
+                    const double x1 = hq[(jj * B + i + 4 * MQ) % MQ] + lk[1];
+                    const double mx = smm_fmax(pm, x1);
+                    const double rf = (mx == SMM_NEG_INF) ? 0.0 : mx;
+                    const float s = ps * smm_exp2f((float)(pm - rf) * (float)SMM_LOG2E) + smm_exp2f((float)(x1 - rf) * (float)SMM_LOG2E);
+                    const double acc = (mx == SMM_NEG_INF) ? mx : mx + (double)(__builtin_amdgcn_logf(s) * (float)SMM_LN2);
+                    cum = cumn;
+                    const double gm = cum + acc;
+                    st_gam[0] = gm;
+                    st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
+                    st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
+                    if (n < T) {
+                        // beta[to] = LSE_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
+                        const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
+                        double2 gv[HF / 2];
+#pragma unroll
+                        for (int q = 0; q < HF / 2; ++q) gv[q] = gp[q];
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i + 1 < B) {                   // the next position's h-independent part, in the shadow of the LDS round trip
+                            partial(i + 1 < B ? i + 1 : 0, pm, ps);
+                            cumn = cum + ev[i + 1 < B ? i + 1 : 0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        double v[HF];
+                        double vm = SMM_NEG_INF;
+#pragma unroll
+                        for (int q = 0; q < HF / 2; ++q) {
+                            v[2 * q] = gv[q].x + tr[2 * q];
+                            v[2 * q + 1] = gv[q].y + tr[2 * q + 1];
+                            vm = smm_fmax(vm, smm_fmax(v[2 * q], v[2 * q + 1]));
+                        }
+                        vm = smm_max_halves(vm);                    // common reference of both halves
+                        const double vr = (vm == SMM_NEG_INF) ? 0.0 : vm;
+                        float sv = 0.f;
+#pragma unroll
+                        for (int q = 0; q < HF; ++q) sv += smm_exp2f((float)(v[q] - vr) * (float)SMM_LOG2E);
+                        sv += __shfl_xor(sv, 32);
+                        const double beta = (vm == SMM_NEG_INF) ? vm : vm + (double)(__builtin_amdgcn_logf(sv) * (float)SMM_LN2);
+                        const double hcur = beta - cum;
+                        hq[(jj * B + 1 + i) % MQ] = hcur;
+                        st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
+                    }
+                }
+                __syncthreads();                                           // end of block j
             }
-            __syncthreads();
         }
-        // last position: LSE over fin[to], to = 0..C  (sh_gam holds gamma[T][.])
+    } else {
+        // ============================================================================ pusher waves
+        int rank = w - 1;
+        if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);   // the chain wave's SIMD partner owns the fewest states
+        const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
+        const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
+        float M[SPW][R], S[SPW][R], L[SPW][R];
+        double ref[SPW], hd[SPW];
+#pragma unroll
+        for (int js = 0; js < SPW; ++js) {
+            const int c = js * NP + rank;
+            const bool on = js < nv;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // block protocol (source position -B at push step 0): slot p waits for k = (p + B + 1) mod RING; lengths
+                // up to K0 belong to the chain wave
+                const int k = (lane * R + r + B + 1) & (64 * R - 1);
+                M[js][r] = SMM_M_EMPTY;
+                S[js][r] = 0.f;
+                L[js][r] = (on && k > K0 && k <= kp - 1) ? (float)(len[(size_t)k * cm + c] * SMM_LOG2E) : -__builtin_huge_valf();
+            }
+            const double h0 = on ? sh_h0[c] : 0.0;
+            ref[js] = (h0 > -1e300 && h0 < 1e300) ? __builtin_ceil(h0 * SMM_LOG2E) : 0.0;
+            hd[js] = SMM_NEG_INF;
+        }
+        // mover role of this wave: block-relative element e = lane + 64 q  <->  (row e / cm, column e % cm)
+        int lo[NE], row[NE], col[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            row[q] = e / cm;
+            col[q] = e - row[q] * cm;
+            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + col[q] : -1;
+        }
+        // elp rows of block q (positions qB+1.., i.e. DP rows qB..): unconditional loads from clamped rows
+        auto load_block = [&](double (&pre)[NE], int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                int i = q * B + row[x];
+                i = i < T ? i : T - 1;
+                pre[x] = elp[(size_t)frame_of(i) * cm + (lo[x] >= 0 ? col[x] : 0)];
+            }
+        };
+        double pre[NE];
+        if (w == MW) load_block(pre, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0), see smm_viterbi.hip
+        auto store_block = [&](const double *src, double *dst, int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x;
+                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+            }
+        };
+        for (int j0 = 0; j0 < J; j0 += UB) {
+#pragma unroll
+            for (int jj = 0; jj < UB; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                if (w == MW) {
+                    // block j+1 (fetched a block ago) -> LDS, then fetch block j+2; history of block j-1 -> HBM
+                    double *dst = &sh_e[(jj + 1) & 1][0][0];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q)
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+                    load_block(pre, j + 2);
+                    if (j >= 1) {
+                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
+                        store_block(&sh_h[(jj + 1) & 1][0][0], hh, j - 1);
+                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
+                    }
+                }
+#pragma unroll
+                for (int js = 0; js < SPW; ++js) {
+                    if (js >= nv) break;
+                    const int c = js * NP + rank;
+                    smm_lse_ring_block<R, B>(M[js], S[js], L[js], ref[js], hd[js], &sh_h[(jj + 1) & 1][0][c],
+                                             &sh_apart[(jj + 1) & 1][0][c], j, jj % UB, lane);
+                }
+                __syncthreads();                             // end of block j
+            }
+        }
+        if (w == MW) {                                       // the last block's history
+            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
+            store_block(&sh_h[(J - 1) & 1][0][0], hh, J - 1);
+            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
+        }
+    }
+
+    // -------------------------------------------------------------------------------- last position
+    // sh_gam holds gamma[T][.]
+    __syncthreads();
+    if (w == 0) {
         double f = SMM_NEG_INF;
         if (!bwd) {
-            if (lane <= C) {
+            if (no_eos) {
+                if (lane < C) {
+                    for (int c = 0; c < C; ++c) f = smm_lse2(f, sh_gam[c] + trans[(size_t)lane * cm + c]);
+                    f = f + elp[(size_t)T * cm + lane];   // the closing label only emits frame T
+                }
+            } else if (lane <= C) {
                 for (int c = 0; c < C; ++c) {
                     const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c] + SMM_BIG_NEG;
                     f = smm_lse2(f, sh_gam[c] + wgt);
@@ -191,132 +433,28 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) f = smm_lse2(f, __shfl_xor(f, off));
         if (lane == 0) logz[vid] = f;
-    } else {
-        // ============================================================================ pusher waves
-        int rank = w - 1;
-        if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
-        const int nv_all = (C - rank + NP - 1) / NP;
-        const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
-        // A ring slot keeps m (fp64), s (fp32) and its length score as fp32: 4 registers, so that 21 states x 1024
-        // slots fit the register file (with an fp64 copy they spill from 15 states on).  Rounding len to fp32 moves a
-        // candidate by <= 6e-8 |len| nats -- 1e-6 where candidates carry weight, against a tolerance of 1e-4 relative
-        // on log Z ~ 1e5 -- and the time-reversed run sees the same rounded table, so forward and backward agree.
-        double M[SPW][R], hs[SPW];
-        float S[SPW][R], L[SPW][R];
-#pragma unroll
-        for (int j = 0; j < SPW; ++j) {
-            const int c = j * NP + rank;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int p = lane * R + r;
-                M[j][r] = SMM_NEG_INF;
-                S[j][r] = 0.f;
-                L[j][r] = (j < nv && p >= 1 && p <= kp - 1) ? fmaxf((float)len[(size_t)p * cm + c], SMM_MASKED_F) : SMM_MASKED_F;
-            }
-            hs[j] = 0.0;
-        }
-        constexpr int QMAX = (SMM_MAX_STATES_DEV + NP - 1) / NP;
-        double pre[QMAX];
-#pragma unroll
-        for (int q = 0; q < QMAX; ++q) pre[q] = 0.0;
-        const int pidx = (w - 1) * 64 + lane;
-        for (int n0 = 0; n0 < T; n0 += R) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const int n = n0 + u;
-                if (n >= T) break;
-                const int r2 = (u + 2) % R;
-                const bool clear = lane == (n & (RING - 1)) / R;
-                const bool hand = lane == ((n + 2) & (RING - 1)) / R;
-                if (u == 0 && (n & 31) == 0) {
-                    const int nbase = (n & ~63) + 64;
-                    const int nel = (T - nbase < 64 ? T - nbase : 64) * cm;
-                    if ((n & 63) == 0) {
-#pragma unroll
-                        for (int q = 0; q < QMAX; ++q) {
-                            const int e = pidx + q * NP * 64;
-                            if (e < nel) {
-                                const int j = e / cm, c = e - j * cm;
-                                pre[q] = elp[(size_t)(bwd ? T - 1 - (nbase + j) : nbase + j) * cm + c];
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < QMAX; ++q) {
-                            const int e = pidx + q * NP * 64;
-                            if (e < nel) sh_elp[(nbase >> 6) & 1][e] = pre[q];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    if (j >= nv) break;
-                    hs[j] = smm_fmax(sh_h[n & 1][j * NP + rank], SMM_MASKED);   // h[n][c], never -inf (x - m must not be NaN)
-                }
-#pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    if (j >= nv) break;
-                    if (clear) { M[j][u] = SMM_NEG_INF; S[j][u] = 0.f; }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        smm_lse_push(M[j][r], S[j][r], hs[j] + (double)L[j][(r - u + R) % R]);
-                        // four slots in flight are enough to cover the exp latency; without the fence the scheduler
-                        // interleaves all R updates and their temporaries push the rings out of the register file
-                        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (hand) {
-                        sh_am[n & 1][j * NP + rank] = M[j][r2];
-                        sh_as[n & 1][j * NP + rank] = S[j][r2];
-                    }
-                    L[j][(R - 1 - u + R) % R] = smm_wave_ror1f(L[j][(R - 1 - u + R) % R]);
-                }
-                __syncthreads();
-            }
-        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-template <int R, int SPW, int NW>
-static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int nw, int c_need, hipStream_t stream)
+template <int R, int SPW>
+static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int c_need, hipStream_t stream)
 {
-    if (spw != SPW || nw != NW) return 0;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, NW, 8>), dim3(a.b), dim3(NW * 64), 0, stream, a, logz);
-    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, NW, 16>), dim3(a.b), dim3(NW * 64), 0, stream, a, logz);
+    if (spw != SPW) return 0;
+    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8>), dim3(a.b), dim3(512), 0, stream, a, logz);
+    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16>), dim3(a.b), dim3(512), 0, stream, a, logz);
     return 1;
 }
 
 template <int R>
 static int logz_launch_r(const SmmDpArgs &a, double *logz, int c_need, hipStream_t stream)
 {
-    // a pusher needs ~4*R*SPW + 50 VGPRs (m fp64, s fp32, len fp32 per slot): 8 waves -> R*SPW <= 50, 16 waves -> <= 19
-    constexpr int SPW8 = (50 / R) > 5 ? 5 : (50 / R);
-    int nw = 8;
-    if ((c_need + 6) / 7 > SPW8) nw = 16;
-    int spw = (c_need + nw - 2) / (nw - 1);
-    if (nw == 16 && 4 * R * spw + 50 > 128) {
-        // K > 512 with more than 15 states: the rings no longer fit the register file.  8 waves x 3..5 states per
-        // pusher with the overflow in scratch: correct, a few times slower (a two-CU split as in the Viterbi kernel's
-        // PAIR mode is the fast answer and is not built for the log semiring).
-        nw = 8;
-        spw = (c_need + 6) / 7;
-    }
-    int hit = 0;
-    if constexpr (R <= 4) {
-        hit = logz_launch_if<R, 1, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 2, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 3, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 4, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 5, 8>(a, logz, spw, nw, c_need, stream);
-    } else if constexpr (R == 8) {
-        hit = logz_launch_if<R, 1, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 2, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 3, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 4, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 5, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 1, 16>(a, logz, spw, nw, c_need, stream);
-    } else if constexpr (R == 16) {
-        hit = logz_launch_if<R, 1, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 2, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 1, 16>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 3, 8>(a, logz, spw, nw, c_need, stream) || logz_launch_if<R, 4, 8>(a, logz, spw, nw, c_need, stream) ||
-              logz_launch_if<R, 5, 8>(a, logz, spw, nw, c_need, stream);
-    }
+    // 8 waves: 1 chain + 7 pushers x SPW states; a pusher keeps 3*R*SPW ring registers (+ ~50): everything up to
+    // 28 states x 1024 slots stays in the register file (32 states x 1024: the 5-state configuration spills a little)
+    const int spw = (c_need + 6) / 7;
+    const int hit = logz_launch_if<R, 1>(a, logz, spw, c_need, stream) || logz_launch_if<R, 2>(a, logz, spw, c_need, stream) ||
+                    logz_launch_if<R, 3>(a, logz, spw, c_need, stream) || logz_launch_if<R, 4>(a, logz, spw, c_need, stream) ||
+                    logz_launch_if<R, 5>(a, logz, spw, c_need, stream);
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
 }
 

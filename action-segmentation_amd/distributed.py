@@ -12,8 +12,13 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for one process."""
+def init(backend=None, timeout_s=180):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for one process.
+
+    ``backend``: 'nccl' (RCCL; the default whenever a GPU is visible) or 'gloo'.  Nothing is downgraded silently: an
+    RCCL group that does not come up raises.  ``timeout_s`` bounds the rendezvous and every collective, so a rank that
+    died cannot hang the others forever."""
+    import datetime
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world <= 1 or dist.is_initialized():
         return int(os.environ.get('RANK', 0)), world
@@ -21,9 +26,59 @@ def init(backend=None):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-    dist.init_process_group(backend)
+        local = int(os.environ.get('LOCAL_RANK', 0))
+        if local >= torch.cuda.device_count():
+            raise RuntimeError("rank with LOCAL_RANK=%d but only %d GPU(s) visible: RCCL needs one GPU per rank"
+                               % (local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s))
     return dist.get_rank(), dist.get_world_size()
+
+
+def active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def reduce_device():
+    """Where a tensor has to live to be reduced by the active backend: the current GPU for RCCL ('nccl' cannot reduce
+    host tensors), the host for gloo."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_reduce_tensor(t, op=None):
+    """Sum (or ``op``) of a tensor over the ranks, returned on the tensor's own device.  Device tensors go straight
+    through RCCL; under gloo they take a round trip through the host.  No-op for a single process."""
+    if not active():
+        return t
+    op = op or dist.ReduceOp.SUM
+    rd = reduce_device()
+    if t.device == rd:
+        dist.all_reduce(t, op=op)
+        return t
+    buf = t.to(rd)
+    dist.all_reduce(buf, op=op)
+    return buf.to(t.device)
+
+
+def broadcast_parameters(module, src=0):
+    """Every rank ends with rank ``src``'s parameters and buffers (what loading the same pickle does in the reference
+    flow, ``main.py:445-469``).  The closed-form fit sums with fp64 atomics, so two ranks fitting the same data may
+    differ in the last bit; decode results are only comparable across world sizes when the parameters are identical."""
+    if not active():
+        return
+    rd = reduce_device()
+    with torch.no_grad():
+        for _, t in sorted(module.state_dict().items()):
+            buf = t.detach().to(rd).contiguous()
+            if buf.dtype == torch.bool:
+                b8 = buf.to(torch.uint8)
+                dist.broadcast(b8, src)
+                t.copy_(b8.to(torch.bool).to(t.device))
+            else:
+                dist.broadcast(buf, src)
+                t.copy_(buf.to(t.device))
 
 
 def shard_batches(batches, costs, rank, world):
@@ -49,10 +104,9 @@ def all_reduce_counters(counters, device=None):
     as sums and finalised after the reduce.
     """
     keys = sorted(counters)
-    flat = torch.tensor([float(v) for k in keys for v in counters[k]], dtype=torch.float64, device=device or 'cpu')
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat = flat.cpu().tolist()
+    flat = torch.tensor([float(v) for k in keys for v in counters[k]], dtype=torch.float64,
+                        device=device or reduce_device())
+    flat = all_reduce_tensor(flat).cpu().tolist()
     out, i = {}, 0
     for k in keys:
         n = len(counters[k])

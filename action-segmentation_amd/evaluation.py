@@ -188,10 +188,15 @@ def evaluate_labels(pred, gt, lengths, frame_offset, tasks, space, optimal_assig
         for g in group:
             video_key.append(seen.get(g, 0))
             seen[g] = video_key[-1] + 1
-    eb = ops.EvalBatch(lengths, frame_offset, group, len(space.tasks), space.c_max, space.n_labels, gt2.size(1),
-                       video_key=video_key, total_frames=pred.numel())
+    empty = len(group) == 0                  # a rank of a sharded job that holds no video: zeros into the reductions
     local_of = space.local_table(pred.device)
-    conf_d = ops.eval_confusion(eb, pred, gt2, local_of)
+    if empty:
+        eb = None
+        conf_d = torch.zeros((len(space.tasks), space.c_max + 1, space.c_max + 1), dtype=torch.int64, device=pred.device)
+    else:
+        eb = ops.EvalBatch(lengths, frame_offset, group, len(space.tasks), space.c_max, space.n_labels, gt2.size(1),
+                           video_key=video_key, total_frames=pred.numel())
+        conf_d = ops.eval_confusion(eb, pred, gt2, local_of)
     if reduce is not None:
         conf_d = reduce(conf_d)
     conf = conf_d.cpu().numpy()
@@ -205,12 +210,15 @@ def evaluate_labels(pred, gt, lengths, frame_offset, tasks, space, optimal_assig
         n_pred = int((conf[g, :n, :n].sum(0) > 0).sum())
         assert n_pred <= n, "more predicted labels than the task has classes (accuracy.py:349-352)"
     cluster, gbg, pbg = _kernel_tables(space, g2c, pred.device)
-    per_video = ops.eval_videos(eb, pred, gt2, local_of, cluster, gbg, pbg, seed=seed).cpu().numpy()
+    if empty:
+        per_video = np.zeros((0, _lib.EVAL_COUNTERS), dtype=np.int64)
+    else:
+        per_video = ops.eval_videos(eb, pred, gt2, local_of, cluster, gbg, pbg, seed=seed).cpu().numpy()
 
     # additive per-task sums: integer counters, then the three per-video quantities of levenshtein()
     ng = len(space.tasks)
     sums = np.zeros((ng, _lib.EVAL_COUNTERS + 4), dtype=np.float64)
-    grp = np.asarray(group)
+    grp = np.asarray(group, dtype=np.int64)
     for g in range(ng):
         rows = per_video[grp == g]
         if rows.shape[0] == 0:
@@ -238,14 +246,20 @@ def accuracy_corpus(data, predictions, optimal_assignment, seed=0, reduce=None, 
 
     ``data``: a datasplit with ``_videos_by_task`` / ``corpus``; ``predictions``: ``{video_name: int64[T]}`` as
     ``SemiMarkovModel.predict`` returns (numpy or tensors), uploaded once and counted on the device.
+    With ``reduce`` (multi-process: ``distributed.all_reduce_tensor``) ``predictions`` may hold only this rank's videos;
+    the counters are summed over ranks before anything is finalised, so every rank returns the corpus statistics
+    (``main.py:486-532`` sums the same pairs over tasks).
     """
     device = device or torch.device('cuda', torch.cuda.current_device())
     tasks = list(data._videos_by_task)
     space = LabelSpace.from_corpus(data.corpus, tasks)
-    lengths, offsets, task_of, preds, gts = [], [], [], [], []
+    lengths, offsets, task_of, preds, gts, keys = [], [], [], [], [], []
     off = 0
     for task in tasks:
-        for name in data._videos_by_task[task]:
+        for key, name in enumerate(data._videos_by_task[task]):
+            if reduce is not None and name not in predictions:
+                continue                                   # another rank's video
+            keys.append(key)                               # index inside the task: seeds the step-recall draw
             gt = torch.as_tensor(data._videos[(task, name)]['gt_single']).to(torch.int64)
             pr = torch.as_tensor(predictions[name]).to(torch.int64)
             assert gt.numel() == pr.numel(), "%s: %d ground-truth vs %d predicted frames" % (name, gt.numel(), pr.numel())
@@ -255,8 +269,11 @@ def accuracy_corpus(data, predictions, optimal_assignment, seed=0, reduce=None, 
             preds.append(pr.to(device, non_blocking=True))
             gts.append(gt.to(device, non_blocking=True))
             off += lengths[-1]
+    if not preds:                                          # a rank without videos still takes part in the reductions
+        preds, gts = [torch.zeros(1, dtype=torch.int64, device=device)], [torch.zeros(1, dtype=torch.int64, device=device)]
+        lengths, offsets, task_of, keys = [], [], [], []
     return evaluate_labels(torch.cat(preds), torch.cat(gts), lengths, offsets, task_of, space, optimal_assignment,
-                           seed=seed, reduce=reduce)
+                           seed=seed, video_key=keys, reduce=reduce)
 
 
 def summarise(stats_by_task, keys, prefix=''):

@@ -182,10 +182,12 @@ class SemiMarkovModel(object):
         return fn
 
     # ------------------------------------------------------------------ decode (reference :318-410)
-    def prepare(self, test_data):
+    def prepare(self, test_data, shard=None):
         """Everything that happens before the timed decode: collate the reference's batches, move them to the
-        device once, stack the per-task factor tables."""
-        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size)
+        device once, stack the per-task factor tables.  ``shard=(rank, world)``: this rank's share of the batches
+        (multi-GPU decode: videos are independent, every rank decodes its own; batching.make_data_loader)."""
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
+                                  shard=shard)
         pc = pack_batches(loader, self.device, self.model.max_k, constraints_fn=self._test_constraints(test_data),
                           additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
         return self.model.prepare_packed(pc)
@@ -204,12 +206,20 @@ class SemiMarkovModel(object):
             assert self.model.n_classes not in preds[name], "predictions should not contain EOS"
         return preds
 
-    def predict(self, test_data, fused=True):
+    def predict(self, test_data, fused=True, shard=None):
+        """``{video: int64[T]}``.  ``shard=(rank, world)`` (default: the torch.distributed group when one is up) limits the
+        result to this rank's videos; reduce the evaluation counters with ``evaluation.accuracy_corpus(reduce=...)``."""
         self.model.eval()
+        if shard is None:
+            from . import distributed
+            if distributed.active():
+                import torch.distributed as dist
+                shard = (dist.get_rank(), dist.get_world_size())
         if fused:
-            return self.predict_packed(self.prepare(test_data))
+            return self.predict_packed(self.prepare(test_data, shard=shard))
         predictions = {}
-        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size)
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
+                                  shard=shard)
         cons_fn = self._test_constraints(test_data)
         for batch in loader:
             tasks = batch['task_name']

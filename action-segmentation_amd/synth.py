@@ -29,6 +29,10 @@ CONFIGS = {
     'cfg3': dict(n_tasks=18, videos_per_task=20, steps=(5, 11), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
                  chain=True, rate=(20, 400), batch_size=5),
     # the same capped at 21 states per task (what one 8-wave workgroup holds at K = 1024), for comparison
+    # configs[4]: the FULL CrossTask primary set (2750 videos over 18 tasks -> 153 per task) with cfg3's shapes; the
+    # corpus of the strong-scaling leg (one corpus sharded by video over the ranks)
+    'cfg5': dict(n_tasks=18, videos_per_task=153, steps=(5, 11), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
+                 chain=True, rate=(20, 400), batch_size=5),
     'cfg3c': dict(n_tasks=18, videos_per_task=20, steps=(5, 10), t_lognormal=(6000, 0.5, 500, 14000), max_k=1024, d=200,
                   chain=True, rate=(20, 400), batch_size=5),
     # configs[3]: ordering constraints + narration constraints, small shapes
@@ -48,9 +52,13 @@ class SynthCorpus:
 
 
 class SynthDatasplit(Dataset):
-    def __init__(self, cfg, seed=0, device='cpu', scale=1.0, video_seed=None):
+    def __init__(self, cfg, seed=0, device='cpu', scale=1.0, video_seed=None, keep=None):
         """``seed`` fixes the label space (tasks, steps, class means, rates); ``video_seed`` (optional) draws a
-        different set of videos over the SAME label space -- a held-out split for a model fitted on ``seed``."""
+        different set of videos over the SAME label space -- a held-out split for a model fitted on ``seed``.
+        ``keep``: None = every video gets features; otherwise a set of video names (possibly empty): the others are
+        STRUCTURE ONLY (labels, lengths, ``features`` a storage-less 'meta' tensor of the right shape) -- what a rank of
+        a sharded job holds for the videos of other ranks; the random streams advance identically either way, so the
+        kept videos are bit-identical to those of the full corpus."""
         c = dict(CONFIGS[cfg]) if isinstance(cfg, str) else dict(cfg)
         self.cfg = c
         rng = np.random.default_rng(seed)
@@ -88,6 +96,7 @@ class SynthDatasplit(Dataset):
             means.append(mu)
             rates.append(rt)
             names = []
+            mu_t = sigma_t = None
             for vi in range(n_videos):
                 if 't_fixed' in c:
                     t = int(c['t_fixed'])
@@ -104,9 +113,15 @@ class SynthDatasplit(Dataset):
                 name = '%s_v%03d' % (task, vi)
                 names.append(name)
                 lab = torch.from_numpy(labels_local)
-                mu_t = torch.from_numpy(mu).to(device)
-                x = mu_t[lab.to(device)] + torch.from_numpy(self.sigma).to(device) * torch.randn(
-                    t, d, generator=gen, device=device)
+                if keep is not None and name not in keep:
+                    if len(keep):                      # keep the feature stream in step with the full corpus
+                        torch.randn(t, d, generator=gen, device=device)   # (drawn and dropped)
+                    x = torch.empty(t, d, device='meta')
+                else:
+                    if mu_t is None:
+                        mu_t = torch.from_numpy(mu).to(device)
+                        sigma_t = torch.from_numpy(self.sigma).to(device)
+                    x = mu_t[lab.to(device)] + sigma_t * torch.randn(t, d, generator=gen, device=device)
                 sample = dict(features=x, gt_single=lab + ids[0], task_name=task, video_name=name,
                               task_indices=torch.tensor(ids, dtype=torch.long))
                 if cons is not None:

@@ -1,15 +1,25 @@
 #!/usr/bin/env python
 """Benchmark of the semi-Markov decode path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg3c|cfg2|cfg1|cfg4] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg5|cfg3c|cfg2|cfg1|cfg4] [--scaling weak|strong]
 
 One "step" = one decode pass (emission scorer + Viterbi DP + back-trace + label expansion + labels on the host: the
-DP kernel writes them into pinned host memory over PCIe while it decodes) over this rank's synthetic corpus, features
-already resident in HBM.  Default workload: cfg3, the shape
-BASELINE.json's metric is quoted on (CrossTask-shaped: 18 tasks x 20 videos, T ~ 6k (500..14k), 11..23 states per
-task, max span L = K-1 = 1023, D = 200).  With N > 1 (torchrun, one rank per GPU) every rank decodes its own
-corpus of that size (weak scaling; videos are independent, so there is no data-path collective); RCCL carries the
-MAX of the step time and the SUM of the metric counters.
+DP kernel writes them into pinned host memory over PCIe while it decodes) over this rank's share of a synthetic corpus,
+features already resident in HBM.  Default workload: cfg3, the shape BASELINE.json's metric is quoted on
+(CrossTask-shaped: 18 tasks x 20 videos, T ~ 6k (500..14k), 11..23 states per task, max span L = K-1 = 1023, D = 200;
+seed 2 as SURVEY.md 8(d) fixes it: the draw contains two 23-state tasks, one with a 14 000-frame video).
+
+N > 1: one process per GPU.  Under ``torchrun`` (RANK / WORLD_SIZE in the environment) this process is one rank; started
+plainly as ``python bench.py --gpus N`` it spawns the N ranks itself as child processes BEFORE touching the GPU and
+relays rank 0's line.  Either way the job fails (non-zero exit) unless the group comes up with exactly N ranks on RCCL
+(backend "nccl"); ``--backend gloo`` is an explicit opt-in for rehearsals without one GPU per rank.
+  * headline (``scaling: weak``): every rank decodes its own cfg3-sized corpus (seed + rank); videos are independent, so
+    there is no data-path collective; RCCL carries the MAX of the step time and the SUM of the frame counters;
+  * ``strong_scaling`` (second object in the same line, N > 1 or --strong-leg): ONE corpus (default cfg5 = the full
+    CrossTask primary set, 2754 videos) sharded by video over the ranks (distributed.shard_batches), every rank decodes
+    its share, and the reference's evaluation counters (Datasplit.accuracy_corpus, src/data/corpus.py:405-604, summed
+    as src/main.py:486-532 does) are all-reduced over RCCL before they are finalised: the statistics printed are those
+    of the whole corpus and do not depend on N.  ``--scaling strong`` makes this leg the headline instead.
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (the DP kernel), timed live with HIP events
 on the stream it is launched on; ``cpu_baseline`` is the oracle's dense reference-path restatement on a bounded
@@ -18,6 +28,7 @@ sample (N = 1 only).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,57 +40,123 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9   # fp64 lane-ops/s: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
+METRIC = "frames/sec semi-Markov decode, CrossTask T~10k K~20 L=1024, 1/2/4/8 GPUs"
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=2)
-    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3c', 'cfg4'])
+    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3c', 'cfg4', 'cfg5', 'tiny'])
     p.add_argument('--scale', type=float, default=1.0, help='videos per task multiplier')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--seed', type=int, default=1000, help='corpus seed of rank 0 (rank r uses seed + r)')
+    p.add_argument('--seed', type=int, default=2, help='corpus seed of rank 0 (weak scaling: rank r uses seed + r)')
     p.add_argument('--fit-videos', type=int, default=6, help='videos per task the closed-form fit sees (untimed)')
     p.add_argument('--labels-via-copy', action='store_true',
                    help='labels to a device tensor + D->H copy through a pinned buffer instead of kernel stores to pinned host memory')
-    return p.parse_args()
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                   help='which leg is the headline value when N > 1 (the other one is reported beside it)')
+    p.add_argument('--strong-workload', default='cfg5', choices=['cfg3', 'cfg5', 'cfg4', 'tiny'],
+                   help='corpus of the strong-scaling leg (one corpus, seed --seed, sharded by video over the ranks)')
+    p.add_argument('--strong-leg', action='store_true', help='run the strong-scaling leg with one rank too')
+    p.add_argument('--no-strong-leg', action='store_true')
+    p.add_argument('--no-predict-e2e', action='store_true', help='skip the SemiMarkovModel.predict wall-time figures')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help="collectives: 'nccl' = RCCL (required for a measurement); 'gloo' only for rehearsals")
+    p.add_argument('--share-gpus', action='store_true',
+                   help='rehearsal only: ranks may share a GPU (LOCAL_RANK %% device_count); needs --backend gloo')
+    p.add_argument('--dry-run', action='store_true',
+                   help='host-only rehearsal of the N-rank path: rendezvous, shard the corpus structure, reduce the '
+                        'frame counters; nothing is decoded and no GPU is touched (implies --backend gloo)')
+    a = p.parse_args(argv)
+    if a.dry_run:
+        a.backend = 'gloo'
+    if a.share_gpus and a.backend != 'gloo':
+        p.error('--share-gpus needs --backend gloo (RCCL refuses two ranks on one GPU)')
+    if a.gpus < 1:
+        p.error('--gpus must be >= 1')
+    return a
 
 
-def dist_setup(n):
-    """One process per GPU (torchrun env).  Collectives run over RCCL (backend "nccl" on ROCm); if RCCL cannot come up
-    on this box the tiny metric reductions fall back to gloo on host tensors rather than losing the measurement."""
+# ------------------------------------------------------------------------------------------------ N-rank launch
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(a, argv):
+    """``python bench.py --gpus N`` without torchrun: start the N ranks as fresh child processes (this parent never
+    initialises the GPU: ``torch.cuda.device_count()`` does not, on this image), wait for them, exit with their status.
+    Rank 0's stdout is the parent's, so its JSON line is the job's line."""
+    if not a.dry_run and not a.share_gpus:
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus:
+            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (a.gpus, n_dev))
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', LOCAL_WORLD_SIZE=str(a.gpus))
+    procs = []
+    for r in range(a.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in alive:                      # a rank died: the others would wait for it until the timeout
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dist_setup(a):
+    """One process per GPU.  Fails loudly: the world size must equal --gpus and the backend must come up as asked."""
     import torch.distributed as dist
+    from action_segmentation_amd import distributed as D
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    backend = None
-    if n > 1 or world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        try:
-            dist.init_process_group('nccl', rank=rank, world_size=world)
-            probe = torch.ones(1, device='cuda')
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-            assert int(probe.item()) == world
-            backend = 'nccl'
-        except Exception as e:                                    # pragma: no cover (needs a broken RCCL setup)
-            sys.stderr.write('bench.py: RCCL unavailable (%s); metric reductions fall back to gloo\n' % e)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-            backend = 'gloo'
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or plainly "
+                         "as `python bench.py --gpus %d`, which spawns the ranks)" % (a.gpus, world, a.gpus, a.gpus))
+    if a.dry_run:
+        if world > 1:
+            D.init('gloo')
+        return rank, world, local, ('gloo' if world > 1 else None)
+    n_dev = torch.cuda.device_count()
+    if a.share_gpus:
+        torch.cuda.set_device(local % max(1, n_dev))
     else:
-        torch.cuda.set_device(0)
-    return rank, world, local, backend
+        if local >= n_dev:
+            raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own (%d visible)" % (rank, local, n_dev))
+        torch.cuda.set_device(local)
+    if world == 1:
+        return rank, world, local, None
+    D.init(a.backend)
+    probe = torch.ones(1, device=D.reduce_device())
+    dist.all_reduce(probe)
+    if a.backend == 'nccl':
+        torch.cuda.synchronize()
+    if int(probe.item()) != world or dist.get_world_size() != world:
+        raise SystemExit("bench.py: the %s group did not come up with %d ranks" % (a.backend, world))
+    return rank, world, local, a.backend
 
 
+# ------------------------------------------------------------------------------------------------ CPU baselines
 def cpu_baseline(data, model, pc):
     """Dense reference-path restatement (oracle/dense_ref.py: log_hsmm potentials + sequential max-DP with
-    back-pointers, fp32 like the reference) on a bounded sample: the first frames of the first video."""
+    back-pointers, fp32 like the reference) on a bounded sample: the first frames of the first videos."""
     from oracle import dense_ref as O
     m = model.model
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
@@ -124,27 +201,184 @@ def cpu_baseline(data, model, pc):
                       % (t, n_done, c, m.max_k, feats_all.shape[-1], dt)}
 
 
-def cpu_factored(pc, model, max_videos=8):
-    """The plain-C factored oracle (OpenMP over videos) on a few videos: the 'fair' CPU number."""
+def cpu_factored(pc, model, budget_s=12.0):
+    """The plain-C factored oracle, OpenMP over the videos of one task at a time (the 'fair' CPU
+    number): emission + Viterbi for whole tasks until ~budget_s of wall time are spent."""
     from oracle import factored as F
     t = pc.tables
-    n = min(max_videos, pc.n_videos)
-    frames, dt = 0, 0.0
-    for i in range(n):
-        g = pc.group[i]
+    cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    frames, dt, n_vid, n_task = 0, 0.0, 0, 0
+    by_group = {}
+    for i in range(pc.n_videos):
+        by_group.setdefault(pc.group[i], []).append(i)
+    inv_var = t['inv_var'].cpu().numpy()
+    for g, vids in sorted(by_group.items()):
         c = pc.n_states[g]
-        off, ln = pc.frame_offset[i], pc.lengths[i]
-        x = pc.x[off:off + ln].cpu().numpy()
-        t0 = time.perf_counter()
+        tmax = max(pc.lengths[i] for i in vids)
+        kp = max(pc.kp[i] for i in vids)
         w = t['w'][g, :, :c].cpu().numpy()
-        xd = x.astype(np.float64)
-        elp = t['cst'][g, :c].cpu().numpy() + xd @ w - 0.5 * (xd * xd) @ t['inv_var'].cpu().numpy()[:, None]
-        F.viterbi(elp[None], [ln], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
-                  t['len'][g, :pc.kp[i], :c].cpu().numpy())
+        cst = t['cst'][g, :c].cpu().numpy()
+        xs = [pc.x[pc.frame_offset[i]:pc.frame_offset[i] + pc.lengths[i]].cpu().numpy() for i in vids]
+        t0 = time.perf_counter()
+        elp = np.zeros((len(vids), tmax, c))
+        for j, x in enumerate(xs):                           # (the emission GEMM runs on numpy's BLAS threads)
+            xd = x.astype(np.float64)
+            elp[j, :x.shape[0]] = cst + xd @ w - 0.5 * (xd * xd) @ inv_var[:, None]
+        F.viterbi(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
+                  t['len'][g, :kp, :c].cpu().numpy())
         dt += time.perf_counter() - t0
-        frames += ln
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d videos, oracle/smm_oracle.c factored fp64 DP, one video at a time" % n}
+        frames += sum(pc.lengths[i] for i in vids)
+        n_vid += len(vids)
+        n_task += 1
+        if dt > budget_s:
+            break
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d videos of %d task(s), oracle/smm_oracle.c factored fp64 DP, OpenMP over the videos of a task "
+                      "(%d host threads), %.1f s" % (n_vid, n_task, cores, dt)}
+
+
+# ------------------------------------------------------------------------------------------------ legs
+def fit_model(a, cfg, data, dev, D, world):
+    """Closed-form fit on a few videos per task (untimed), the decode model around it.  N > 1: rank 0's parameters are
+    broadcast, like every rank loading the same pickle."""
+    from action_segmentation_amd import synth
+    from action_segmentation_amd.semimarkov import SemiMarkovModel
+    fit_args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'])
+    fitted = SemiMarkovModel.from_args(fit_args, data)
+    fitted.fit(data.subset(a.fit_videos), use_labels=True)
+    args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'],
+                           sm_constrain_transitions=bool(cfg.get('narration')),
+                           sm_constrain_with_narration=['test'] if cfg.get('narration') else [])
+    model = SemiMarkovModel.from_args(args, data)
+    model.model.load_state_dict(fitted.model.state_dict(), strict=False)
+    model.model.to(dev)
+    return args, model
+
+
+def timed_decode(a, pc, world, want_events=True):
+    """W warm-up + exactly K timed decode steps of this rank's packed corpus, bracketed by barrier + synchronize.
+    Returns (wall seconds of the K steps, mean DP kernel ms, last labels (pinned host int64))."""
+    from action_segmentation_amd import ops
+    t = pc.tables
+    stream = torch.cuda.current_stream()
+    empty = pc is None or pc.n_videos == 0
+
+    def step(events=None):
+        """emission -> DP -> labels on the host.  (Same two launches as smm_decode_f32; split only so that HIP
+        events can bracket the DP kernel on the stream it runs on.)  Returns the int64 labels as a CPU tensor."""
+        if empty:
+            return torch.zeros(0, dtype=torch.int64)
+        elp64, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
+        if events:
+            events[0].record(stream)
+        out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
+                          class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=not a.labels_via_copy)
+        if events:
+            events[1].record(stream)
+        if a.labels_via_copy:
+            return ops.to_host(out['labels'])
+        stream.synchronize()          # the kernel wrote the labels into pinned host memory: they are on the host now
+        return out['labels']
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    labels = None
+    for _ in range(a.warmup):
+        labels = step()
+    sync()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    import gc
+    gc.collect()
+    gc.disable()                      # a collection inside a 0.5 ms step would be a quarter of it
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        labels = step(evs[i] if (want_events and not empty) else None)
+    sync()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if not empty:
+        ops.check_decoded(pc.batch)
+    dp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs])) if (want_events and not empty) else None
+    return dt, dp_ms, labels
+
+
+def gt_on_device(pc, data, dev):
+    gt_dev = torch.empty(max(1, pc.batch.total_frames), dtype=torch.int64, device=dev)
+    for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths):
+        gt_dev[o:o + n] = data._videos[(tk, nm)]['gt_single'].to(dev)
+    return gt_dev
+
+
+def video_keys(pc, data):
+    """Index of each packed video inside its task's (sorted) video list: seeds the step-recall draw, so that a sharded
+    evaluation draws exactly the frames the one-process evaluation draws."""
+    pos = {(t, n): i for t, names in data._videos_by_task.items() for i, n in enumerate(names)}
+    return [pos[(t, n)] for t, n in zip(pc.task_names, pc.video_names)]
+
+
+def strong_leg(a, rank, world, dev, D):
+    """ONE corpus (seed --seed) sharded by video over the ranks; evaluation counters reduced over the backend."""
+    from action_segmentation_amd import evaluation, synth
+    from action_segmentation_amd.batching import batch_cost
+    cfg = synth.CONFIGS[a.strong_workload]
+    # structure first (no features): the shard is a function of lengths and state counts only
+    dry = synth.SynthDatasplit(a.strong_workload, seed=a.seed, keep=set())
+    batches = dry.batch_sampler(cfg['batch_size'], True, False).batches
+    costs = [batch_cost(dry, keys, cfg['max_k']) for keys in batches]
+    mine = D.shard_batches(batches, costs, rank, world)
+    keep = {name for i in mine for (_, name) in batches[i]}
+    keep |= {n for names in dry._videos_by_task.values() for n in names[:a.fit_videos]}     # the fit's videos
+    data = synth.SynthDatasplit(a.strong_workload, seed=a.seed, device=dev, keep=keep)
+    args, model = fit_model(a, cfg, data, dev, D, world)
+    D.broadcast_parameters(model.model, src=0)
+    pc = model.prepare(data, shard=(rank, world))
+    assert sorted(pc.video_names) == sorted(n for i in mine for (_, n) in batches[i])
+    dt, dp_ms, labels = timed_decode(a, pc, world, want_events=True)
+    space = evaluation.LabelSpace.from_corpus(data.corpus, list(data._videos_by_task))
+    if pc.n_videos:
+        stats_by_task = evaluation.evaluate_labels(labels.to(dev), gt_on_device(pc, data, dev), pc.lengths, pc.frame_offset,
+                                                   pc.task_names, space, optimal_assignment=False, seed=0,
+                                                   video_key=video_keys(pc, data), reduce=D.all_reduce_tensor)
+    else:
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        stats_by_task = evaluation.evaluate_labels(z, z, [], [], [], space, optimal_assignment=False, seed=0,
+                                                   video_key=[], reduce=D.all_reduce_tensor)
+    summary = evaluation.summarise(stats_by_task, evaluation.STAT_KEYS)
+    rd = D.reduce_device()
+    tot = D.all_reduce_tensor(torch.tensor([float(pc.n_frames), float(pc.n_videos), float(sum(costs[i] for i in mine))],
+                                           dtype=torch.float64, device=rd))
+    tmax = D.all_reduce_tensor(torch.tensor([dt, float(pc.n_frames), dp_ms or 0.0], dtype=torch.float64, device=rd),
+                               op=torch.distributed.ReduceOp.MAX)
+    dt_all = float(tmax[0])
+    return {"scaling": "strong", "workload": "%s seed %d: %d videos, %d frames, sharded by video (whole single-task "
+            "batches of %d, greedy LPT on the DP work)" % (a.strong_workload, a.seed, int(tot[1]), int(tot[0]), cfg['batch_size']),
+            "value": float(tot[0]) * a.steps / dt_all, "unit": "frames/s", "n_gpus": world, "ms_per_step": dt_all / a.steps * 1e3,
+            "frames": int(tot[0]), "videos": int(tot[1]), "max_frames_on_a_rank": int(tmax[1]),
+            "dp_kernel_ms_max_over_ranks": float(tmax[2]),
+            "stats_reduced_over": "RCCL all-reduce" if (world > 1 and a.backend == 'nccl') else ("gloo all-reduce" if world > 1 else "1 rank"),
+            "stats": {k: round(v, 9) for k, v in summary.items()}}
+
+
+def predict_end_to_end(model, data):
+    """Wall time of SemiMarkovModel.predict over the same corpus, host work included (collate, pack_batches, table
+    stacking, constraint scatter, upload of nothing: the synthetic features already live on the device): the fused ragged
+    launch and the reference's per-batch call pattern (fused=False)."""
+    out = {}
+    for name, fused in (('fused', True), ('per_batch', False)):
+        model.predict(data, fused=fused)                 # warm-up (table cache, workspaces)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        preds = model.predict(data, fused=fused)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        frames = sum(len(v) for v in preds.values())
+        out[name] = {"ms": dt * 1e3, "frames_per_s": frames / dt}
+    out["what"] = ("SemiMarkovModel.predict(test_data) wall time, all host work included; 'per_batch' = the reference's "
+                   "call pattern, one viterbi() per single-task batch (semimarkov.py:318-410)")
+    return out
 
 
 def train_step_rate(args, data, model):
@@ -176,83 +410,76 @@ def train_step_rate(args, data, model):
     return {"value": frames / dt, "unit": "frames/s", "batches": len(batches), "ms_per_batch": dt / len(batches) * 1e3}
 
 
-def main():
-    a = parse()
-    torch.set_num_threads(min(8, os.cpu_count() or 1))   # host-side torch ops are tiny: a 256-thread pool only adds latency
-    rank, world, local, backend = dist_setup(a.gpus)
-    dev = torch.device('cuda', torch.cuda.current_device())
-    red_dev = dev if backend != 'gloo' else torch.device('cpu')
-    from action_segmentation_amd import ops, synth
-    from action_segmentation_amd.semimarkov import SemiMarkovModel
+def pmc_traffic(workload):
+    """HBM bytes per launch of the DP kernel from the committed rocprofv3 PMC summary -- a STORED value (PMC passes
+    cannot run inside this process), returned with its provenance; None when there is none for this workload."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    try:
+        rec = json.load(open(path)).get(workload, {})
+        val = rec.get('smm_viterbi_kernel_hbm_bytes_per_launch')
+        if val is None:
+            return None, None
+        return val, "stored: profiles/pmc_summary.json[%s] (%s)" % (workload, rec.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes'))
+    except Exception:
+        return None, None
 
+
+def dry_run(a, rank, world, D):
+    """Host-only rehearsal of the N-rank path (tests/test_bench_spawn.py): shard the corpus STRUCTURE, reduce the frame
+    counters over gloo, print the line with value null."""
+    from action_segmentation_amd import synth
+    from action_segmentation_amd.batching import batch_cost
+    wl = a.strong_workload if a.strong_workload in synth.CONFIGS else 'tiny'
+    cfg = synth.CONFIGS[wl]
+    dry = synth.SynthDatasplit(wl, seed=a.seed, keep=set())
+    batches = dry.batch_sampler(cfg['batch_size'], True, False).batches
+    costs = [batch_cost(dry, keys, cfg['max_k']) for keys in batches]
+    mine = D.shard_batches(batches, costs, rank, world)
+    frames = sum(int(dry[key]['features'].shape[0]) for i in mine for key in batches[i])
+    red = D.all_reduce_counters({'frames': [frames, len(mine)], 'ranks': [1, rank]})
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
+                          "frames": int(red['frames'][0]), "batches": int(red['frames'][1]), "ranks_seen": int(red['ranks'][0]),
+                          "corpus_frames": dry.n_frames, "n_batches": len(batches), "backend": "gloo" if world > 1 else None}),
+              flush=True)
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a, argv))                      # before any GPU call in this process
+    torch.set_num_threads(min(8, os.cpu_count() or 1))   # host-side torch ops are tiny: a 256-thread pool only adds latency
+    rank, world, local, backend = dist_setup(a)
+    from action_segmentation_amd import distributed as D
+    if a.dry_run:
+        dry_run(a, rank, world, D)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    dev = torch.device('cuda', torch.cuda.current_device())
+    from action_segmentation_amd import evaluation, ops, synth
+
+    # ---------------------------------------------------------------- weak leg: every rank its own corpus
     cfg = synth.CONFIGS[a.workload]
     data = synth.SynthDatasplit(a.workload, seed=a.seed + rank, device=dev, scale=a.scale)
-    fit_args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'])
-    fitted = SemiMarkovModel.from_args(fit_args, data)
-    fitted.fit(data.subset(a.fit_videos), use_labels=True)   # closed-form fit (device statistics) on a few videos per task
-    args = synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size'],
-                           sm_constrain_transitions=bool(cfg.get('narration')),
-                           sm_constrain_with_narration=['test'] if cfg.get('narration') else [])
-    model = SemiMarkovModel.from_args(args, data)
-    model.model.load_state_dict(fitted.model.state_dict(), strict=False)
-    model.model.to(dev)
+    args, model = fit_model(a, cfg, data, dev, D, world)
     pc = model.prepare(data)                                         # inputs resident in HBM from here on
     frames = pc.n_frames
-    t = pc.tables
     stream = torch.cuda.current_stream()
-
-    def step(events=None):
-        """emission -> DP -> labels on the host.  (Same two launches as smm_decode_f32; split only so that HIP
-        events can bracket the DP kernel on the stream it runs on.)  Returns the int64 labels as a CPU tensor."""
-        elp64, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
-        if events:
-            events[0].record(stream)
-        out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
-                          class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=not a.labels_via_copy)
-        if events:
-            events[1].record(stream)
-        if a.labels_via_copy:
-            return ops.to_host(out['labels'])
-        stream.synchronize()          # the kernel wrote the labels into pinned host memory: they are on the host now
-        return out['labels']
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(a.warmup):
-        labels = step()
-    sync()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    import gc
-    gc.collect()
-    gc.disable()                      # a collection inside a 0.5 ms step would be a quarter of it
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        labels = step(evs[i])
-    sync()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    ops.check_decoded(pc.batch)
+    dt, dp_ms, labels = timed_decode(a, pc, world)
     labels_dev = labels.to(dev)      # the evaluation kernels below (outside the timed region) read device labels
-    dp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
 
-    # evaluation (SURVEY.md 8f.1), outside the timed region: the reference's per-task statistics from device counters.
-    # Every rank holds its own synthetic corpus (weak scaling), so the statistics are per rank; the job's collectives
-    # are the all-reduce of the MoF counters (SUM) and of the wall time (MAX).
-    from action_segmentation_amd import evaluation
-
+    # evaluation (SURVEY.md 8f.1), outside the timed region: the reference's per-task statistics from device counters
+    # of THIS rank's corpus (weak scaling: the corpora differ per rank; the strong leg reduces one corpus's counters)
     space = evaluation.LabelSpace.from_corpus(data.corpus, list(data._videos_by_task))
-    gt_dev = torch.empty(pc.batch.total_frames, dtype=torch.int64, device=dev)
-    for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths):
-        gt_dev[o:o + n] = data._videos[(tk, nm)]['gt_single'].to(dev)
+    gt_dev = gt_on_device(pc, data, dev)
     eval_ms = []
     for _ in range(3):
-        sync()
+        torch.cuda.synchronize()
         e0 = time.perf_counter()
         stats_by_task = evaluation.evaluate_labels(labels_dev, gt_dev, pc.lengths, pc.frame_offset, pc.task_names, space,
-                                                   optimal_assignment=False, seed=0)
+                                                   optimal_assignment=False, seed=0, video_key=video_keys(pc, data))
         eval_ms.append((time.perf_counter() - e0) * 1e3)
     summary = evaluation.summarise(stats_by_task, evaluation.STAT_KEYS)
     # closed-form fit statistics (SURVEY.md 8f.2) over the whole resident corpus: one HBM pass over the features
@@ -268,14 +495,18 @@ def main():
     lab = labels.numpy()
     correct = sum(int((lab[o:o + n] == data._videos[(tk, nm)]['gt_single'].cpu().numpy()).sum())
                   for nm, tk, o, n in zip(pc.video_names, pc.task_names, pc.frame_offset, pc.lengths))
-    counters = torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        torch.distributed.all_reduce(counters, op=torch.distributed.ReduceOp.SUM)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     assert abs(summary['mof'] - correct / frames) < 1e-12, "device MoF != host MoF"
+    rd = D.reduce_device()
+    counters = D.all_reduce_tensor(torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=rd))
+    tmax = D.all_reduce_tensor(torch.tensor([dt], dtype=torch.float64, device=rd),
+                               op=torch.distributed.ReduceOp.MAX if world > 1 else None)
     total_frames = float(counters[2])
     dt = float(tmax[0])
+
+    strong = None
+    if (world > 1 or a.strong_leg) and not a.no_strong_leg:
+        del labels_dev, gt_dev
+        strong = strong_leg(a, rank, world, dev, D)
 
     if rank == 0:
         c_avg = float(np.mean([pc.n_states[g] for g in pc.group]))
@@ -284,26 +515,25 @@ def main():
         # algorithmic HBM bytes of the DP kernel per frame: elp in 8C, history out 24C, label out 8
         dp_bytes = sum(ln * (32 * pc.n_states[g] + 8) for ln, g in zip(pc.lengths, pc.group))
         achieved = dp_bytes / (dp_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(a.workload, {}).get('smm_viterbi_kernel_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_src = pmc_traffic(a.workload)
+        par = {None: "1 rank, no collective", "nccl": "RCCL", "gloo": "gloo (rehearsal: NOT a measurement of the RCCL path)"}[backend]
+        weak = {"value": total_frames * a.steps / dt, "ms_per_step": dt / a.steps * 1e3}
+        head = weak if (a.scaling == 'weak' or strong is None) else strong
         res = {
-            "metric": "frames/sec semi-Markov decode, CrossTask T~10k K~20 L=1024, 1/2/4/8 GPUs",
-            "value": total_frames * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
-                                   "task (mean %.1f), max span length %d, D=%d; closed-form-fitted HSMM parameters"
-                       % (a.workload, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
-                          max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg, cfg['max_k'] - 1, cfg['d']),
-                       "parallelism": "videos sharded across %d GPU(s), no data-path collective; metric counters all-reduced over %s"
-                                      % (world, {None: "nothing (1 rank)", "nccl": "RCCL", "gloo": "gloo (RCCL unavailable)"}[backend])},
+            "metric": METRIC,
+            "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if head is weak else "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "backend": backend,
+            "config": {"workload": "%s seed %d: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
+                                   "task (mean %.1f; per task: %s), max span length %d, D=%d; closed-form-fitted HSMM parameters"
+                       % (a.workload, a.seed, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
+                          max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg,
+                          ' '.join(str(c) for c in sorted(pc.n_states)), cfg['max_k'] - 1, cfg['d']),
+                       "parallelism": "videos sharded across %d GPU(s), no data-path collective; step time MAX and frame counters "
+                                      "SUM all-reduced over: %s" % (world, par)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "smm_viterbi_kernel", "kernel_ms": dp_ms,
                          "algorithmic_bytes_per_launch": dp_bytes,
                          "note": "the DP is fp64-VALU-bound, not HBM-bound: %.3g lattice cells/launch = %.2f T cell/s "
@@ -311,10 +541,12 @@ def main():
                                      cells, cells / (dp_ms * 1e-3) / 1e12,
                                      2 * cells / (dp_ms * 1e-3) / FP64_VALU_PEAK)},
             "mof": float(counters[0] / counters[1]),
+            "weak_scaling": dict(weak, scaling="weak", n_gpus=world,
+                                 note="every rank decodes its own corpus of this size (seed + rank)"),
             "evaluation": {"ms": min(eval_ms), "frames_per_s": frames / (min(eval_ms) * 1e-3),
-                           "what": "accuracy_corpus statistics (confusion + per-video counters on the device, "
-                                   "assignment and ratios on the host), all tasks, outside the timed decode",
-                           "stats": {k: round(v, 6) for k, v in summary.items()}},
+                           "what": "accuracy_corpus statistics of rank 0's corpus (confusion + per-video counters on the "
+                                   "device, assignment and ratios on the host), all tasks, outside the timed decode",
+                           "stats": {k: round(v, 9) for k, v in summary.items()}},
             "fit_stats": {"ms": min(fit_ms[1:]), "frames_per_s": frames / (min(fit_ms[1:]) * 1e-3),
                           "roofline": {"bound": "hbm", "achieved": fit_bytes / (min(fit_ms[1:]) * 1e-3) / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -322,8 +554,12 @@ def main():
                                        "algorithmic_bytes_per_launch": fit_bytes},
                           "what": "smm_fit_stats_f64 (class sums + span statistics) over every frame of the workload"},
         }
+        if strong is not None:
+            res["strong_scaling"] = strong
         if a.workload == 'cfg4':
             res["logz_fwd_bwd"] = train_step_rate(args, data, model)
+        if world == 1 and not a.no_predict_e2e:
+            res["predict_end_to_end"] = predict_end_to_end(model, data)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(data, model, pc)
             try:
@@ -332,6 +568,7 @@ def main():
                 res["cpu_factored"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

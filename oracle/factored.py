@@ -25,6 +25,11 @@ def lib():
     return _lib
 
 
+def set_threads(n=0):
+    """OpenMP threads of the batch loops (n <= 0: leave as is).  Returns the number in use."""
+    return int(lib().smm_oracle_set_threads(int(n)))
+
+
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(ctypes.POINTER(ct))
 

@@ -35,6 +35,14 @@
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 
+/* OpenMP threads the batch loops below run on (bench.py's cpu_factored leg reports the number it used). */
+#ifdef _OPENMP
+#include <omp.h>
+int smm_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int smm_oracle_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* ---------------------------------------------------------------- emission */
 /* elp[i,t,c] = lognorm - 0.5 * sum_d (x-mu)^2 * inv_var + cons ; semimarkov_modules.py:324-381 */
 void smm_oracle_emission(const float *x, const int64_t *lengths, const double *mu, const double *inv_var,

@@ -81,3 +81,39 @@ def test_cli_train_save_load_decode(tmp_path):
     s2 = cli.main(['--classifier', 'semimarkov', '--cuda', '--dataset', 'synthetic:tiny', '--sm_max_span_length', '12',
                    '--batch_size', '2', '--model_input_path', out])
     assert s1 == s2 and s1['test_mof'] > 0.5
+
+
+def test_cli_training_loop_decodes_every_epoch_and_keeps_the_best_snapshot(tmp_path, capsys):
+    """main.py:207-264: per-epoch train + dev decode, epoch snapshots every 5 epochs, best model by training loss
+    (unsupervised) written to <out>/<split>.pkl."""
+    import os
+    import pickle
+    from action_segmentation_amd import cli
+    out = str(tmp_path / 'model')
+    stats = cli.main(['--classifier', 'semimarkov', '--training', 'unsupervised', '--cuda', '--dataset', 'synthetic:tiny',
+                      '--sm_max_span_length', '12', '--batch_size', '2', '--epochs', '7', '--lr', '5e-2',
+                      '--print_every', '0', '--model_output_path', out])
+    hist = cli.train.last_history
+    assert sorted(hist['stats_by_epoch']) == list(range(7))
+    assert sorted(hist['dev_mof_by_epoch']) == list(range(7))                 # --dev_decode_frequency 1
+    assert all(0.0 <= v <= 1.0 for v in hist['dev_mof_by_epoch'].values())
+    assert sorted(os.listdir(out)) == ['synthetic.pkl', 'synthetic_epoch-0.pkl', 'synthetic_epoch-5.pkl']
+    text = capsys.readouterr().out
+    assert 'best train loss' in text and text.count('dev_mof') >= 7
+    best_epoch = min(hist['stats_by_epoch'].items(), key=lambda t: t[1]['train_loss'])[0]
+    with open(os.path.join(out, 'synthetic.pkl'), 'rb') as f:
+        best = pickle.load(f)
+    assert best.model.n_classes > 0 and 'test_mof' in stats
+    assert 'best train loss %.4f in epoch %d' % (hist['stats_by_epoch'][best_epoch]['train_loss'], best_epoch) in text
+
+
+def test_cli_supervised_gradient_training_stops_on_dev(tmp_path, capsys):
+    """Supervised gradient-based training: early stopping on dev MoF (main.py:248-252)."""
+    from action_segmentation_amd import cli
+    cli.main(['--classifier', 'semimarkov', '--training', 'supervised', '--sm_supervised_method', 'closed-then-gradient',
+              '--cuda', '--dataset', 'synthetic:tiny', '--sm_max_span_length', '12', '--batch_size', '2', '--epochs', '3',
+              '--print_every', '0', '--dev_decode_frequency', '2'])
+    hist = cli.train.last_history
+    assert sorted(hist['stats_by_epoch']) == [-1, 0, 1, 2]                   # the closed-form stage calls back with -1
+    assert sorted(hist['dev_mof_by_epoch']) == [-1, 0, 2]
+    assert 'best dev mof' in capsys.readouterr().out

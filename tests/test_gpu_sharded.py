@@ -1,0 +1,153 @@
+"""Multi-GPU path on ONE GPU: a corpus sharded by video decodes to the same labels, and the evaluation counters summed
+over the shards give the statistics of the whole corpus (reference src/data/corpus.py:405-604 summed as
+src/main.py:486-532)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from action_segmentation_amd import evaluation, synth
+from action_segmentation_amd.semimarkov import SemiMarkovModel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(seed=4):
+    data = synth.SynthDatasplit('tiny', seed=seed)
+    fit_args = synth.make_args(data.max_k, cuda=False, batch_size=2)
+    fitted = SemiMarkovModel.from_args(fit_args, data)
+    fitted.fit(data, use_labels=True)
+    args = synth.make_args(data.max_k, cuda=True, batch_size=2)
+    model = SemiMarkovModel.from_args(args, data)
+    model.model.load_state_dict(fitted.model.state_dict(), strict=False)
+    model.model.cuda()
+    return data, model
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_predict_is_a_partition_of_predict(world):
+    data, model = build()
+    full = model.predict(data)
+    seen = {}
+    for rank in range(world):
+        part = model.predict(data, shard=(rank, world))
+        assert not set(part) & set(seen)
+        seen.update(part)
+    assert set(seen) == set(full)
+    for name in full:
+        np.testing.assert_array_equal(seen[name], full[name], err_msg=name)
+
+
+class _Abort(Exception):
+    pass
+
+
+def _sharded_stats(data, preds_by_rank, optimal):
+    """evaluate every shard with a ``reduce`` that sums over the shards (three passes: the second reduction depends on
+    the result of the first, exactly as in a real job where both are collectives)."""
+    world = len(preds_by_rank)
+    grab = {}
+
+    def run(rank, reduce):
+        return evaluation.accuracy_corpus(data, preds_by_rank[rank], optimal, seed=3, reduce=reduce)
+
+    def first(rank):
+        def reduce(t):
+            grab[('conf', rank)] = t.clone()
+            raise _Abort
+        return reduce
+    for r in range(world):
+        with pytest.raises(_Abort):
+            run(r, first(r))
+    conf = sum(grab[('conf', r)] for r in range(world))
+
+    def second(rank):
+        calls = []
+
+        def reduce(t):
+            calls.append(1)
+            if len(calls) == 1:
+                return conf.clone()
+            grab[('sums', rank)] = t.clone()
+            raise _Abort
+        return reduce
+    for r in range(world):
+        with pytest.raises(_Abort):
+            run(r, second(r))
+    sums = sum(grab[('sums', r)] for r in range(world))
+
+    def third():
+        calls = []
+
+        def reduce(t):
+            calls.append(1)
+            return conf.clone() if len(calls) == 1 else sums.clone()
+        return reduce
+    return [run(r, third()) for r in range(world)]
+
+
+@pytest.mark.parametrize('optimal', [False, True])
+def test_reduced_counters_equal_single_process(optimal):
+    data, model = build(seed=6)
+    full = model.predict(data)
+    rng = np.random.default_rng(0)
+    noisy = {}
+    for (task, name), smp in data._videos.items():          # imperfect predictions: every counter gets exercised
+        p = full[name].copy()
+        ids = smp['task_indices'].numpy()
+        flip = rng.random(p.shape[0]) < 0.15
+        p[flip] = rng.choice(ids, size=int(flip.sum()))
+        noisy[name] = p
+    single = evaluation.accuracy_corpus(data, noisy, optimal, seed=3)
+    names = sorted(noisy)
+    shards = [{n: noisy[n] for n in names[0::3]}, {n: noisy[n] for n in names[1::3]}, {n: noisy[n] for n in names[2::3]},
+              {}]                                            # (a rank without videos takes part too)
+    for got in _sharded_stats(data, shards, optimal):
+        assert set(got) == set(single)
+        for task in single:
+            for key, pair in single[task].items():
+                np.testing.assert_allclose(np.asarray(got[task][key], dtype=np.float64),
+                                           np.asarray(pair, dtype=np.float64), rtol=1e-13, atol=0, err_msg='%s %s' % (task, key))
+
+
+def _bench(args, timeout=900):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_one_corpus_same_stats_as_one_rank():
+    """`python bench.py --gpus 2` spawns two ranks (here both on the one GPU of the box, gloo for the reductions --
+    RCCL refuses two ranks on one device) and the strong-scaling leg's reduced statistics equal the one-rank ones."""
+    common = ['--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+              '--no-predict-e2e', '--seed', '5']
+    one = _bench(['--gpus', '1', '--strong-leg'] + common)
+    two = _bench(['--gpus', '2', '--backend', 'gloo', '--share-gpus'] + common)
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2
+    assert two['backend'] == 'gloo' and two['scaling'] == 'weak'
+    s1, s2 = one['strong_scaling'], two['strong_scaling']
+    assert s2['n_gpus'] == 2 and s1['frames'] == s2['frames'] and s1['videos'] == s2['videos']
+    assert s2['max_frames_on_a_rank'] < s2['frames']
+    assert s1['stats'] == s2['stats']
+    assert two['weak_scaling']['value'] > 0 and two['value'] == two['weak_scaling']['value']
+    strong_head = _bench(['--gpus', '2', '--backend', 'gloo', '--share-gpus', '--scaling', 'strong'] + common)
+    assert strong_head['scaling'] == 'strong' and strong_head['strong_scaling']['stats'] == s1['stats']
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bench_two_ranks_rccl():
+    common = ['--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+              '--no-predict-e2e', '--seed', '5']
+    one = _bench(['--gpus', '1', '--strong-leg'] + common)
+    two = _bench(['--gpus', '2'] + common)
+    assert two['n_gpus'] == 2 and two['backend'] == 'nccl'
+    assert one['strong_scaling']['stats'] == two['strong_scaling']['stats']

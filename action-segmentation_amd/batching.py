@@ -127,6 +127,7 @@ class PackedCorpus:
         self.task_names = []
         self.groups = []           # per group: dict(task, valid_classes (LongTensor or None))
         self.additional_ends = []  # per video (list) or None
+        self.batch_index = []      # per video: index of the source batch it came from
         self.k_rows = None
         self.tables = None         # stacked per-group fp64 tables on the device (filled by the module)
 
@@ -150,7 +151,7 @@ def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn
     group_of = {}
     off = 0
     k_rows = max(max_k, 2)
-    for batch in batches:
+    for bi, batch in enumerate(batches):
         tasks = batch['task_name']
         assert len(set(tasks)) == 1, "a source batch holds one task"
         task = tasks[0]
@@ -179,6 +180,7 @@ def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn
             pc.video_names.append(batch['video_name'][i])
             pc.task_names.append(task)
             pc.additional_ends.append(None if addl is None else addl[i])
+            pc.batch_index.append(bi)
             off += int(t)
     pc.k_rows = k_rows
     pc.x = torch.cat([f.to(device=device, dtype=torch.float32) for f in feats], dim=0).contiguous()

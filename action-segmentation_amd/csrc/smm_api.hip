@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(512) smm_meta_upload_kernel(SmmMetaChunk c, ui
 
 int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream)
 {
+    if (std::getenv("SMM_UPLOAD_MEMCPY")) return (int)hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream);   // (debug)
     const size_t words = (bytes + 3) / 4;                    // (every destination is padded to 256 B by the planners)
     const unsigned char *src = static_cast<const unsigned char *>(src_host);
     for (size_t off = 0; off < words; off += 512) {

@@ -209,6 +209,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
             sh_h[0][i][c] = SMM_NEG_INF;
             sh_h[1][i][c] = (i == B - 1) ? h0 : SMM_NEG_INF;     // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)frame_of(i) * cm + c] : 0.0;    // block 0
+            sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again: the chain wave's dead lanes must not read LDS garbage)
         }
         sh_gam[c] = SMM_NEG_INF;
         if (c < C) { hcum[c] = 0.0; hh[c] = h0; }
@@ -252,7 +253,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     ap[i] = sh_apart[jj & 1][i][to];
-                    ev[i] = sh_e[jj & 1][i][to];
+                    ev[i] = live ? sh_e[jj & 1][i][to] : 0.0;   // dead lanes stay at (cum 0, everything else -inf): no NaN can form
                 }
                 // Everything of a position that does not depend on h[n-1] -- the pushers' A' and the candidates
                 // k = 2..K0 -- is folded into (pm, ps) ahead of the serial path: A = LSE(that, h[n-1] + len[1]).

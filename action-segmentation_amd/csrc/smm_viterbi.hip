@@ -452,6 +452,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_h[0][i][c] = SMM_NEG_INF;
             sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
+            sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
             if (PAIR) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[PAIR ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
         sh_gam[c] = SMM_NEG_INF;

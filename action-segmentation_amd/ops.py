@@ -150,7 +150,7 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
         _dev(len_scores, dt, 'len_scores'), _dev(endpen, dt, 'endpen'), _dev(class_map, torch.int64, 'class_map'),
         _dev(spans, torch.int64, 'spans'), _dev(labels, torch.int64, 'labels'), _dev(best, torch.float64, 'best'),
         _dev(n_segs, torch.int32, 'n_segs'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
-    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs)
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, _err=_err_view(batch, ws))
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
@@ -172,7 +172,7 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(class_map, torch.int64, 'class_map'), _dev(spans, torch.int64, 'spans'),
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
-    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32)
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=_err_view(batch, ws))
 
 
 def logz(batch, elp, trans, init, len_scores, endpen=None, ws=None):
@@ -231,20 +231,30 @@ def to_host(t):
     return out
 
 
-def error_flag(batch, ws=None):
-    """The kernels' error word for the last call on this batch's workspace (synchronises): non-zero means a NaN (or
-    inf - inf) reached the DP and the decode of that video stopped early."""
+def _err_view(batch, ws):
+    """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
+    return ws[off:off + 4].view(torch.int32)
+
+
+def error_flag(batch, out=None, ws=None):
+    """The kernels' error word of a decode (synchronises): non-zero means a NaN (or inf - inf) reached the DP and the
+    decode of that video stopped early.  ``out``: the dict the launch returned (its ``_err`` entry views the workspace
+    that launch wrote to -- the per-stream cache may have been regrown or switched since); without it the current
+    (device, stream) workspace is read, which is only right directly after the launch."""
+    if out is not None and out.get('_err') is not None:
+        return int(out['_err'].item())
     if ws is None:
         ws = workspace(batch.workspace_bytes(), torch.device('cuda', torch.cuda.current_device()))
-    return int(ws[off:off + 4].view(torch.int32).item())
+    return int(_err_view(batch, ws).item())
 
 
-def check_decoded(batch):
+def check_decoded(batch, out=None):
     """Call after the decode's outputs have reached the host (the stream is idle then): raises SmmError when the DP
-    kernel flagged the run.  1: a NaN / inf - inf reached the DP; 2: a two-CU pair (smm_viterbi.hip, PAIR mode) gave
-    up waiting for its partner workgroup -- the outputs are invalid; SMM_PAIRS=0 in the environment disables pairing."""
-    flag = error_flag(batch)
+    kernel flagged the run.  1: a NaN / inf - inf reached the DP; 2: a two-CU gang (smm_viterbi.hip, PAIR mode) gave
+    up waiting for its partner workgroup -- the outputs are invalid (the library relaunches such a batch without
+    gangs by itself, so this only surfaces when that was switched off)."""
+    flag = error_flag(batch, out)
     if flag == 2:
         raise _lib.SmmError("libsmmdp: a leader / follower workgroup pair timed out waiting for its partner (the two "
                             "were not co-resident on the GPU); rerun with SMM_PAIRS=0")

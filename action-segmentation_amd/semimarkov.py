@@ -106,22 +106,48 @@ class SemiMarkovModel(object):
             self.model.initialize_gaussian(big['features'].to(self.device), big['lengths'])
         loader = make_data_loader(args, train_data, batch_by_task=True, shuffle=True, batch_size=args.batch_size)
         k = args.sm_max_span_length
+        # Unlabelled data with --batch_accumulation > 1: the batches of one optimiser step go through ONE launch of each
+        # kernel (log_likelihood_packed) instead of one latency-bound launch pair per batch of 5 videos; the loss is the
+        # same mean over batches of the batch-mean -log Z, so the step is the reference's step.
+        packed = (not use_labels) and args.batch_accumulation > 1
+        train_cons = self._train_constraints(train_data)
         for epoch in range(args.epochs):
             start_time = time.time()
             self.model.train()
             losses, pending = [], []
             train_nll = num_frames = num_videos = 0
+
+            def step(batch_ix):
+                if args.print_every and batch_ix % args.print_every == 0:
+                    print('Epoch: %02d, Batch: %03d/%03d, loss: %.4f, recon: %.4f, Throughput: %.2f vid / sec' % (
+                        epoch, batch_ix, len(loader), train_nll / num_videos, train_nll / num_frames,
+                        num_videos / (time.time() - start_time)))
+                if args.max_grad_norm is not None:
+                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), args.max_grad_norm)
+                optimizer.step()
+                self.model.zero_grad()
+
             for batch_ix, batch in enumerate(loader):
                 if args.train_limit and batch_ix >= args.train_limit:
                     break
                 tasks, lengths = batch['task_name'], batch['lengths']
-                cons = None
-                if 'train' in args.sm_constrain_with_narration:
-                    assert all_equal(tasks)
-                    cons = self.expand_constraints(train_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
-                    cons = cons * args.sm_constrain_narration_weight
                 num_frames += int(lengths.sum())
                 num_videos += len(lengths)
+                if packed:
+                    pending.append(batch)
+                    if len(pending) >= args.batch_accumulation:
+                        pc = pack_batches(pending, self.device, self.model.max_k, constraints_fn=train_cons,
+                                          additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
+                        ll = self.model.log_likelihood_packed(pc)              # [batches]
+                        loss_b = -ll
+                        loss_b.mean().backward()
+                        vals = loss_b.detach().cpu().tolist()
+                        losses += vals
+                        train_nll += sum(v * len(b['lengths']) for v, b in zip(vals, pending))
+                        pending = []
+                        step(batch_ix)
+                    continue
+                cons = train_cons(batch) if train_cons else None
                 features = batch['features'].to(self.device)
                 spans = semimarkov_utils.labels_to_spans(batch['gt_single'], max_k=k) if use_labels else None
                 addl = self.make_additional_allowed_ends(tasks, lengths)
@@ -135,14 +161,7 @@ class SemiMarkovModel(object):
                 if len(pending) >= args.batch_accumulation:
                     (sum(pending) / len(pending)).backward()
                     pending = []
-                    if args.print_every and batch_ix % args.print_every == 0:
-                        print('Epoch: %02d, Batch: %03d/%03d, loss: %.4f, recon: %.4f, Throughput: %.2f vid / sec' % (
-                            epoch, batch_ix, len(loader), train_nll / num_videos, train_nll / num_frames,
-                            num_videos / (time.time() - start_time)))
-                    if args.max_grad_norm is not None:
-                        torch.nn.utils.clip_grad_norm_(self.model.parameters(), args.max_grad_norm)
-                    optimizer.step()
-                    self.model.zero_grad()
+                    step(batch_ix)
             train_loss = float(np.mean(losses))
             if scheduler is not None:
                 scheduler.step(train_loss)
@@ -169,6 +188,17 @@ class SemiMarkovModel(object):
         for index, label in enumerate(step_indices):
             out[:, :, task_indices.index(label)] = constraints[:, :, index]
         return out
+
+    def _train_constraints(self, train_data):
+        if 'train' not in self.args.sm_constrain_with_narration:
+            return None
+
+        def fn(batch):
+            tasks = batch['task_name']
+            assert all_equal(tasks)
+            ce = self.expand_constraints(train_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
+            return ce * self.args.sm_constrain_narration_weight
+        return fn
 
     def _test_constraints(self, test_data):
         if 'test' not in self.args.sm_constrain_with_narration:
@@ -199,7 +229,7 @@ class SemiMarkovModel(object):
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
         torch.cuda.current_stream().synchronize()
         labels = out['labels'].numpy().copy()
-        ops.check_decoded(pc.batch)
+        ops.check_decoded(pc.batch, out)
         preds = {}
         for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
             preds[name] = labels[off:off + t]

@@ -42,16 +42,18 @@ def sliding_sum(inputs, k):
 
 
 class _LogPartition(torch.autograd.Function):
-    """log Z of one batch as a differentiable function of the fp64 factor tables (emission factors w, cst; transition,
-    initial and length tables).  Forward: smm_emission_f64 + smm_logz_f64; backward: smm_logz_bwd_f64 (posterior
-    marginals) + the chain rule through elp = cst + x.w - 0.5 x^2.inv_var as two small torch GEMMs."""
+    """log Z of every video of one launch as a differentiable function of the fp64 factor tables (emission factors w,
+    cst; transition, initial and length tables; stacked per parameter group).  Forward: smm_emission_f64 +
+    smm_logz_f64; backward: smm_logz_bwd_f64 (posterior marginals) + the chain rule through
+    elp = cst + x.w - 0.5 x^2.inv_var as small torch GEMMs, one per run of frames that share a group.
+    ``runs``: [(group, first frame, end frame)] covering every frame that belongs to a video."""
 
     @staticmethod
-    def forward(ctx, batch, x, cons, endpen, w, cst, inv_var, trans, init, len_scores):
+    def forward(ctx, batch, runs, x, cons, endpen, w, cst, inv_var, trans, init, len_scores):
         ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=x.device)   # private: survives until backward
         elp64, _ = ops.emission(batch, x, w, cst, inv_var, cons=cons)
         z = ops.logz(batch, elp64, trans, init, len_scores, endpen=endpen, ws=ws)
-        ctx.batch, ctx.endpen, ctx.ws = batch, endpen, ws
+        ctx.batch, ctx.endpen, ctx.ws, ctx.runs = batch, endpen, ws, runs
         ctx.save_for_backward(x, elp64, trans, init, len_scores, z)
         return z
 
@@ -61,11 +63,17 @@ class _LogPartition(torch.autograd.Function):
         g = ops.logz_bwd(ctx.batch, elp64, trans, init, len_scores, z, grad_logz=gz.to(torch.float64).contiguous(),
                          endpen=ctx.endpen, ws=ctx.ws)
         ge = g['elp']                                   # [frames, C]: posterior state occupancy x upstream
-        xd = x.to(torch.float64)
-        g_w = (xd.t() @ ge).unsqueeze(0)                # [1, D, C]
-        g_cst = ge.sum(0, keepdim=True)                 # [1, C]
-        g_iv = -0.5 * ((xd * xd) * ge.sum(1, keepdim=True)).sum(0)
-        return None, None, None, None, g_w, g_cst, g_iv, g['trans'], g['init'], g['len']
+        n_groups, d, cm = trans.size(0), x.size(1), ge.size(1)
+        g_w = torch.zeros((n_groups, d, cm), dtype=torch.float64, device=x.device)
+        g_cst = torch.zeros((n_groups, cm), dtype=torch.float64, device=x.device)
+        g_iv = torch.zeros(d, dtype=torch.float64, device=x.device)
+        for grp, f0, f1 in ctx.runs:
+            xd = x[f0:f1].to(torch.float64)
+            gr = ge[f0:f1]
+            g_w[grp] += xd.t() @ gr                     # [D, C]
+            g_cst[grp] += gr.sum(0)
+            g_iv += -0.5 * ((xd * xd) * gr.sum(1, keepdim=True)).sum(0)
+        return None, None, None, None, None, g_w, g_cst, g_iv, g['trans'], g['init'], g['len']
 
 
 class SemiMarkovModule(nn.Module):
@@ -433,7 +441,7 @@ class SemiMarkovModule(nn.Module):
         out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
                            want_elp=return_elp, want_labels=False)
         pred_spans = out['spans'].cpu()
-        ops.check_decoded(out['_batch'])
+        ops.check_decoded(out['_batch'], out)
         if return_elp:
             b, tmax = features.shape[:2]
             return pred_spans, out['elp'].view(b, tmax, -1)
@@ -465,25 +473,36 @@ class SemiMarkovModule(nn.Module):
         return out
 
     # ------------------------------------------------------------------ packed multi-task decode
-    def prepare_packed(self, pc):
-        """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns."""
+    def stacked_tables(self, pc, differentiable=False):
+        """fp64 factor tables of every group of a PackedCorpus stacked to [groups, ...] and zero-padded to c_max columns.
+        ``differentiable``: built from the parameters with autograd history (training); otherwise the cached decode
+        tables."""
         dev = pc.x.device
-        tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
+        if differentiable:
+            tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
+        else:
+            tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
         n_states = [int(t['init'].numel()) for t in tabs]
-        cm, d, g = max(n_states), pc.x.size(1), len(tabs)
-        k_rows = tabs[0]['len'].size(0)
-        f64 = dict(dtype=torch.float64, device=dev)
-        st = dict(trans=torch.zeros(g, cm, cm, **f64), init=torch.zeros(g, cm, **f64), len=torch.zeros(g, k_rows, cm, **f64),
-                  w=torch.zeros(g, d, cm, **f64), cst=torch.zeros(g, cm, **f64), inv_var=tabs[0]['inv_var'],
-                  class_map=torch.zeros(g, cm + 1, dtype=torch.int64, device=dev))
-        for i, (t, c) in enumerate(zip(tabs, n_states)):
-            st['trans'][i, :c, :c] = t['trans']
-            st['init'][i, :c] = t['init']
-            st['len'][i, :, :c] = t['len']
-            st['w'][i, :, :c] = t['w']
-            st['cst'][i, :c] = t['cst']
-            st['class_map'][i, :c + 1] = t['class_map']
+        cm = max(n_states)
+        pad = lambda t, c, rows=False: F.pad(t, (0, cm - c) + ((0, cm - c) if rows else ()))
+        st = dict(trans=torch.stack([pad(t['trans'], c, True) for t, c in zip(tabs, n_states)]).contiguous(),
+                  init=torch.stack([pad(t['init'], c) for t, c in zip(tabs, n_states)]).contiguous(),
+                  len=torch.stack([pad(t['len'], c) for t, c in zip(tabs, n_states)]).contiguous(),
+                  w=torch.stack([pad(t['w'], c) for t, c in zip(tabs, n_states)]).contiguous(),
+                  cst=torch.stack([pad(t['cst'], c) for t, c in zip(tabs, n_states)]).contiguous(),
+                  inv_var=tabs[0]['inv_var'],
+                  class_map=torch.stack([F.pad(t['class_map'], (0, cm - c)) for t, c in zip(tabs, n_states)]).contiguous())
+        return st, n_states, cm, tabs[0]['len'].size(0)
+
+    def prepare_packed(self, pc, differentiable=False):
+        """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns, and
+        build the per-video end penalties / constraint block / launch metadata."""
+        dev = pc.x.device
+        d = pc.x.size(1)
+        st, n_states, cm, k_rows = self.stacked_tables(pc, differentiable)
         pc.tables, pc.n_states, pc.c_max, pc.k_rows = st, n_states, cm, k_rows
+        if getattr(pc, '_static', None) == (cm, k_rows, id(self)):
+            return pc                                # end penalties, constraints and launch metadata do not change
         pc.kp = [min(k, k_rows) for k in pc.kp]
         pc.endpen = None
         if self.allowed_ends is not None:
@@ -504,6 +523,7 @@ class SemiMarkovModule(nn.Module):
             pc.cons = cons
         pc.batch = ops.Batch(pc.lengths, n_states, k_rows, c_max=cm, frame_offset=pc.frame_offset, group=pc.group,
                              kp=pc.kp, d=d, total_frames=pc.x.size(0))
+        pc._static = (cm, k_rows, id(self))
         return pc
 
     def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False, labels_on_host=False):
@@ -573,10 +593,39 @@ class SemiMarkovModule(nn.Module):
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
         endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
-        return _LogPartition.apply(batch, x, cons, endpen, tab['w'].unsqueeze(0).contiguous(),
+        runs = [(0, i * tmax, i * tmax + int(t)) for i, t in enumerate(lengths_host)]    # (padding frames carry no gradient)
+        return _LogPartition.apply(batch, runs, x, cons, endpen, tab['w'].unsqueeze(0).contiguous(),
                                    tab['cst'].unsqueeze(0).contiguous(), tab['inv_var'].contiguous(),
                                    tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
                                    tab['len'].unsqueeze(0).contiguous())
+
+    def log_partition_packed(self, pc):
+        """log Z of every video of a PackedCorpus (any number of single-task batches, any mix of tasks) in ONE launch
+        of each kernel, differentiable w.r.t. the parameters: the unsupervised objective of reference
+        semimarkov.py:259-286 for many batches at once (gradient accumulation, or the E-step over a whole corpus).
+        Returns fp64 [n_videos] in the order of ``pc.video_names``."""
+        self._require_device(pc.x, 'log_partition_packed')
+        self.prepare_packed(pc, differentiable=True)
+        t = pc.tables
+        runs, cur = [], None
+        for g, off, n in zip(pc.group, pc.frame_offset, pc.lengths):      # runs of frames that share a group
+            if cur is not None and cur[0] == g and cur[2] == off:
+                cur[2] = off + n
+            else:
+                cur = [g, off, off + n]
+                runs.append(cur)
+        return _LogPartition.apply(pc.batch, [tuple(r) for r in runs], pc.x, pc.cons, pc.endpen, t['w'], t['cst'],
+                                   t['inv_var'], t['trans'], t['init'], t['len'])
+
+    def log_likelihood_packed(self, pc):
+        """Per source batch the mean log-likelihood the reference's ``log_likelihood(spans=None)`` returns for it
+        (semimarkov_modules.py:657: ``dist.partition.mean()``): fp64 [n_batches], differentiable."""
+        z = self.log_partition_packed(pc)
+        bi = torch.as_tensor(pc.batch_index, device=z.device)
+        nb = int(bi.max()) + 1
+        sums = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, z)
+        cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
+        return sums / cnt
 
     def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None):

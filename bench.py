@@ -273,6 +273,7 @@ def timed_decode(a, pc, world, want_events=True):
             events[0].record(stream)
         out = ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen,
                           class_map=t['class_map'], want_spans=False, want_labels=True, labels_on_host=not a.labels_via_copy)
+        last['out'] = out
         if events:
             events[1].record(stream)
         if a.labels_via_copy:
@@ -286,6 +287,7 @@ def timed_decode(a, pc, world, want_events=True):
             torch.distributed.barrier()
 
     labels = None
+    last = {}
     for _ in range(a.warmup):
         labels = step()
     sync()
@@ -300,7 +302,7 @@ def timed_decode(a, pc, world, want_events=True):
     dt = time.perf_counter() - t0
     gc.enable()
     if not empty:
-        ops.check_decoded(pc.batch)
+        ops.check_decoded(pc.batch, last.get('out'))
     dp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs])) if (want_events and not empty) else None
     return dt, dp_ms, labels
 
@@ -382,32 +384,116 @@ def predict_end_to_end(model, data):
 
 
 def train_step_rate(args, data, model):
-    """Secondary figure for config 4: frames/s of the unsupervised objective's forward + backward (emission, log Z
-    forward kernel, time-reversed backward kernel, marginal kernels, chain rule into the parameters), batch by batch
-    as SemiMarkovModel.fit does it (single-task batches of --batch_size videos, narration constraints on)."""
-    from action_segmentation_amd.batching import make_data_loader
+    """Secondary figures for config 4: frames/s of the unsupervised objective's forward + backward (emission, log Z
+    forward kernel, time-reversed backward kernel, marginal kernels, chain rule into the parameters):
+      * ``packed``: every batch of the corpus through ONE launch of each kernel (log_likelihood_packed) -- the E-step of
+        EM / a --batch_accumulation step over the whole corpus;
+      * ``per_batch``: batch by batch as SemiMarkovModel.fit steps with --batch_accumulation 1 (single-task batches of
+        --batch_size videos, narration constraints on): a latency-bound launch pair per 5 videos."""
+    from action_segmentation_amd.batching import make_data_loader, pack_batches
     m = model.model
     m.train()
     batches = list(make_data_loader(args, data, shuffle=False, batch_by_task=True, batch_size=args.batch_size))
     cons_fn = model._test_constraints(data)
+    ends_fn = lambda b: model.make_additional_allowed_ends(b['task_name'], b['lengths'])
+    frames = sum(int(b['lengths'].sum()) for b in batches)
 
-    def one_pass():
-        frames = 0
+    def per_batch():
         for b in batches:
             m.zero_grad()
             cons = cons_fn(b) if cons_fn else None
-            addl = model.make_additional_allowed_ends(b['task_name'], b['lengths'])
             ll, _ = m.log_likelihood(b['features'].to(model.device), b['lengths'], b['task_indices'], spans=None,
-                                     additional_allowed_ends_per_instance=addl, constraints=cons)
+                                     additional_allowed_ends_per_instance=ends_fn(b), constraints=cons)
             (-ll).backward()
-            frames += int(b['lengths'].sum())
         torch.cuda.synchronize()
-        return frames
-    one_pass()
-    t0 = time.perf_counter()
-    frames = one_pass()
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "batches": len(batches), "ms_per_batch": dt / len(batches) * 1e3}
+
+    pc = pack_batches(batches, model.device, m.max_k, constraints_fn=cons_fn, additional_ends_fn=ends_fn)
+
+    def packed():
+        m.zero_grad()
+        ll = m.log_likelihood_packed(pc)
+        (-ll.mean()).backward()
+        torch.cuda.synchronize()
+
+    def kernels_only():
+        """the two DP launches + marginal kernels alone, HIP events on the stream (no torch glue)"""
+        from action_segmentation_amd import ops
+        t = pc.tables
+        tt = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in t.items()}
+        ws = torch.empty(pc.batch.workspace_bytes(), dtype=torch.uint8, device=model.device)
+        elp64, _ = ops.emission(pc.batch, pc.x, tt['w'], tt['cst'], tt['inv_var'], cons=pc.cons)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        st = torch.cuda.current_stream()
+        e[0].record(st)
+        z = ops.logz(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], endpen=pc.endpen, ws=ws)
+        e[1].record(st)
+        ops.logz_bwd(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], z, endpen=pc.endpen, ws=ws)
+        e[2].record(st)
+        torch.cuda.synchronize()
+        return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+
+    out = {}
+    for name, fn in (('packed', packed), ('per_batch', per_batch)):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": frames / dt, "unit": "frames/s", "ms": dt * 1e3}
+    kernels_only()
+    fwd_ms, bwd_ms = kernels_only()
+    # algorithmic HBM bytes of the forward + backward DP (SURVEY 8d): elp 8C read twice, two histories 24C each written,
+    # both read by the marginals, g_elp 8C written
+    c_sum = sum(ln * pc.n_states[g] for ln, g in zip(pc.lengths, pc.group))
+    lz_bytes = c_sum * (8 + 24) * 2 + c_sum * (48 + 8)
+    cells = sum(ln * ((min(kp, ln + 1) - 1) * pc.n_states[g] + pc.n_states[g] ** 2)
+                for ln, kp, g in zip(pc.lengths, pc.kp, pc.group))
+    out.update(value=out['packed']['value'], unit="frames/s", batches=len(batches),
+               ms_per_batch=out['per_batch']['ms'] / len(batches),
+               kernels={"logz_fwd_ms": fwd_ms, "logz_bwd_ms": bwd_ms,
+                        "roofline": {"bound": "hbm", "achieved": lz_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": lz_bytes / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes": lz_bytes,
+                                     "note": "latency/VALU-bound like the Viterbi kernel: %.3g lattice cells x 2 passes" % cells}})
+    return out
+
+
+def logz_cpu_baseline(pc, budget_s=10.0):
+    """cpu_baseline of the log-partition leg (kind 'port'): oracle/smm_oracle.c forward + exact backward (posteriors),
+    OpenMP over the videos of a task, on whole tasks until ~budget_s are spent."""
+    from oracle import factored as F
+    t = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in pc.tables.items()}
+    cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    by_group = {}
+    for i in range(pc.n_videos):
+        by_group.setdefault(pc.group[i], []).append(i)
+    inv_var = t['inv_var'].cpu().numpy()
+    frames, dt, n_vid = 0, 0.0, 0
+    for g, vids in sorted(by_group.items()):
+        c = pc.n_states[g]
+        tmax = max(pc.lengths[i] for i in vids)
+        kp = max(pc.kp[i] for i in vids)
+        w, cst = t['w'][g, :, :c].cpu().numpy(), t['cst'][g, :c].cpu().numpy()
+        xs = [pc.x[pc.frame_offset[i]:pc.frame_offset[i] + pc.lengths[i]].cpu().numpy() for i in vids]
+        cons = None if pc.cons is None else [pc.cons[pc.frame_offset[i]:pc.frame_offset[i] + pc.lengths[i], :c].cpu().numpy() for i in vids]
+        ep = None if pc.endpen is None else pc.endpen[vids][:, :c].cpu().numpy()
+        t0 = time.perf_counter()
+        elp = np.zeros((len(vids), tmax, c))
+        for j, x in enumerate(xs):
+            xd = x.astype(np.float64)
+            elp[j, :x.shape[0]] = cst + xd @ w - 0.5 * (xd * xd) @ inv_var[:, None]
+            if cons is not None:
+                elp[j, :x.shape[0]] += cons[j]
+        F.logz(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
+               t['len'][g, :kp, :c].cpu().numpy(), ep, grad=True)
+        dt += time.perf_counter() - t0
+        frames += sum(pc.lengths[i] for i in vids)
+        n_vid += len(vids)
+        if dt > budget_s:
+            break
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d videos, oracle/smm_oracle.c log-partition forward + exact backward, OpenMP over the videos of a "
+                      "task (%d host threads), %.1f s" % (n_vid, cores, dt)}
 
 
 def pmc_traffic(workload):
@@ -558,6 +644,11 @@ def main():
             res["strong_scaling"] = strong
         if a.workload == 'cfg4':
             res["logz_fwd_bwd"] = train_step_rate(args, data, model)
+            if not a.no_cpu_baseline:
+                try:
+                    res["logz_fwd_bwd"]["cpu_baseline"] = logz_cpu_baseline(pc)
+                except Exception as e:
+                    res["logz_fwd_bwd"]["cpu_baseline"] = {"error": str(e)}
         if world == 1 and not a.no_predict_e2e:
             res["predict_end_to_end"] = predict_end_to_end(model, data)
         if world == 1 and not a.no_cpu_baseline:

@@ -22,5 +22,5 @@ def probe(b, T, C, K, reps=3):
         e0.record(); z = ops.logz(batch, elp, trans, init, lens); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print(f"logz b={b} T={T} C={C} K={K}: {min(ts):.3f} ms  ns/frame/video={min(ts)*1e6/T:.0f}", flush=True)
-for c, k in ((14, 1024), (15, 1024), (21, 1024), (23, 1024), (16, 64), (16, 256)):
+for c, k in ((14, 1024), (15, 1024), (21, 1024), (23, 1024), (28, 1024), (16, 64), (16, 256), (12, 20), (21, 512)):
     probe(64, 2048, c, k)

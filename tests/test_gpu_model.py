@@ -117,3 +117,55 @@ def test_cli_supervised_gradient_training_stops_on_dev(tmp_path, capsys):
     assert sorted(hist['stats_by_epoch']) == [-1, 0, 1, 2]                   # the closed-form stage calls back with -1
     assert sorted(hist['dev_mof_by_epoch']) == [-1, 0, 2]
     assert 'best dev mof' in capsys.readouterr().out
+
+
+@pytest.mark.parametrize('constrain', [False, True])
+def test_packed_log_likelihood_equals_per_batch(constrain):
+    """One launch for many single-task batches (log_likelihood_packed) == the reference's batch-by-batch calls: the
+    per-batch values and the gradient of their mean (what --batch_accumulation forms) agree to 1e-9."""
+    from action_segmentation_amd.batching import pack_batches
+    data = synth.SynthDatasplit('tiny', seed=12)
+    narr = ['train'] if constrain else []
+    args = synth.make_args(data.max_k, cuda=True, batch_size=2, sm_constrain_transitions=constrain,
+                           sm_constrain_with_narration=narr)
+    torch.manual_seed(0)
+    model = SemiMarkovModel.from_args(args, data)
+    m = model.model
+    with torch.no_grad():
+        m.gaussian_means.normal_(0, 0.3)
+        m.poisson_log_rates.uniform_(1.0, 2.0)
+        m.transition_logits.normal_()
+    batches = list(make_data_loader(args, data, shuffle=False, batch_by_task=True, batch_size=2))
+    cons_fn = model._train_constraints(data)
+    names = ['poisson_log_rates', 'gaussian_means', 'transition_logits', 'init_logits']
+    # reference pattern
+    m.zero_grad()
+    lls = []
+    for b in batches:
+        ll, _ = m.log_likelihood(b['features'].to(model.device), b['lengths'], b['task_indices'], spans=None,
+                                 additional_allowed_ends_per_instance=model.make_additional_allowed_ends(b['task_name'], b['lengths']),
+                                 constraints=cons_fn(b) if cons_fn else None)
+        lls.append(ll)
+    (-(sum(lls) / len(lls))).backward()
+    ref_ll = torch.stack(lls).detach().cpu().numpy()
+    ref_g = {n: getattr(m, n).grad.detach().cpu().double().numpy().copy() for n in names}
+    # packed
+    m.zero_grad()
+    pc = pack_batches(batches, model.device, m.max_k, constraints_fn=cons_fn,
+                      additional_ends_fn=lambda b: model.make_additional_allowed_ends(b['task_name'], b['lengths']))
+    ll_p = m.log_likelihood_packed(pc)
+    (-ll_p.mean()).backward()
+    np.testing.assert_allclose(ll_p.detach().cpu().numpy(), ref_ll, rtol=1e-12, atol=1e-9)
+    for n in names:
+        got = getattr(m, n).grad.detach().cpu().double().numpy()
+        # (the parameters and their .grad are fp32: agreement to fp32 rounding of sums formed in a different order)
+        np.testing.assert_allclose(got, ref_g[n], rtol=2e-6, atol=2e-6 * max(1.0, np.abs(ref_g[n]).max()), err_msg=n)
+
+
+def test_fit_with_batch_accumulation_uses_packed_launches():
+    data = synth.SynthDatasplit('tiny', seed=9)
+    args = synth.make_args(data.max_k, cuda=True, batch_size=2, epochs=5, lr=5e-2, print_every=0, batch_accumulation=3)
+    model = SemiMarkovModel.from_args(args, data)
+    log = []
+    model.fit(data, use_labels=False, callback_fn=lambda ep, st: log.append(st['train_loss']))
+    assert len(log) == 5 and all(np.isfinite(log)) and log[-1] < log[0] - 0.5, log

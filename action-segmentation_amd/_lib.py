@@ -18,7 +18,10 @@ SYMBOLS = [
 class SmmShape(ctypes.Structure):
     _fields_ = [("b", ctypes.c_int32), ("d", ctypes.c_int32), ("n_groups", ctypes.c_int32),
                 ("c_max", ctypes.c_int32), ("k_rows", ctypes.c_int32), ("t_max", ctypes.c_int32),
-                ("total_frames", ctypes.c_int64)]
+                ("flags", ctypes.c_int32), ("total_frames", ctypes.c_int64)]
+
+
+SHAPE_NO_EOS = 1
 
 
 class SmmEvalShape(ctypes.Structure):

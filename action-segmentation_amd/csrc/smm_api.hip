@@ -268,8 +268,9 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         if (n_states[g] < 1 || n_states[g] > s->c_max) return SMM_ERR_ARG;
         c_need = std::max(c_need, n_states[g]);
     }
+    const bool no_eos = (s->flags & SMM_SHAPE_NO_EOS) != 0;
     for (int i = 0; i < s->b; ++i)
-        if (lengths[i] < 1 || lengths[i] > s->t_max) return SMM_ERR_ARG;
+        if (lengths[i] < (no_eos ? 2 : 1) || lengths[i] > s->t_max) return SMM_ERR_ARG;
     const SmmPlan p = make_plan(s, lengths);
     if (ws_bytes < p.total) return SMM_ERR_WORKSPACE;
 
@@ -289,7 +290,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         if (k < 1 || k > s->k_rows) return SMM_ERR_ARG;
         hv[i].frame_off = frame_off[i];
         hv[i].hist_off = (int64_t)hoff;
-        hv[i].T = (int32_t)t;
+        hv[i].T = (int32_t)t;                      // (no EOS: the DP kernels take T - 1, the emission kernel every frame)
         hv[i].group = g;
         hv[i].kp = k;
         hv[i].nfol = 0;
@@ -349,18 +350,24 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
     SmmDpArgs a{};
     a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
-    a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = endpen; a.class_map = class_map;
+    const bool no_eos = (s->flags & SMM_SHAPE_NO_EOS) != 0;
+    a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = no_eos ? nullptr : endpen; a.class_map = class_map;
     a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
     a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
     {
-        const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling aid, see SmmDpArgs::flags
+        const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling / test aid, see SmmDpArgs::flags
         a.flags = dbg ? std::atoi(dbg) : 0;
     }
+    if (no_eos) a.flags |= 8;
     a.n_pairs = st.n_pairs;
     a.pair_flags = st.pair_flags;
     if (st.pairs_cover_big) a.flags |= 4;
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
+    // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant
+    // may hold the CUs): a gang that gives up flags itself and its video is decoded again here, on one CU, behind the
+    // main kernel on the same stream.  Without a time-out these launches cost two empty grids.
+    if (st.n_pairs > 0 && !(a.flags & 1)) smm_launch_viterbi_recovery(a, st.c_need, stream);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }
@@ -449,6 +456,7 @@ extern "C" int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host,
     a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = endpen;
     a.hist = st.hist; a.err = st.err;
     a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
+    if (shape->flags & SMM_SHAPE_NO_EOS) { a.flags |= 8; a.endpen = nullptr; }
     rc = smm_launch_logz(a, logz, ring_regs(st.kp_max), st.c_need, hs);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());
@@ -478,6 +486,8 @@ extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_h
     a.hist = st.hist; a.err = st.err;
     a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
     a.flags = 2;                               // time-reversed run -> backward messages in the second history half
+    const bool no_eos = (shape->flags & SMM_SHAPE_NO_EOS) != 0;
+    if (no_eos) { a.flags |= 8; a.endpen = nullptr; }
     rc = smm_launch_logz(a, logz_b, ring_regs(st.kp_max), st.c_need, hs);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipMemsetAsync(g_trans, 0, sizeof(double) * g * cm * cm, hs));
@@ -485,7 +495,7 @@ extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_h
     SMM_HIP(hipMemsetAsync(g_len, 0, sizeof(double) * g * shape->k_rows * cm, hs));
     SMM_HIP(hipMemsetAsync(g_elp, 0, sizeof(double) * (size_t)shape->total_frames * cm, hs));
     SmmBwdArgs m{st.videos, st.n_states, trans, len_scores, st.hist, logz, grad_logz, g_elp, g_trans, g_init, g_len,
-                 shape->c_max, shape->k_rows, shape->b};
+                 shape->c_max, shape->k_rows, shape->b, elp, no_eos ? 1 : 0};
     smm_launch_marginals(m, shape->t_max, st.kp_max, hs);
     SMM_HIP(hipGetLastError());
     return SMM_OK;

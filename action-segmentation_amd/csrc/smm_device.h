@@ -32,12 +32,14 @@ struct SmmDpArgs {
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
-    int32_t *err;              // [1] sticky error flag (NaN in the inputs)
+    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] gangs that timed out, [2] gangs repaired
     int32_t c_max, k_rows, t_max, b;
     int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
-                               // backward; bit 2: every video with more than 21 states is in the paired prefix
+                               // backward; bit 2: every video with more than 21 states is in the paired prefix;
+                               // bit 3 (8): no EOS (add_eos=False; SmmVideo::T = frames - 1); bit 4 (16): recovery launch
+                               // behind a gang launch; bit 5 (32): test hook -- gang 0's followers never show up
     int32_t n_pairs;           // the first n_pairs entries of order[] run as leader / follower pairs (smm_viterbi.hip)
-    int32_t *pair_flags;       // [2 * n_pairs] progress counters, zero at launch
+    int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
 };
 
 // ---- 64-bit register helpers -------------------------------------------------------------------

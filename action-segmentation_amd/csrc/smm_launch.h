@@ -25,6 +25,8 @@ void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, int64_t tota
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
+// follow-up of a launch with gangs: decodes, on one CU each, the videos whose gang gave up (no-op kernels otherwise)
+void smm_launch_viterbi_recovery(const SmmDpArgs &a, int c_need, hipStream_t stream);
 // LogSemiring forward: logz[b]; same arguments as the Viterbi launch
 int smm_launch_logz(const SmmDpArgs &a, double *logz, int r, int c_need, hipStream_t stream);
 
@@ -41,6 +43,8 @@ struct SmmBwdArgs {
     double *g_init;            // [g][c_max]
     double *g_len;             // [g][k_rows][c_max]
     int32_t c_max, k_rows, b;
+    const double *elp;         // [total_frames][c_max]   (no_eos only: the closing label's emission)
+    int32_t no_eos;            // add_eos=False (smmdp.h: SMM_SHAPE_NO_EOS)
 };
 void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStream_t stream);
 void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream);

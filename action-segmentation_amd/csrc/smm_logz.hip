@@ -148,7 +148,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
     const int vid = a.order[blockIdx.x];
     const SmmVideo mv = a.videos[vid];
-    const int T = mv.T;
+    const int T = mv.T - ((a.flags & 8) ? 1 : 0);   // no EOS: the DP covers the frames before the last one (smmdp.h)
     const int g = mv.group;
     const int C = a.n_states[g];
     const int cm = a.c_max;

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
 {
     const int vid = blockIdx.x;
     const SmmVideo mv = a.videos[vid];
-    const int T = mv.T, g = mv.group, cm = a.c_max;
+    const int T = mv.T - a.no_eos, g = mv.group, cm = a.c_max;
     const int C = a.n_states[g];
     const size_t blk = (size_t)cm * (T + 1);
     const double *F_cum = a.hist + mv.hist_off, *F_h = F_cum + blk, *F_g = F_h + blk;
@@ -82,6 +82,16 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
             a.g_elp[(size_t)(mv.frame_off + t) * cm + c] = up * run;
         }
     }
+    // (e) no EOS (add_eos=False): the closing transition into the label of frame T, which only emits:
+    //     P(last label = to) = exp( LSE_c(F_g[T][c] + trans[to][c]) + elp[T][to] - logZ ) goes to elp[T][to], and its
+    //     summands to trans[to][c].  (With EOS the closing weights are constants.)
+    if (a.no_eos && tid < C * C) {
+        const int to = tid / C, from = tid - to * C;
+        const double e_last = a.elp[(size_t)(mv.frame_off + T) * cm + to];
+        const double p = up * exp(F_g[(size_t)T * cm + from] + trans[(size_t)to * cm + from] + e_last - lz);
+        atomicAdd(&a.g_trans[(size_t)g * cm * cm + (size_t)to * cm + from], p);
+        atomicAdd(&a.g_elp[(size_t)(mv.frame_off + T) * cm + to], p);
+    }
     // (c) d/d init
     if (tid < C)
         atomicAdd(&a.g_init[(size_t)g * cm + tid],
@@ -107,7 +117,7 @@ __global__ void __launch_bounds__(256) smm_glen_kernel(SmmBwdArgs a)
     const int cm = a.c_max;
     const int vid = blockIdx.z / cm, c = blockIdx.z - vid * cm;
     const SmmVideo mv = a.videos[vid];
-    const int T = mv.T, g = mv.group;
+    const int T = mv.T - a.no_eos, g = mv.group;
     if (c >= a.n_states[g]) return;
     const int k = 1 + blockIdx.x * 256 + threadIdx.x;
     const int s0 = blockIdx.y * SMM_GLEN_SCH;

@@ -248,18 +248,38 @@ __device__ __forceinline__ void smm_st_agent(double *p, double v)
 }
 
 // One lane waits until a progress counter reaches `need` (bounded).  `seen` caches the last value read: the partner
-// usually runs ahead, and a poll is a round trip to memory.  Returns false once the partner is given up on.
-__device__ __forceinline__ bool smm_wait_progress(const int32_t *ctr, int need, int &seen, int32_t *err, bool alive)
+// usually runs ahead, and a poll is a round trip to memory.  Returns false once the partner is given up on: the gang's
+// failure word (pair_flags[4 gang + 3]) is set, every later wait of this workgroup returns at once, the loops run to
+// their counted end, and the recovery launch that follows the kernel on the stream decodes the video again without a
+// gang (smm_api.hip: run_viterbi).
+//
+// Memory ordering.  The hand-off is the form MI355X_MICROARCH.md lists as valid without an acquire/release pair: every
+// exchanged byte is stored sc1 (smm_st_agent) and loaded sc1 into registers (smm_ld_agent), the storing wave drains
+// its stores (s_waitcnt vmcnt(0)) before the counter store, and the counter is an agent-scope atomic polled with sc1
+// loads.  The signal fences pin the COMPILER's order (relaxed atomics to different addresses may otherwise be moved
+// across the poll); they emit no instruction.
+__device__ __forceinline__ bool smm_wait_progress(const int32_t *ctr, int need, int &seen, int32_t *gang_fail, bool alive,
+                                                  int spin_limit)
 {
     if (!alive) return false;
     if (seen >= need) return true;
-    for (int spin = 0; spin < SMM_SPIN_LIMIT; ++spin) {
+    for (int spin = 0; spin < spin_limit; ++spin) {
         seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >= need) return true;
+        if (seen >= need) {
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);       // data loads stay behind the poll that matched
+            return true;
+        }
         __builtin_amdgcn_s_sleep(8);
     }
-    atomicExch(err, 2);
+    __hip_atomic_store(gang_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
+}
+
+// publish a progress counter: the caller has drained its stores (s_waitcnt vmcnt(0)) just before
+__device__ __forceinline__ void smm_publish(int32_t *ctr, int value)
+{
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);               // the counter store stays behind the data stores and their wait
+    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Follower workgroup of a pair: 8 pusher waves, wave w owns states cl + w and cl + w + 8 (long range only).
@@ -278,7 +298,8 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
     const double *len = a.len + (size_t)g * a.k_rows * cm;
     double *hh = a.hist + mv.hist_off + (size_t)cm * (T + 1);
     double *along = a.hist + mv.hist_off + (size_t)3 * cm * (T + 1);
-    int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1 + fidx;
+    int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1 + fidx, *gang_fail = prog_h + 3;
+    const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
     __shared__ __attribute__((aligned(16))) double f_h[2][BF][SMM_MAX_STATES_DEV];
     __shared__ __attribute__((aligned(16))) double f_a[2][BF][SMM_MAX_STATES_DEV];
 
@@ -287,7 +308,7 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
     for (int i = threadIdx.x; i < n0 * nf; i += blockDim.x) smm_st_agent(&along[(size_t)(1 + i / nf) * cm + cl + i % nf], SMM_NEG_INF);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(prog_a, n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) smm_publish(prog_a, n0);
     if (T <= SMM_KS) return;
 
     double A[2][R], L[2][R];
@@ -316,7 +337,7 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
         const int s0 = q * BF;
         int ok = 1;
         if (lane == 0) {
-            alive = smm_wait_progress(prog_h, (s0 + BF - 1 < T - 1) ? s0 + BF - 1 : T - 1, seen, a.err, alive);
+            alive = smm_wait_progress(prog_h, (s0 + BF - 1 < T - 1) ? s0 + BF - 1 : T - 1, seen, gang_fail, alive, spin_limit);
             ok = alive;
         }
         ok = __builtin_amdgcn_readfirstlane(ok);
@@ -358,7 +379,7 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
         if (w == 0 && q + 1 < QF) stage(q + 1);
         if (w == 4) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                // the previous block's rows are out
-            if (q >= 1 && lane == 0) __hip_atomic_store(prog_a, s0 - BF + KL + BF - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q >= 1 && lane == 0) smm_publish(prog_a, s0 - BF + KL + BF - 1);
 #pragma unroll
             for (int x = 0; x < NX; ++x) {
                 const int n = s0 + KL + xr[x];
@@ -369,7 +390,7 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
     }
     if (w == 4) {
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (lane == 0) __hip_atomic_store(prog_a, (QF - 1) * BF + KL + BF - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) smm_publish(prog_a, (QF - 1) * BF + KL + BF - 1);
     }
 }
 
@@ -399,12 +420,27 @@ smm_viterbi_kernel(SmmDpArgs a)
         else vsel = blockIdx.x - 2 * a.n_pairs;
     }
     const int pair = blockIdx.x / 3;
+    const bool recover = !PAIR && (a.flags & 16);
+    if (recover) {
+        // RECOVERY launch (follows a gang launch on the stream; grid = number of gangs): workgroup p decodes the video of
+        // gang p again on ONE CU if that gang gave up waiting for a partner, and only if this configuration holds the
+        // video's states (the host launches the 8-wave and the 12-wave configuration; exactly one fits).
+        if (__hip_atomic_load(a.pair_flags + 4 * blockIdx.x + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    }
     const int vid = a.order[vsel];
-    const SmmVideo mv = a.videos[vid];
+    SmmVideo mv = a.videos[vid];
+    if (a.flags & 8) mv.T -= 1;               // no EOS: the DP covers the frames before the last one (smmdp.h)
     const int T = mv.T;
     const int g = mv.group;
     const int C = a.n_states[g];
+    if (recover) {
+        constexpr int cap = (NW - 1) * SPW + CP;
+        const bool mine = (NW == 8) ? C <= cap : (C > 21 && C <= cap);
+        if (NW == 8 && threadIdx.x == 0) atomicAdd(a.err + 1, 1);          // gangs that timed out
+        if (!mine) return;
+    }
     if (PAIR && role >= 2) {
+        if ((a.flags & 32) && pair == 0) return;                           // (test hook: gang 0's followers never show up)
         if (T > 0) smm_follower(a, mv, C, pair, role - 2);
         return;
     }
@@ -612,6 +648,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         }
         double *along = hgam + (size_t)cm * (T + 1);                       // fourth history array: A'_long rows of the follower
         int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1;  // [1], [2]: follower 0, follower 1
+        int32_t *gang_fail = prog_h + 3;
+        const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
         const bool two = mv.nfol == 2;
         const int64_t e_last = (int64_t)T * cm - 1, a_last = (int64_t)(T + 1) * cm - 1;
         // Movers: every wave waits only for what it issued TWO blocks ago (nothing younger of its own is in flight),
@@ -668,8 +706,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                     // fetch block j+3: elp rows, and the follower's A' rows once it has published them
                     if (lane == 0) {
                         const int need = ((j + 4) * B < T) ? (j + 4) * B : T;
-                        alive = smm_wait_progress(prog_a, need, seen, a.err, alive);
-                        if (two) alive = smm_wait_progress(prog_a + 1, need, seen1, a.err, alive);
+                        alive = smm_wait_progress(prog_a, need, seen, gang_fail, alive, spin_limit);
+                        if (two) alive = smm_wait_progress(prog_a + 1, need, seen1, gang_fail, alive, spin_limit);
                     }
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
@@ -680,8 +718,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     }
                 } else if (stpar == (jj & 1)) {
                     __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (j >= 3 && lane == 0)
-                        __hip_atomic_store(prog_h, (j - 2) * B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (j >= 3 && lane == 0) smm_publish(prog_h, (j - 2) * B);
                     if (j >= 1) {
                         store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
                         store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
@@ -810,23 +847,27 @@ smm_viterbi_kernel(SmmDpArgs a)
     // sh_gam holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
     if (PAIR && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
-        __hip_atomic_store(a.pair_flags + 4 * pair, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        smm_publish(a.pair_flags + 4 * pair, T);
+    const bool no_eos = (a.flags & 8) != 0;    // add_eos=False: T counts the frames before the last one (see smmdp.h)
     if (w == 0) {
         double f = SMM_NEG_INF;
-        if (lane <= C) {
+        const int last = no_eos ? C - 1 : C;   // candidates: the real labels, and EOS unless there is none
+        if (lane <= last) {
             for (int c = 0; c < C; ++c) {
                 const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c];
                 f = fmax(f, sh_gam[c] + wgt);
             }
-            if (lane < C) f = f + SMM_BIG_NEG;
+            if (no_eos) f = f + elp[(size_t)T * cm + lane];   // the closing label only emits frame T
+            else if (lane < C) f = f + SMM_BIG_NEG;
         }
-        int kk = 0, cc = (lane <= C) ? lane : 0x7fffffff;
-        if (lane > C) f = SMM_NEG_INF;
+        int kk = 0, cc = (lane <= last) ? lane : 0x7fffffff;
+        if (lane > last) f = SMM_NEG_INF;
         smm_wave_best3(f, kk, cc);
         if (lane == 0) {
             sh_c = cc;
             if (a.best) a.best[vid] = f;
             if (spans) spans[T] = cmap ? cmap[cc] : cc;
+            if (no_eos && labels) labels[T] = cmap ? cmap[cc] : cc;
         }
     }
     __threadfence_block();
@@ -834,6 +875,11 @@ smm_viterbi_kernel(SmmDpArgs a)
 
     // -------------------------------------------------------------------------------- back-trace
     if (a.flags & 1) return;
+    if (PAIR && lead) {
+        // a gang that gave up (this workgroup or a follower) has garbage in its lattice: leave the outputs to the recovery
+        // launch.  (A follower only ever gives up when this leader was not making progress, i.e. before this point.)
+        if (__hip_atomic_load(a.pair_flags + 4 * pair + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    }
     // At a span start (n, to) the predecessor is the FIRST (k ascending, then from ascending) whose
     //   (cumE[n][from] + (h[n-k][from] + len[k][from])) + w(to, from)  equals the maximum.
     // Adding is monotone, so a hit needs gamma[n][from] + w(to, from) == maximum: phase A (every wave, redundantly,
@@ -908,7 +954,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         pp[40] = bt_a; pp[41] = bt_b; pp[42] = bt_c; pp[43] = (unsigned long long)nseg;
     }
 #endif
-    if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg;
+    if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg + (no_eos ? 1 : 0);
+    if (recover && threadIdx.x == 0) atomicAdd(a.err + 2, 1);                   // repaired
 #ifdef SMM_PROFILE_END   // diagnostic build: when did each video's (leader) workgroup finish?  (100 MHz wall clock into best[])
     if (a.best && threadIdx.x == 0) a.best[vid] = (double)wall_clock64();
 #endif
@@ -995,6 +1042,20 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
               launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
+}
+
+// Recovery launches behind a gang launch (see the kernel: `recover`): one workgroup per gang, which returns at once
+// unless its gang's failure word is set.  1024-slot rings only (gangs exist for nothing else).
+void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t stream)
+{
+    SmmDpArgs a = a0;
+    a.flags = (a0.flags & ~4) | 16;
+    const dim3 grid(a0.n_pairs);
+    a.n_pairs = 0;
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 8, 0, SMM_B>), grid, dim3(512), 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, SMM_B>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 16, 0, SMM_B>), grid, dim3(512), 0, stream, a);
+    if (c_need > 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), grid, dim3(12 * 64), 0, stream, a);
 }
 
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)

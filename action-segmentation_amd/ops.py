@@ -20,10 +20,11 @@ class Batch:
     group          parameter group per video (default 0)
     kp             per-video min(K, Tmax of its reference batch) (reference semimarkov_modules.py:450-452)
     n_states       states per group
+    no_eos         add_eos=False of the reference: no EOS label, the last frame's label only emits
     """
 
     def __init__(self, lengths, n_states, k_rows, c_max=None, frame_offset=None, group=None, kp=None, d=0,
-                 t_max=None, total_frames=None):
+                 t_max=None, total_frames=None, no_eos=False):
         self.lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
         self.b = int(self.lengths.shape[0])
         self.n_states = np.ascontiguousarray(np.asarray(n_states, dtype=np.int32).reshape(-1))
@@ -40,7 +41,9 @@ class Batch:
             total_frames = int((self.frame_offset + self.lengths).max())
         self.total_frames = int(total_frames)
         self.d = int(d)
-        self.shape = SmmShape(self.b, self.d, self.n_groups, self.c_max, self.k_rows, self.t_max, self.total_frames)
+        self.no_eos = bool(no_eos)     # add_eos=False of the reference (include/smmdp.h: SMM_SHAPE_NO_EOS)
+        self.shape = SmmShape(self.b, self.d, self.n_groups, self.c_max, self.k_rows, self.t_max,
+                              _lib.SHAPE_NO_EOS if self.no_eos else 0, self.total_frames)
 
     def workspace_bytes(self):
         n = _lib.load().smm_workspace_bytes(ctypes.byref(self.shape), self.lengths.ctypes.data)
@@ -234,7 +237,7 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 4].view(torch.int32)
+    return ws[off:off + 12].view(torch.int32)      # [error, gangs timed out, gangs repaired]
 
 
 def error_flag(batch, out=None, ws=None):
@@ -242,11 +245,19 @@ def error_flag(batch, out=None, ws=None):
     decode of that video stopped early.  ``out``: the dict the launch returned (its ``_err`` entry views the workspace
     that launch wrote to -- the per-stream cache may have been regrown or switched since); without it the current
     (device, stream) workspace is read, which is only right directly after the launch."""
+    return error_words(batch, out, ws)[0]
+
+
+gang_timeouts_repaired = 0     # how often a decode had gangs repaired by the recovery launch (diagnostic counter)
+
+
+def error_words(batch, out=None, ws=None):
+    """[error word, gangs that timed out, gangs repaired by the recovery launch] of a decode (synchronises)."""
     if out is not None and out.get('_err') is not None:
-        return int(out['_err'].item())
+        return [int(v) for v in out['_err'].tolist()]
     if ws is None:
         ws = workspace(batch.workspace_bytes(), torch.device('cuda', torch.cuda.current_device()))
-    return int(_err_view(batch, ws).item())
+    return [int(v) for v in _err_view(batch, ws).tolist()]
 
 
 def check_decoded(batch, out=None):
@@ -254,10 +265,12 @@ def check_decoded(batch, out=None):
     kernel flagged the run.  1: a NaN / inf - inf reached the DP; 2: a two-CU gang (smm_viterbi.hip, PAIR mode) gave
     up waiting for its partner workgroup -- the outputs are invalid (the library relaunches such a batch without
     gangs by itself, so this only surfaces when that was switched off)."""
-    flag = error_flag(batch, out)
-    if flag == 2:
-        raise _lib.SmmError("libsmmdp: a leader / follower workgroup pair timed out waiting for its partner (the two "
-                            "were not co-resident on the GPU); rerun with SMM_PAIRS=0")
+    global gang_timeouts_repaired
+    flag, timed_out, repaired = error_words(batch, out)
+    gang_timeouts_repaired += repaired
+    if timed_out > repaired:
+        raise _lib.SmmError("libsmmdp: %d gang(s) of workgroups timed out waiting for a partner and %d were repaired by "
+                            "the recovery launch; outputs invalid (SMM_PAIRS=0 disables gangs)" % (timed_out, repaired))
     if flag != 0:
         raise _lib.SmmError("libsmmdp: NaN (or inf - inf) in the DP inputs; decode stopped early (error word %d)" % flag)
 

@@ -432,15 +432,14 @@ class SemiMarkovModule(nn.Module):
         or None.  Returns pred_spans: CPU int64 b x (Tmax+1) -- global class id at every span start, -1 for a
         continuation, ``n_classes`` (EOS) at position lengths[i], -1 after it [, elp b x Tmax x C fp32 on device].
         """
-        if not add_eos:
-            raise NotImplementedError("the HIP path decodes with the EOS augmentation only (add_eos=True), "
-                                      "which is what SemiMarkovModel.predict / fit use")
         self._require_device(features, 'viterbi')
         valid_classes = self._check_valid_classes(valid_classes_per_instance)
         self.set_z(features, lengths, use_mean=use_mean_z)
         out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                           want_elp=return_elp, want_labels=False)
+                           want_elp=return_elp, want_labels=False, no_eos=not add_eos)
         pred_spans = out['spans'].cpu()
+        if not add_eos:
+            pred_spans = pred_spans[:, :features.size(1)].contiguous()   # b x Tmax: no EOS position (reference :679)
         ops.check_decoded(out['_batch'], out)
         if return_elp:
             b, tmax = features.shape[:2]
@@ -449,21 +448,28 @@ class SemiMarkovModule(nn.Module):
 
     viterbi_decode = viterbi   # name used by BASELINE.json's north star
 
+    @staticmethod
+    def _check_no_eos_lengths(lengths_host, no_eos):
+        if no_eos and int(lengths_host.min()) < 2:
+            raise ValueError("add_eos=False needs at least two frames per video (a one-frame video has no edge at all "
+                             "in the reference's lattice)")
+
     def _decode(self, features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                want_elp=False, want_labels=True, want_spans=True):
+                want_elp=False, want_labels=True, want_spans=True, no_eos=False):
         b, tmax, d = features.shape
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
         assert int(lengths_host.max()) == tmax, "one instance must span the padded length (padding_colate)"
+        self._check_no_eos_lengths(lengths_host, no_eos)
         tab = self._decode_tables(valid_classes, dev)
         c = tab['init'].numel()
         k_rows = tab['len'].size(0)
-        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
+        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos)
         x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
         cons = None
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
-        endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+        endpen = None if no_eos else self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
         out = ops.decode(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
                          tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
                          tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
@@ -539,9 +545,11 @@ class SemiMarkovModule(nn.Module):
 
     # ------------------------------------------------------------------ likelihoods (reference :597-658)
     def gold_score(self, features, lengths, valid_classes, spans, additional_allowed_ends_per_instance=None,
-                   constraints=None):
+                   constraints=None, no_eos=False):
         """Joint score of given span encodings = sum(potentials * to_parts(spans)) of the reference (:641-655),
-        evaluated on the factors (differentiable torch ops, O(T*C); no dense tensor).  spans: b x Tmax global ids."""
+        evaluated on the factors (differentiable torch ops, O(T*C); no dense tensor).  spans: b x Tmax global ids.
+        ``no_eos`` (add_eos=False): ``to_parts`` has an edge per span START after the first, so the last span is not
+        scored, except that its label's emission of the last frame counts when it starts there (modules:519-521)."""
         tab = self.factor_tables(valid_classes, features.device)
         f64 = torch.float64
         x = features.to(f64)
@@ -564,20 +572,24 @@ class SemiMarkovModule(nn.Module):
             assert starts and starts[0] == 0, "a span encoding starts with a label"
             bounds = starts + [t]
             labs = [local[int(row[s])] for s in starts]
-            total = tab['init'][labs[0]]
+            total = tab['init'][labs[0]] if (not no_eos or len(labs) > 1) else tab['init'][labs[0]] * 0
             for j, (s0, s1) in enumerate(zip(bounds[:-1], bounds[1:])):
+                if no_eos and j + 1 == len(labs):
+                    if s0 == t - 1:
+                        total = total + elp[i, t - 1, labs[j]]
+                    break
                 kk = s1 - s0
                 assert 1 <= kk <= kp - 1, "span longer than the model's max span length"
                 total = total + tab['len'][kk, labs[j]] + (cum[i, s1, labs[j]] - cum[i, s0, labs[j]])
                 if j + 1 < len(labs):
                     total = total + tab['trans'][labs[j + 1], labs[j]]
-            if ends is not None and labs[-1] not in ends[i]:
+            if not no_eos and ends is not None and labs[-1] not in ends[i]:
                 total = total + BIG_NEG
             out.append(total)
         return torch.stack(out)
 
     def log_partition(self, features, lengths, valid_classes, additional_allowed_ends_per_instance=None,
-                      constraints=None):
+                      constraints=None, no_eos=False):
         """log Z per instance on the device, differentiable w.r.t. the module's parameters
         (smm_emission_f64 + smm_logz_f64 forward, smm_logz_bwd_f64 backward)."""
         self._require_device(features, 'log_partition')
@@ -585,14 +597,16 @@ class SemiMarkovModule(nn.Module):
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
         assert int(lengths_host.max()) == tmax
+        self._check_no_eos_lengths(lengths_host, no_eos)
         tab = self.factor_tables(valid_classes, dev)
         c = tab['init'].numel()
-        batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d)
+        batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d,
+                          no_eos=no_eos)
         x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
         cons = None
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
-        endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+        endpen = None if no_eos else self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
         runs = [(0, i * tmax, i * tmax + int(t)) for i, t in enumerate(lengths_host)]    # (padding frames carry no gradient)
         return _LogPartition.apply(batch, runs, x, cons, endpen, tab['w'].unsqueeze(0).contiguous(),
                                    tab['cst'].unsqueeze(0).contiguous(), tab['inv_var'].contiguous(),
@@ -635,16 +649,17 @@ class SemiMarkovModule(nn.Module):
         score - log Z.  spans=None: the log-partition (marginal likelihood) from the HIP forward kernel; its gradient
         (posterior marginals chained into the parameters) comes from the HIP backward kernels.
         """
-        if not add_eos:
-            raise NotImplementedError("the HIP path works with the EOS augmentation only (add_eos=True)")
+        no_eos = not add_eos
         valid_classes = self._check_valid_classes(valid_classes_per_instance)
         self.set_z(features, lengths, use_mean=use_mean_z)
         log_det = torch.zeros(features.size(0), device=features.device)
         if spans is not None:
-            ll = self.gold_score(features, lengths, valid_classes, spans, additional_allowed_ends_per_instance, constraints)
+            ll = self.gold_score(features, lengths, valid_classes, spans, additional_allowed_ends_per_instance, constraints,
+                                 no_eos=no_eos)
             if getattr(self.args, 'sm_train_discriminatively', False):
                 ll = ll - self.log_partition(features, lengths, valid_classes, additional_allowed_ends_per_instance,
-                                             constraints)
+                                             constraints, no_eos=no_eos)
         else:
-            ll = self.log_partition(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints)
+            ll = self.log_partition(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
+                                    no_eos=no_eos)
         return ll.mean(), log_det.mean()

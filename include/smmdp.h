@@ -66,8 +66,15 @@ typedef struct smm_shape {
     int32_t c_max;     /* table column stride, >= every n_states[g], <= SMM_MAX_STATES */
     int32_t k_rows;    /* rows of the length table (= --sm_max_span_length, or 2 for the K==1 HMM table) */
     int32_t t_max;     /* max lengths[i] */
+    int32_t flags;     /* SMM_SHAPE_* bits, 0 = the reference's default (add_eos=True) */
     int64_t total_frames; /* extent of the packed frame axis (>= every frame_offset[i] + lengths[i]) */
 } smm_shape;
+
+/* add_eos=False of the reference (semimarkov_modules.py:494-505, :660): no EOS label is appended.  The DP positions
+ * are the frames themselves: segments cover frames 0 .. T-2 and the video closes with a transition into the label of
+ * frame T-1, which contributes its emission only (no length score); end penalties do not apply (endpen is ignored).
+ * Viterbi: spans[i][T-1] holds that label and no EOS id is written; log Z and its gradient likewise.  lengths[i] >= 2. */
+#define SMM_SHAPE_NO_EOS 1
 
 const char *smm_strerror(int status);
 int smm_last_hip_error(void);
@@ -81,9 +88,13 @@ int smm_device_count(void);
 size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 
 /* Byte offset, inside the workspace, of the int32 error word the kernels set.  1: a NaN / inf-inf reached the DP of
- * some video and its decode stopped early.  2: a video decoded by a pair of workgroups on two CUs (long videos at
- * K > 512; environment SMM_PAIRS=0 disables pairing) gave up waiting for its partner workgroup: outputs invalid.
- * It is cleared at the start of every call.  Returns 0 on invalid shape. */
+ * some video and its decode stopped early.  (Gangs -- videos decoded by two or three workgroups on as many CUs, long
+ * videos at K > 512; environment SMM_PAIRS=0 disables them -- that give up waiting for a partner workgroup are
+ * counted in the next word, see below.)
+ * It is cleared at the start of every call.  Returns 0 on invalid shape.
+ * The two int32 words behind it count gang time-outs and gang time-outs REPAIRED: a video whose gang gave up is decoded
+ * again without a gang by a follow-up kernel of the same call (same stream, no host involvement), so the outputs are
+ * invalid only if word[1] > word[2]. */
 size_t smm_error_word_offset(const smm_shape *shape);
 
 /*

@@ -51,8 +51,9 @@ def emission(x, lengths, mu, inv_var, lognorm, cons=None):
     return elp
 
 
-def viterbi(elp, lengths, trans, init, len_scores, endpen=None):
-    """-> (spans b x (Tmax+1) int64 local ids with EOS = C, v b).  len_scores: K x C, clipped to Tmax rows here."""
+def viterbi(elp, lengths, trans, init, len_scores, endpen=None, no_eos=False):
+    """-> (spans b x (Tmax+1) int64 local ids with EOS = C, v b).  len_scores: K x C, clipped to Tmax rows here.
+    ``no_eos``: add_eos=False of the reference (no EOS label; the last frame's label only emits)."""
     elp = _f64(elp)
     b, tmax, c = elp.shape
     len_scores = _f64(len_scores)[:tmax]
@@ -61,10 +62,10 @@ def viterbi(elp, lengths, trans, init, len_scores, endpen=None):
     trans, init, endpen = _f64(trans), _f64(init), _f64(endpen)
     spans = np.empty((b, tmax + 1), np.int64)
     v = np.empty(b, np.float64)
-    rc = lib().smm_oracle_viterbi(_p(elp, ctypes.c_double), _p(lengths, ctypes.c_int64), _p(trans, ctypes.c_double),
-                                  _p(init, ctypes.c_double), _p(len_scores, ctypes.c_double),
-                                  _p(endpen, ctypes.c_double), b, tmax, c, kp, _p(spans, ctypes.c_int64),
-                                  _p(v, ctypes.c_double))
+    rc = lib().smm_oracle_viterbi_ex(_p(elp, ctypes.c_double), _p(lengths, ctypes.c_int64), _p(trans, ctypes.c_double),
+                                     _p(init, ctypes.c_double), _p(len_scores, ctypes.c_double),
+                                     _p(endpen, ctypes.c_double), b, tmax, c, kp, int(bool(no_eos)),
+                                     _p(spans, ctypes.c_int64), _p(v, ctypes.c_double))
     assert rc == 0, rc
     return spans, v
 

@@ -72,14 +72,17 @@ void smm_oracle_emission(const float *x, const int64_t *lengths, const double *m
  * spans out: b x (tmax+1) int64, local ids, EOS = c, -1 = continuation / beyond the end.
  * v out: b.  Returns 0, or -1 on allocation failure.
  */
-int smm_oracle_viterbi(const double *elp, const int64_t *lengths, const double *trans, const double *init,
-                       const double *len, const double *endpen, int b, int tmax, int c, int kp,
-                       int64_t *spans, double *v)
+/* no_eos != 0: add_eos=False of the reference (semimarkov_modules.py:494-505, positions = frames): the segments cover
+ * frames 0 .. T-2 and the video closes with a transition into the label of frame T-1, which only emits:
+ *   fin[to] = max_c ( gamma[T-1][c] + trans[to][c] ) + elp[T-1][to],   no EOS label, no end penalties. */
+int smm_oracle_viterbi_ex(const double *elp, const int64_t *lengths, const double *trans, const double *init,
+                          const double *len, const double *endpen, int b, int tmax, int c, int kp, int no_eos,
+                          int64_t *spans, double *v)
 {
     int rc = 0;
     #pragma omp parallel for schedule(dynamic)
     for (int i = 0; i < b; ++i) {
-        const int t_i = (int)lengths[i];
+        const int t_i = (int)lengths[i] - (no_eos ? 1 : 0);
         const double *e = elp + (size_t)i * tmax * c;
         int64_t *sp = spans + (size_t)i * (tmax + 1);
         for (int n = 0; n <= tmax; ++n) sp[n] = -1;
@@ -108,13 +111,14 @@ int smm_oracle_viterbi(const double *elp, const int64_t *lengths, const double *
         /* last position: first maximal entry of [fin[0..c-1], fin[EOS]] */
         int best_to = -1;
         double best = -INFINITY;
-        for (int to = 0; to <= c; ++to) {
+        for (int to = 0; to <= c - (no_eos ? 1 : 0); ++to) {
             double f = -INFINITY;
             for (int j = 0; j < c; ++j) {
                 double w = (to == c) ? (endpen ? endpen[(size_t)i * c + j] : 0.0) : trans[(size_t)to * c + j];
                 f = dmax(f, gam[j] + w);
             }
-            if (to < c) f = f + SMM_BIG_NEG;
+            if (no_eos) f = f + e[(size_t)t_i * c + to];
+            else if (to < c) f = f + SMM_BIG_NEG;
             if (best_to < 0 || f > best) { best = f; best_to = to; }
         }
         v[i] = best;
@@ -145,6 +149,13 @@ int smm_oracle_viterbi(const double *elp, const int64_t *lengths, const double *
         free(cum); free(h); free(gam);
     }
     return rc;
+}
+
+int smm_oracle_viterbi(const double *elp, const int64_t *lengths, const double *trans, const double *init,
+                       const double *len, const double *endpen, int b, int tmax, int c, int kp,
+                       int64_t *spans, double *v)
+{
+    return smm_oracle_viterbi_ex(elp, lengths, trans, init, len, endpen, b, tmax, c, kp, 0, spans, v);
 }
 
 /* ---------------------------------------------------------------- log-partition + posteriors */

@@ -140,3 +140,41 @@ def test_log_likelihood_gradients_match_dense_autograd(golden, case):
         got = getattr(m, n).grad.detach().cpu().double().numpy()
         ref = leaves[n].grad.numpy()
         np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()), err_msg=n)
+
+
+def test_no_eos_viterbi_and_log_likelihood_match_reference_path(golden):
+    """add_eos=False through the module API (reference :597-696 with add_eos=False) on the reference-generated 'no_eos'
+    golden case: Viterbi spans / labels and log Z + parameter gradients against the dense reference path in fp64."""
+    case = 'no_eos'
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    b, tmax = feats.shape[:2]
+    vc = None if valid is None else [valid for _ in range(b)]
+    spans = m.viterbi(feats.float().to(dev), lengths.to(dev), vc, add_eos=False)
+    assert tuple(spans.shape) == (b, tmax) and (spans != m.n_classes).all()
+    r = O.viterbi_full(p, feats, lengths, valid, False, None, cons)
+    ref = r['spans'].numpy()[:, :tmax]
+    for i, t in enumerate(lengths.tolist()):
+        np.testing.assert_array_equal(O.spans_to_labels(spans.numpy()[i:i + 1, :t]), O.spans_to_labels(ref[i:i + 1, :t]))
+    # log Z and its gradient
+    m.zero_grad()
+    ll, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=None, add_eos=False)
+    ll.backward()
+    names = ['poisson_log_rates', 'gaussian_means', 'transition_logits', 'init_logits']
+    q = p.to(torch.float64)
+    leaves = {n: getattr(q, n).clone().requires_grad_(True) for n in names}
+    for n, v in leaves.items():
+        setattr(q, n, v)
+    scores, _ = O.score_features(q, feats, lengths, valid, False, None, cons)
+    z, _ = O.semimarkov_dp(scores, lengths, O.LogSemiring)
+    z.mean().backward()
+    assert abs(ll.item() - z.mean().item()) <= 1e-6 * abs(z.mean().item()) + 1e-4
+    for n in names:
+        got = getattr(m, n).grad.detach().cpu().double().numpy()
+        refg = leaves[n].grad.numpy()
+        np.testing.assert_allclose(got, refg, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(refg).max()), err_msg=n)
+    # gold-span score of the Viterbi path (to_parts has no edge for the last span: reference :641-655)
+    js, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=r['spans'][:, :tmax].to(dev), add_eos=False)
+    parts = O.to_parts(r['spans'][:, :tmax], scores.shape[-1], scores.shape[2], lengths)
+    np.testing.assert_allclose(js.item(), (scores * parts).sum(dim=(1, 2, 3, 4)).mean().item(), rtol=1e-9, atol=1e-6)

@@ -435,3 +435,77 @@ def test_nan_input_sets_error_word_and_terminates():
     ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
     torch.cuda.synchronize()
     assert ops.error_flag(batch) == 0
+
+
+# ---------------------------------------------------------------------------------------------------- add_eos=False
+NO_EOS_SHAPES = [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (2, 130, 16, 64), (2, 300, 17, 130), (1, 1300, 23, 600),
+                 (2, 1030, 21, 1024), (2, 2, 3, 4), (3, 9, 2, 20)]
+
+
+@pytest.mark.parametrize('shape', NO_EOS_SHAPES)
+@pytest.mark.parametrize('integer', [False, True])
+def test_viterbi_no_eos_bit_exact(shape, integer):
+    """add_eos=False (reference semimarkov_modules.py:494-505, :660): no EOS label; the label of the last frame closes the
+    video with its emission only.  Bit-exact against the C twin (which is pinned to the dense no-EOS potentials on the
+    CPU: tests/test_oracle_factored.py)."""
+    b, tmax, c, k = shape
+    ops = _ops()
+    p = make_problem(hash(shape) % 1000 + 11, b, tmax, c, k, integer=integer, min_len=2)
+    p['lengths'] = np.maximum(p['lengths'], 2)
+    dev = torch.device('cuda:0')
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax, no_eos=True)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    out = ops.viterbi(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    torch.cuda.synchronize()
+    ops.check_decoded(batch, out)
+    spans, v = F.viterbi(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], None, no_eos=True)
+    np.testing.assert_array_equal(out['best'].cpu().numpy(), v)
+    np.testing.assert_array_equal(out['spans'].cpu().numpy(), spans)
+    labels = out['labels'].cpu().numpy().reshape(b, tmax)
+    for i, tt in enumerate(p['lengths']):
+        np.testing.assert_array_equal(labels[i, :tt], O.spans_to_labels(spans[i:i + 1, :tt])[0])
+        assert spans[i, tt - 1] >= 0 and (spans[i, tt:] == -1).all() and (spans[i] != c).all()
+        assert out['n_segs'][i].item() == (spans[i, :tt] != -1).sum()
+    # log Z without EOS: against the dense potentials of log_hsmm(add_eos=False) (small shapes)
+    if b * tmax * k * c * c <= 4e7:
+        z = ops.logz(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+        tt_ = lambda a: torch.tensor(a, dtype=torch.float64)
+        scores = O.log_hsmm(tt_(p['trans']), tt_(p['elp']), tt_(p['init']), tt_(p['lens']), torch.tensor(p['lengths']), add_eos=False)
+        ref, _ = O.semimarkov_dp(scores, torch.tensor(p['lengths']), O.LogSemiring)
+        np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-5)
+
+
+def test_no_eos_needs_two_frames():
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=dev)
+    from action_segmentation_amd._lib import SmmError
+    with pytest.raises(SmmError):
+        ops.viterbi(ops.Batch([1, 5], [3], 4, t_max=5, total_frames=10, no_eos=True), z(10, 3), z(1, 3, 3), z(1, 3), z(1, 4, 3))
+
+
+# ---------------------------------------------------------------------------------------------------- gang recovery
+@pytest.mark.parametrize('c', [13, 23])
+def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):
+    """A gang whose follower workgroups never become resident (test hook: SmmDpArgs::flags bit 5 -- gang 0's followers
+    return at once and the leader's waits are short) gives up, flags itself, and the recovery launch behind the main
+    kernel decodes its video again on one CU: bit-exact output, no exception, the repair is counted."""
+    ops = _ops()
+    shape = (4, 1500, c, 1024)
+    b, tmax, _, k = shape
+    p = make_problem(91 + c, b, tmax, c, k, ends=True)
+    monkeypatch.setenv('SMM_PAIRS', '3')
+    monkeypatch.setenv('SMM_DEBUG_FLAGS', '32')
+    before = ops.gang_timeouts_repaired
+    dev = torch.device('cuda:0')
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    out = ops.viterbi(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]),
+                      t(p['endpen']))
+    torch.cuda.synchronize()
+    words = ops.error_words(batch, out)
+    assert words[0] == 0 and words[1] >= 1 and words[1] == words[2], words
+    ops.check_decoded(batch, out)                                   # does not raise
+    assert ops.gang_timeouts_repaired == before + words[2]
+    spans, v = run_oracle(p)
+    check(p, {k_: v_.cpu().numpy() for k_, v_ in out.items() if k_ in ('best', 'spans', 'labels', 'n_segs')}, spans, v)

@@ -108,3 +108,54 @@ def test_logz_and_posteriors_match_dense_autograd(seed):
     np.testing.assert_allclose(fz, z.detach().numpy(), rtol=1e-12)
     for name, leaf in zip(('elp', 'trans', 'init', 'len'), leaves):
         np.testing.assert_allclose(g[name], leaf.grad.numpy(), rtol=1e-9, atol=1e-11, err_msg=name)
+
+
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('integer', [True, False])
+def test_no_eos_factored_matches_dense(seed, integer):
+    """add_eos=False (reference semimarkov_modules.py:494-505): the C twin's closed form of the last position against
+    the dense potentials of log_hsmm(add_eos=False) scanned by the restated pytorch-struct DP."""
+    b, tmax, c, k = 3, 9 + seed, 3 + seed % 2, 3 + seed % 4
+    elp, lengths, trans, init, lens, _ = random_problem(300 + seed, b, tmax, c, k, integer=integer)
+    lengths = lengths.clamp(min=2)
+    scores = O.log_hsmm(trans, elp, init, lens, lengths, add_eos=False)
+    v, segs = O.viterbi_backpointers(scores, lengths)
+    spans = O.spans_from_segments(segs, scores.shape[1] + 1)
+    fs, fv = F.viterbi(elp.numpy(), lengths.numpy(), trans.numpy(), init.numpy(), lens.numpy(), None, no_eos=True)
+    fs = fs[:, :tmax]
+    if integer:
+        np.testing.assert_array_equal(fv, v.numpy())
+        np.testing.assert_array_equal(fs, spans.numpy())
+    else:
+        np.testing.assert_allclose(fv, v.numpy(), rtol=1e-12, atol=1e-9)
+        for i, t in enumerate(lengths.tolist()):     # same frame labels (boundaries inside a run of one class may differ)
+            np.testing.assert_array_equal(O.spans_to_labels(fs[i:i + 1, :t]), O.spans_to_labels(spans.numpy()[i:i + 1, :t]))
+    assert (fs != c).all()                      # no EOS label anywhere
+    for i, t in enumerate(lengths.tolist()):
+        assert fs[i, t - 1] >= 0                # the last frame starts the closing span
+
+
+def test_factored_matches_dense_at_the_largest_dense_shape():
+    """Factored vs dense agreement at CrossTask magnitudes on the largest lattice whose dense potentials fit the CPU
+    suite comfortably (T = 2000, K = 256, C = 7: 262 MB of fp64 potentials): per-frame emission ~ -290 (D = 200), so cumE
+    reaches 6e5 and h = beta - cumE cancels ~19 bits -- the prefix-sum form must still pick the dense arg-max."""
+    g = torch.Generator().manual_seed(5)
+    t, k, c, d = 2000, 256, 7, 200
+    mu = torch.randn(c, d, generator=g, dtype=torch.float64) * 0.3
+    labels = torch.repeat_interleave(torch.arange(40) % c, 50)[:t]
+    x = mu[labels] + torch.randn(t, d, generator=g, dtype=torch.float64)
+    elp = (-0.5 * ((x[:, None, :] - mu[None]) ** 2).sum(-1) - 0.5 * d * np.log(2 * np.pi))[None]
+    assert -330 < float(elp.max(-1).values.mean()) < -250
+    trans = torch.log_softmax(torch.randn(c, c, generator=g, dtype=torch.float64), 0)
+    init = torch.log_softmax(torch.randn(c, generator=g, dtype=torch.float64), 0)
+    kk = torch.arange(k, dtype=torch.float64)[:, None]
+    rate = torch.rand(c, generator=g, dtype=torch.float64) * 60 + 20
+    lens = kk * rate.log() - rate - torch.lgamma(kk + 1)
+    lengths = torch.tensor([t])
+    scores = O.log_hsmm(trans, elp, init, lens, lengths, add_eos=True)
+    v, segs = O.viterbi_backpointers(scores, lengths + 1)
+    spans = O.spans_from_segments(segs, scores.shape[1] + 1)
+    fs, fv = F.viterbi(elp.numpy(), lengths.numpy(), trans.numpy(), init.numpy(), lens.numpy(), None)
+    np.testing.assert_allclose(fv, v.numpy(), rtol=1e-13)
+    np.testing.assert_array_equal(O.spans_to_labels(fs)[0, :t], O.spans_to_labels(spans.numpy())[0, :t])
+    assert_spans_equivalent(fs, spans.numpy(), lengths, c, scores, v, lengths + 1)

@@ -67,8 +67,10 @@ def test_no_cpu_decode_path(golden):
     _, feats, lengths, valid, cons, cfg = case_inputs(golden, 'tiny', torch.float32)
     with pytest.raises(SmmError):
         m.viterbi(feats, lengths, None)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(SmmError):
         m.viterbi(feats, lengths, None, add_eos=False)
+    with pytest.raises(SmmError):
+        m.log_likelihood(feats, lengths, None, spans=None)
 
 
 def test_module_is_picklable_and_keeps_reference_parameter_names(golden):

@@ -47,7 +47,16 @@ struct SmmMetaChunk { uint32_t w[512]; };
 
 __global__ void __launch_bounds__(512) smm_meta_upload_kernel(SmmMetaChunk c, uint32_t *dst, int n)
 {
-    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.w[threadIdx.x];
+    // the chunk is the first kernel argument: read it from the kernel-argument segment with a per-thread offset (indexing
+    // the by-value struct would make the compiler copy all of it into scratch first)
+    typedef const __attribute__((address_space(4))) uint32_t *smm_kernarg_ptr;
+    (void)c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    smm_kernarg_ptr ka = (smm_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = ka[threadIdx.x];
+#else
+    (void)dst; (void)n;
+#endif
 }
 
 int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream)
@@ -72,8 +81,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #define SMM_MAX_PAIRS 256
 
 struct SmmPlan {
-    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | err | pair progress counters
-    size_t o_order, o_nstates, o_err, o_pflags;
+    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | emission block table[b+1] | err | gang counters
+    size_t o_order, o_nstates, o_emcum, o_err, o_pflags;
     size_t hist_doubles;   // sum over videos of 8*c_max*(T+1): forward cumE/h/gamma, backward cumE/h/gamma, 2 transposes
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
@@ -90,7 +99,8 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     SmmPlan p{};
     p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
-    p.o_err = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
+    p.o_emcum = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
+    p.o_err = p.o_emcum + align_up(sizeof(int32_t) * ((size_t)s->b + 1), 256);
     p.o_pflags = p.o_err + 512;     // error word + diagnostic counters, then 4 counters per leader / follower gang
     p.meta_bytes = p.o_pflags + align_up(sizeof(int32_t) * 4 * (size_t)std::min(s->b, SMM_MAX_PAIRS), 256);
     size_t h = 0;
@@ -114,7 +124,7 @@ extern "C" size_t smm_error_word_offset(const smm_shape *shape)
 {
     if (!shape_ok(shape)) return 0;
     return align_up(sizeof(SmmVideo) * shape->b, 256) + align_up(sizeof(int32_t) * shape->b, 256) +
-           align_up(sizeof(int32_t) * shape->n_groups, 256);
+           align_up(sizeof(int32_t) * shape->n_groups, 256) + align_up(sizeof(int32_t) * ((size_t)shape->b + 1), 256);
 }
 
 struct Staged {
@@ -126,6 +136,8 @@ struct Staged {
     double *elp;
     double *tabs;
     int32_t *pair_flags;
+    int32_t *em_cum;       // emission: workgroups before each video of `order` ([b + 1])
+    int em_tpw, em_blocks;
     int kp_max, c_need;
     int n_pairs;           // Viterbi only: the first n_pairs videos of `order` may run on two CUs each
     bool pairs_cover_big;  // every video with more than 21 states is among them
@@ -149,7 +161,7 @@ static double frame_ns_single(int c)
 // gangs).  Optional gangs: the n most expensive eligible videos, the first n3 of them (above 16 states) as triples;
 // (n, n3) chosen by simulating a list schedule in grid order.  Cost model, ns per frame including the back-trace
 // (measured at K = 1024, T = 4096, 64 videos at a time): one CU: the most loaded SIMD's states x 73, at least 310,
-// + 15; pair: 265 (<= 15 states), 320 (16), 360 (17..23); triple: 325.
+// + 15; pair: 252 (<= 15 states), 300 (16), 330 (17..23); triple: 235 (round 2: per-video finish times on cfg3 seed 2).
 static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need, bool *big_ok)
 {
     *big_ok = false;
@@ -176,7 +188,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     auto states = [&](int32_t v) { return n_states[hv[v].group]; };
     auto gang_ns = [&](int32_t v, int nfol) {
         const int c = states(v);
-        return hv[v].T * (nfol == 2 ? 325.0 : (c > 16 ? 360.0 : (c > 15 ? 320.0 : 265.0)));
+        return hv[v].T * (nfol == 2 ? 235.0 : (c > 16 ? 330.0 : (c > 15 ? 300.0 : 252.0)));   // (measured, round 2: profiles/round2_gang_probe.txt)
     };
     auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(states(v)); };
     // the gang list for (n optional gangs, n3 triples): must + opt[0..n), most expensive first; the first n3 of its
@@ -224,13 +236,13 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     } else {
         double best_t = 1e300;
         // (host time is on the caller's critical path: a handful of candidates, ~b heap operations each)
-        static const int n3s[] = {0, 1, 2, 4, 8, 16, 32};
+        static const int n3s[] = {0, 2, 4, 8};
         for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
             for (int n3 : n3s) {
                 // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few
                 // videos, CUs to spare); on a full GPU their third CU costs the one-CU videos more than it gains
                 // (measured on cfg3: 32 pairs 5.0 ms, 32 triples 5.4 ms)
-                if (n3 > n + (int)must.size() || (n3 > 0 && b + n + (int)must.size() + n3 > n_cu)) continue;
+                if (n3 > n + (int)must.size() || (n3 > 8 && b + n + (int)must.size() + n3 > n_cu)) continue;
                 build(n, n3);
                 const double t = simulate(n);
                 if (std::getenv("SMM_VERBOSE"))
@@ -258,8 +270,11 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
 }
 
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
+// want_gangs: plan gangs for the Viterbi kernel (a list-schedule simulation, ~0.3 ms of host time at 360 videos: only
+// the entry points that launch that kernel ask for it)
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
-                 const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out)
+                 const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
+                 bool want_gangs = false)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
     if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
@@ -303,7 +318,22 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         return (int64_t)hv[a].T * n_states[hv[a].group] > (int64_t)hv[b].T * n_states[hv[b].group];
     });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
-    out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
+    out->n_pairs = 0;
+    out->pairs_cover_big = false;
+    if (want_gangs) out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
+    {
+        // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
+        int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
+        out->em_tpw = smm_emission_tiles_per_wave(s->total_frames, s->b);
+        int64_t cum = 0;
+        for (int i = 0; i < s->b; ++i) {
+            hc[i] = (int32_t)cum;
+            cum += smm_emission_blocks(hv[ho[i]].T, out->em_tpw);
+        }
+        if (cum > 0x7fffffff) return SMM_ERR_UNSUPPORTED;
+        hc[s->b] = (int32_t)cum;
+        out->em_blocks = (int)cum;
+    }
 
     char *base = static_cast<char *>(ws);
     // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream);
@@ -313,6 +343,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     out->videos = reinterpret_cast<SmmVideo *>(base);
     out->order = reinterpret_cast<int32_t *>(base + p.o_order);
     out->n_states = reinterpret_cast<int32_t *>(base + p.o_nstates);
+    out->em_cum = reinterpret_cast<int32_t *>(base + p.o_emcum);
     out->err = reinterpret_cast<int32_t *>(base + p.o_err);
     out->pair_flags = reinterpret_cast<int32_t *>(base + p.o_pflags);
     out->hist = reinterpret_cast<double *>(base + p.meta_bytes);
@@ -338,7 +369,7 @@ static int run_emission(const smm_shape *s, const Staged &st, const float *x, co
     if ((size_t)((s->d + 15) & ~15) * (st.c_need <= 16 ? 21 : 33) * sizeof(double) > 160 * 1024)
         return SMM_ERR_UNSUPPORTED;   // the group's weight table must fit the CU's LDS (D <= 640 at 32 states)
     SmmEmArgs a{st.videos, st.order, st.n_states, x, w, cst, inv_var, cons, elp64, elp32, s->d, s->c_max, s->b};
-    smm_launch_emission(a, st.c_need, s->t_max, s->total_frames, stream);
+    smm_launch_emission(a, st.c_need, st.em_tpw, st.em_blocks, st.em_cum, s->total_frames, stream);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }
@@ -395,7 +426,7 @@ extern "C" int smm_viterbi_f64(const smm_shape *shape, const int64_t *lengths_ho
     Staged st;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
-                   hs, &st);
+                   hs, &st, true);
     if (rc != SMM_OK) return rc;
     return run_viterbi(shape, st, elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
 }
@@ -409,7 +440,7 @@ extern "C" int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_ho
     Staged st;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
-                   hs, &st);
+                   hs, &st, true);
     if (rc != SMM_OK) return rc;
     if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
     const size_t g = shape->n_groups, cm = shape->c_max;
@@ -433,7 +464,7 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     Staged st;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
-                   hs, &st);
+                   hs, &st, true);
     if (rc != SMM_OK) return rc;
     rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs);
     if (rc != SMM_OK) return rc;

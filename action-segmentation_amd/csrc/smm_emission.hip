@@ -8,6 +8,7 @@
 // v_fma_f64 per (frame, d, state).  In fp64 the expansion costs nothing in accuracy (|terms| ~ 1e3, eps 1e-16).
 //
 // Mapping: see the comment above smm_emission_kernel (fp64 MFMA tiles, weights in LDS, 64-B row pieces of x).
+#include <cstdlib>
 #include "smm_launch.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -25,9 +26,21 @@
 // enough bytes are in flight: x is fetched in CHUNKS of 4 macro-steps (4 KB per wave) through a 3-deep register
 // pipeline that runs across tile boundaries -- two chunks are always in flight while the third feeds the MFMAs.
 typedef double smm_d4 __attribute__((ext_vector_type(4)));
+typedef float smm_f4 __attribute__((ext_vector_type(4)));
 
 #define SMM_EM_WAVES 8
 #define SMM_EM_TILES_PER_WAVE 8
+
+// largest i in [0, n) with cum[i] <= b   (cum[0] = 0, cum ascending, cum[n] = grid size)
+__device__ __forceinline__ int smm_em_find_video(const int32_t *__restrict__ cum, int n, int b)
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 
 // NT   state tiles of 16 (1: C <= 16, 2: C <= 32)        VEC  D % 4 == 0: 16-byte loads of x
 // CONS narration constraints are added (they travel through the same pipeline as x: a load in the epilogue would make
@@ -37,7 +50,7 @@ __global__ void __launch_bounds__(SMM_EM_WAVES * 64)
 smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
-                    float *__restrict__ elp32, int D, int cm, int tpw)
+                    float *__restrict__ elp32, int D, int cm, int tpw, const int32_t *__restrict__ blk_cum, int nvid)
 {
     // LDS: this group's weights (zero padded) in the order the lanes read them, then inv_var[D16].
     //   NT = 2: row d = 16 pairs {w[d][fr], w[d][16+fr]} (one ds_read_b128 per lane and MFMA pair; rows 256 B: the four
@@ -45,15 +58,17 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     //   NT = 1: row d = 16 doubles, row stride 20 doubles (160 B: rows 4 apart land 128 B apart modulo the 256-B bank
     //           span, so the two k groups of a ds_read_b64 half-wave do not collide)
     extern __shared__ __attribute__((aligned(16))) double wl[];
-    const int vid = order[blockIdx.y];                               // longest videos first: no long workgroup starts late
+    // flat grid: blk_cum[i] = workgroups of the videos order[0..i) (longest videos first: no long workgroup starts late)
+    const int slot = smm_em_find_video(blk_cum, nvid, blockIdx.x);
+    const int chunk = blockIdx.x - blk_cum[slot];
+    const int vid = order[slot];
     const SmmVideo mv = videos[vid];
     const int T = mv.T, g = mv.group;
     const int C = n_states[g];
     const int ntiles = (T + 15) >> 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
-    const int nbv = (ntiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw);
-    if ((int)blockIdx.x >= nbv) return;
+    const int nbv = blk_cum[slot + 1] - blk_cum[slot];
     const int D16 = (D + 15) & ~15;
     constexpr int WS = (NT == 2) ? 32 : 20;                          // LDS row stride (doubles)
     const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // state tiles this video really needs
@@ -72,7 +87,7 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     const float *__restrict__ xv = xall + (size_t)mv.frame_off * D;
     const double *__restrict__ cst = cstall + (size_t)g * cm;
 
-    const int tile0 = blockIdx.x * SMM_EM_WAVES + wave, tstride = nbv * SMM_EM_WAVES;
+    const int tile0 = chunk * SMM_EM_WAVES + wave, tstride = nbv * SMM_EM_WAVES;
     if (tile0 >= ntiles) return;
     const int nmy = (ntiles - tile0 + tstride - 1) / tstride;        // tiles of this wave
     const int nms = D16 >> 4;                                        // macro-steps of 16 features per tile
@@ -228,6 +243,188 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel v2 (D % 4 == 0): x goes through LDS in whole 128-byte lines.
+//
+// The MFMA A layout gives a row of x only 4 lanes, so loading it straight into A registers (the kernel above) touches
+// half a 128-B line per row and request: 0.65 ms on cfg3 where the bytes alone need 0.38 ms.  Here a wave's 16-frame
+// tile -- 16 * D * 4 CONTIGUOUS bytes of the packed frame axis -- is fetched with 16-byte-per-lane loads of 1 KB per
+// instruction (every line whole, once), parked in a per-wave LDS buffer with a row stride == 8 (mod 16) floats (the
+// A-operand ds_read_b128 of lane (frame l & 15, k l >> 4) is then conflict-free; D = 200 needs no padding at all), and
+// read back in the A layout.  One tile per wave is in flight in registers while the previous one feeds the MFMAs.
+// LDS: weights (D16 * 33 doubles) + 8 waves * 16 * RS floats = 55 + 102 KB at D = 200: one workgroup per CU, 100 KB of
+// loads in flight per CU.
+template <int NT, bool CONS, int NLD>
+__global__ void __launch_bounds__(SMM_EM_WAVES * 64)
+smm_emission_lds_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
+                        const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
+                        const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
+                        float *__restrict__ elp32, int D, int cm, int RS, int64_t x_floats,
+                        const int32_t *__restrict__ blk_cum, int nvid)
+{
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    const int slot = smm_em_find_video(blk_cum, nvid, blockIdx.x);
+    const int chunk = blockIdx.x - blk_cum[slot];
+    const int vid = order[slot];
+    const SmmVideo mv = videos[vid];
+    const int T = mv.T, g = mv.group;
+    const int C = n_states[g];
+    const int ntiles = (T + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nbv = blk_cum[slot + 1] - blk_cum[slot];
+    const int D16 = (D + 15) & ~15;
+    constexpr int WS = (NT == 2) ? 32 : 20;                          // LDS row stride of the weights (doubles)
+    const int nt = (NT == 2 && C > 16) ? 2 : 1;
+    double *ivl = wl + (size_t)D16 * WS;
+    float *xt = reinterpret_cast<float *>(ivl + D16) + (size_t)wave * 16 * RS;   // this wave's tile: 16 rows x RS floats
+    {
+        const double *__restrict__ w = wall + (size_t)g * D * cm;
+        for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
+            const int d = i / (16 * NT), r = i - d * (16 * NT);
+            const int c = (NT == 2) ? (r >> 1) + 16 * (r & 1) : r;
+            wl[(size_t)d * WS + r] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
+        }
+        for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
+    }
+    __syncthreads();
+    const int fr = lane & 15, kq = lane >> 4;
+    const double *__restrict__ cst = cstall + (size_t)g * cm;
+    const int tile0 = chunk * SMM_EM_WAVES + wave, tstride = nbv * SMM_EM_WAVES;
+    if (tile0 >= ntiles) return;
+    const int nmy = (ntiles - tile0 + tstride - 1) / tstride;
+    const int nms = D16 >> 4;
+    // NLD: 16-byte loads per lane and tile, >= 16 D / 256 (the surplus reads the next tile's first bytes; never parked)
+    smm_f4 pre[NLD];
+    float cb[CONS ? 4 * NT : 1];
+    const int64_t last4 = x_floats - 4;                              // clamp: never past the end of x
+
+    // element j of this lane in a tile: linear float offset 4 * (64 j + lane) -> offset in the LDS image (-1: not in the
+    // tile); computed once -- a division per element and tile would cost a third of the MFMA time
+    int lo[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = 4 * (64 * j + lane);
+        const int row = e / D, col = e - row * D;                    // D % 4 == 0: a 16-byte piece never straddles rows
+        lo[j] = row < 16 ? row * RS + col : -1;
+    }
+    double cstv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cstv[t] = (16 * t + fr < C) ? cst[16 * t + fr] : 0.0;
+    auto load_ops = [&](int ms, double (&wv)[4][NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = 16 * ms + 4 * kq + j;
+            if constexpr (NT == 2) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(&wl[(size_t)d * WS + 2 * fr]);
+                wv[j][0] = t2.x;
+                wv[j][NT - 1] = t2.y;
+            } else {
+                wv[j][0] = wl[(size_t)d * WS + fr];
+            }
+        }
+    };
+    // ct = -1: prologue (fetch tile 0 only); single call sites keep the tile registers out of scratch
+    for (int ct = -1; ct < nmy; ++ct) {
+        float cbt[CONS ? 4 * NT : 1];
+        if constexpr (CONS) {
+#pragma unroll
+            for (int i = 0; i < 4 * NT; ++i) cbt[i] = cb[i];
+        }
+        if (ct >= 0) {
+            // registers -> LDS image of the tile (waits for this tile's loads)
+#pragma unroll
+            for (int j = 0; j < NLD; ++j)
+                if (lo[j] >= 0) *reinterpret_cast<smm_f4 *>(xt + lo[j]) = pre[j];
+        }
+        {
+            // the next tile is in flight while this one is computed
+            const int lt = ct + 1;
+            const int ltc = lt < nmy ? lt : nmy - 1;
+            const int f0n = (tile0 + ltc * tstride) << 4;
+            const int64_t base = (int64_t)(mv.frame_off + f0n) * D;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                int64_t e = base + 4 * (64 * j + lane);
+                e = e < last4 ? e : last4;                           // (rows past the video / the buffer are never stored)
+                pre[j] = *reinterpret_cast<const smm_f4 *>(xall + e);
+            }
+            if constexpr (CONS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ff = f0n + kq + 4 * i;
+                    const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int c = 16 * t + fr;
+                        cb[4 * t + i] = cons[rowo + (c < cm ? c : cm - 1)];
+                    }
+                }
+            }
+        }
+        if (ct < 0) continue;
+        smm_d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+        double q = 0.0;
+        double wcur[4][NT];
+        load_ops(0, wcur);
+        const float *xrow = xt + fr * RS;
+        float4 a4 = *reinterpret_cast<const float4 *>(xrow + (4 * kq + 3 < D ? 4 * kq : D - 4));
+        for (int ms = 0; ms < nms; ++ms) {
+            double wnext[4][NT], iv4[4];
+            load_ops(ms + 1 < nms ? ms + 1 : 0, wnext);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) iv4[j] = ivl[16 * ms + 4 * kq + j];
+            int cn = 16 * (ms + 1) + 4 * kq;                         // next macro-step's features of this lane
+            cn = cn + 3 < D ? cn : D - 4;                            // (zero-padded weights ignore what is read there)
+            const float4 an = *reinterpret_cast<const float4 *>(xrow + cn);
+            double av[4];
+            av[0] = (double)a4.x; av[1] = (double)a4.y; av[2] = (double)a4.z; av[3] = (double)a4.w;
+            if (nt == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
+                    acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][NT - 1], acc[NT - 1], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q = fma(av[j] * iv4[j], av[j], q);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wcur[j][t] = wnext[j][t];
+            }
+            a4 = an;
+        }
+        // tile finished.  q: this lane summed the features with k index kq of frame fr; add the four k groups
+        const int f0 = (tile0 + ct * tstride) << 4;
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = kq + 4 * i;
+            const double qr = __shfl(q, row);
+            const int ff = f0 + row;
+            if (ff < T) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = 16 * t + fr;
+                    if (c < C) {
+                        const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
+                        double v = (cstv[t] + acc[t][i]) - 0.5 * qr;
+                        if constexpr (CONS) v += (double)cbt[4 * t + i];
+                        if (elp64) elp64[o] = v;
+                        if (elp32) elp32[o] = (float)v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 -> fp64 widening of a [n] array (smm_viterbi_f32 boundary)
 __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
 {
@@ -236,35 +433,77 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
     for (; i < n; i += stride) dst[i] = (double)src[i];
 }
 
-void smm_launch_emission(const SmmEmArgs &a, int ct, int t_max, int64_t total_frames, hipStream_t stream)
+int smm_emission_tiles_per_wave(int64_t total_frames, int b)
 {
-    const int d16 = (a.d + 15) & ~15;
-    const int tiles = (t_max + 15) / 16;
     // up to 8 tiles per wave (amortises the LDS fill of the weights), fewer when that would leave CUs without a
     // workgroup: aim at >= 2 workgroups on each of the 256 CUs
-    int64_t tpw = (total_frames / 16 + a.b) / (512 * SMM_EM_WAVES);
-    tpw = tpw < 1 ? 1 : (tpw > SMM_EM_TILES_PER_WAVE ? SMM_EM_TILES_PER_WAVE : tpw);
-    int bx = (int)((tiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw));
-    if (bx < 1) bx = 1;
-    dim3 grid(bx, a.b), block(SMM_EM_WAVES * 64);
-    const size_t lds = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);          // <= 160 KiB checked by the caller
+    int64_t tpw = (total_frames / 16 + b) / (512 * SMM_EM_WAVES);
+    return (int)(tpw < 1 ? 1 : (tpw > SMM_EM_TILES_PER_WAVE ? SMM_EM_TILES_PER_WAVE : tpw));
+}
+
+int smm_emission_blocks(int t, int tpw)
+{
+    const int tiles = (t + 15) / 16;
+    return (tiles + SMM_EM_WAVES * tpw - 1) / (SMM_EM_WAVES * tpw);
+}
+
+void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
+                         hipStream_t stream)
+{
+    const int d16 = (a.d + 15) & ~15;
+    dim3 grid(n_blocks), block(SMM_EM_WAVES * 64);
+    const size_t lds_w = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);        // weights + inv_var
     const bool vec = (a.d & 3) == 0;
-    auto go = [&](auto kern) {
+    // v2 (x staged through LDS in whole lines): row stride == 8 (mod 16) floats, >= D
+    int rs = (a.d / 16) * 16 + 8;
+    if (rs < a.d) rs += 16;
+    const int nld = (16 * a.d / 4 + 63) / 64;                                 // 16-byte loads per lane and tile
+    const size_t lds_x = sizeof(float) * 16 * rs * SMM_EM_WAVES;
+    // v2 is opt-in (SMM_EMISSION_V2=1): measured on cfg3 (rocprofv3, profiles/round2_emission_v1_v2.txt) it takes 0.77 ms
+    // against v1's 0.62 ms -- its LDS footprint (weights + 8 tile buffers = 157 KB) leaves ONE 8-wave workgroup per CU
+    // where v1 runs two, and the kernel turned out not to be bound by the 64-byte row pieces of v1's loads.
+    const bool v2 = vec && nld <= 20 && lds_w + lds_x <= 160 * 1024 && std::getenv("SMM_EMISSION_V2");
+    const int nsel = nld <= 4 ? 0 : (nld <= 8 ? 1 : (nld <= 13 ? 2 : 3));     // compiled load counts: 4, 8, 13, 20
+    auto go1 = [&](auto kern) {
+        if (lds_w > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        hipLaunchKernelGGL(kern, grid, block, lds_w, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
+                           a.elp64, a.elp32, a.d, a.c_max, tpw, blk_cum, a.b);
+    };
+    auto go2 = [&](auto kern) {
+        const size_t lds = lds_w + lds_x;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
-                           a.elp64, a.elp32, a.d, a.c_max, (int)tpw);
+                           a.elp64, a.elp32, a.d, a.c_max, rs, (int64_t)total_frames * a.d, blk_cum, a.b);
     };
+    if (v2) {
+#define SMM_EM_V2(NLD_)                                                                         \
+        switch ((ct <= 16 ? 0 : 2) + (a.cons ? 1 : 0)) {                                        \
+        case 0: go2(smm_emission_lds_kernel<1, false, NLD_>); break;                            \
+        case 1: go2(smm_emission_lds_kernel<1, true, NLD_>); break;                             \
+        case 2: go2(smm_emission_lds_kernel<2, false, NLD_>); break;                            \
+        default: go2(smm_emission_lds_kernel<2, true, NLD_>); break;                            \
+        }
+        switch (nsel) {
+        case 0: SMM_EM_V2(4) break;
+        case 1: SMM_EM_V2(8) break;
+        case 2: SMM_EM_V2(13) break;
+        default: SMM_EM_V2(20) break;
+        }
+#undef SMM_EM_V2
+        return;
+    }
     const int sel = (ct <= 16 ? 0 : 4) + (vec ? 2 : 0) + (a.cons ? 1 : 0);
     switch (sel) {
-    case 0: go(smm_emission_kernel<1, false, false>); break;
-    case 1: go(smm_emission_kernel<1, false, true>); break;
-    case 2: go(smm_emission_kernel<1, true, false>); break;
-    case 3: go(smm_emission_kernel<1, true, true>); break;
-    case 4: go(smm_emission_kernel<2, false, false>); break;
-    case 5: go(smm_emission_kernel<2, false, true>); break;
-    case 6: go(smm_emission_kernel<2, true, false>); break;
-    default: go(smm_emission_kernel<2, true, true>); break;
+    case 0: go1(smm_emission_kernel<1, false, false>); break;
+    case 1: go1(smm_emission_kernel<1, false, true>); break;
+    case 2: go1(smm_emission_kernel<1, true, false>); break;
+    case 3: go1(smm_emission_kernel<1, true, true>); break;
+    case 4: go1(smm_emission_kernel<2, false, false>); break;
+    case 5: go1(smm_emission_kernel<2, false, true>); break;
+    case 6: go1(smm_emission_kernel<2, true, false>); break;
+    default: go1(smm_emission_kernel<2, true, true>); break;
     }
 }
 

@@ -12,13 +12,14 @@
 // Algorithmic bytes per frame: 4 D (features, read once) + 8 (label, read by each kernel) -> 4 D + 16.
 // Sums are fp64 and leave the workgroup through atomics: the ORDER of the additions (and with it the last bits of the
 // result) is not fixed from run to run; the reference's BLAS-threaded sklearn sums are not either.
+#include <algorithm>
 #include <vector>
 
 #include "../../include/smmdp.h"
 #include "smm_device.h"
 #include "smm_launch.h"
 
-#define SMM_FIT_ROWS 1024        // frames per workgroup of the class-sum kernel (256 per wave)
+#define SMM_FIT_CHUNK 2048       // frames per work item of both kernels (one table of chunks per video)
 #define SMM_FIT_UNROLL 8
 
 struct SmmFitVideo {
@@ -38,88 +39,148 @@ struct SmmFitArgs {
     unsigned long long *starts;  // [n_classes]
     unsigned long long *trans;   // [n_classes][n_classes]  [to][from]
     int32_t *err;                // label outside [0, n_classes)
-    int32_t d, n_classes, max_k, b;
+    const int32_t *cum;          // [b + 1] chunks of SMM_FIT_CHUNK frames before each video
+    int32_t d, n_classes, max_k, b, n_chunks;
 };
+
+// largest i in [0, n) with cum[i] <= c
+__device__ __forceinline__ int smm_fit_find_video(const int32_t *__restrict__ cum, int n, int c)
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 
 __device__ __forceinline__ void smm_atomic_add(double *p, double v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// grid (b, ceil(t_max / ROWS)); each wave streams its 256 rows; lane = 4 consecutive feature columns
+// Persistent grid (a few workgroups per CU) over the flat list of 2048-frame chunks; a wave streams 512 rows of its
+// chunk, lane = 4 consecutive feature columns (one 800-byte row per load instruction at D = 200, 8 rows in flight).
+// Class sums leave the wave at every label change (one fp64 atomic per column into the class's row: ~300 different rows
+// on CrossTask, so the memory-side atomic units do not queue); the sum of squares -- ONE row for everybody, where
+// per-chunk atomics serialise at ~0.09 TB/s (MI355X_MICROARCH.md, Global float atomics: contention) -- stays in
+// registers across all chunks of the wave, is reduced over the workgroup's waves in LDS and leaves once per workgroup.
 __global__ void __launch_bounds__(256) smm_class_sums_kernel(SmmFitArgs a)
 {
-    const SmmFitVideo mv = a.videos[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * SMM_FIT_ROWS + wv * (SMM_FIT_ROWS / 4);
-    if (r0 >= mv.T) return;
-    const int r1 = min(mv.T, r0 + SMM_FIT_ROWS / 4);
     const int d = a.d;
-    const float *x = a.x + (size_t)mv.frame_off * d;
-    const int64_t *y = a.labels + mv.frame_off;
+    __shared__ double s_sq[4][256];
+    // A lane owns 4 consecutive columns, so its 4 sums are 32 bytes apart from its neighbour's: an atomic instruction
+    // straight from those registers would touch 64 separate 8-byte words.  The sums go through the wave's row of s_sq
+    // first, so that every atomic instruction adds 64 CONSECUTIVE doubles (512 contiguous bytes, the shape the
+    // memory-side atomic units run at full rate for).  Wave-private LDS, wave-uniform control flow: no barrier needed.
+    auto flush = [&](double (&acc)[4], double *dst_row, int c0, int ncol_total) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_sq[wv][lane * 4 + j] = acc[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = 64 * j + lane;
+            if (cc < ncol_total) smm_atomic_add(dst_row + c0 + cc, s_sq[wv][cc]);
+        }
+    };
     for (int c0 = 0; c0 < d; c0 += 256) {                       // column pass (one pass for D <= 256)
+        const int ncol_total = min(256, d - c0);
         const int col = c0 + lane * 4;
         const int ncol = min(4, d - col);                       // <= 0: this lane has no columns in this pass
         const bool vec = ncol == 4 && (d & 3) == 0;
-        double acc[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
-        int64_t cur = y[r0];
-        for (int r = r0; r < r1; r += SMM_FIT_UNROLL) {
-            float v[SMM_FIT_UNROLL][4];
-            int64_t lab[SMM_FIT_UNROLL];
+        double sq[4] = {0, 0, 0, 0};
+        for (int ch = blockIdx.x; ch < a.n_chunks; ch += gridDim.x) {
+            const int vi = smm_fit_find_video(a.cum, a.b, ch);
+            const SmmFitVideo mv = a.videos[vi];
+            const int r0 = (ch - a.cum[vi]) * SMM_FIT_CHUNK + wv * (SMM_FIT_CHUNK / 4);
+            if (r0 >= mv.T) continue;
+            const int r1 = min(mv.T, r0 + SMM_FIT_CHUNK / 4);
+            const float *x = a.x + (size_t)mv.frame_off * d;
+            const int64_t *y = a.labels + mv.frame_off;
+            double acc[4] = {0, 0, 0, 0};
+            int64_t cur = y[r0];
+            for (int r = r0; r < r1; r += SMM_FIT_UNROLL) {
+                float v[SMM_FIT_UNROLL][4];
+                int64_t lab[SMM_FIT_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
-                const int rr = min(r + u, r1 - 1);              // clamped: the tail re-reads the last row, then skips it
-                lab[u] = y[rr];
-                if (vec) {
-                    const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)rr * d + col);
-                    v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
-                } else {
+                for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
+                    const int rr = min(r + u, r1 - 1);          // clamped: the tail re-reads the last row, then skips it
+                    lab[u] = y[rr];
+                    if (vec) {
+                        const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)rr * d + col);
+                        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][j] = j < ncol ? x[(size_t)rr * d + col + j] : 0.f;
+                        for (int j = 0; j < 4; ++j) v[u][j] = j < ncol ? x[(size_t)rr * d + col + j] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
+                    if (r + u >= r1) break;
+                    if (lab[u] != cur) {                         // wave-uniform
+                        if (cur >= 0 && cur < a.n_classes) flush(acc, a.sum_x + (size_t)cur * d, c0, ncol_total);
+                        acc[0] = acc[1] = acc[2] = acc[3] = 0;
+                        cur = lab[u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double xv = (double)v[u][j];
+                        acc[j] += xv;
+                        sq[j] += xv * xv;
+                    }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
-                if (r + u >= r1) break;
-                if (lab[u] != cur) {                             // wave-uniform
-                    if (cur >= 0 && cur < a.n_classes)
-                        for (int j = 0; j < 4; ++j)
-                            if (j < ncol) smm_atomic_add(a.sum_x + (size_t)cur * d + col + j, acc[j]);
-                    acc[0] = acc[1] = acc[2] = acc[3] = 0;
-                    cur = lab[u];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double xv = (double)v[u][j];
-                    acc[j] += xv;
-                    sq[j] += xv * xv;
-                }
-            }
+            if (cur >= 0 && cur < a.n_classes) flush(acc, a.sum_x + (size_t)cur * d, c0, ncol_total);
         }
-        if (cur >= 0 && cur < a.n_classes)
-            for (int j = 0; j < 4; ++j)
-                if (j < ncol) smm_atomic_add(a.sum_x + (size_t)cur * d + col + j, acc[j]);
-        for (int j = 0; j < 4; ++j)
-            if (j < ncol) smm_atomic_add(a.sum_x2 + col + j, sq[j]);
+        // sum of squares: waves -> LDS -> one atomic per column and workgroup
+        __syncthreads();                                        // (every wave is done with its row of s_sq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_sq[wv][lane * 4 + j] = sq[j];
+        __syncthreads();
+        {
+            const int cc = c0 + (int)threadIdx.x;
+            if (cc < d) smm_atomic_add(a.sum_x2 + cc, s_sq[0][threadIdx.x] + s_sq[1][threadIdx.x] + s_sq[2][threadIdx.x] + s_sq[3][threadIdx.x]);
+        }
+        __syncthreads();
     }
 }
 
-// one workgroup per video: ordered tiles of 256 frames; run starts by a max-scan of the change positions
+// One workgroup per 2048-frame chunk (tiles of 256 frames in order); run starts by a max-scan of the change positions.
+// The run that is open where the chunk begins may have started long before it: its start is found by scanning the labels
+// backwards from the chunk's first frame, 256 at a time (one iteration for runs shorter than 256 frames).
 __global__ void __launch_bounds__(256) smm_span_stats_kernel(SmmFitArgs a)
 {
-    const SmmFitVideo mv = a.videos[blockIdx.x];
+    const int vi = smm_fit_find_video(a.cum, a.b, blockIdx.x);
+    const SmmFitVideo mv = a.videos[vi];
     const int T = mv.T, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t *y = a.labels + mv.frame_off;
+    const int c_begin = (blockIdx.x - a.cum[vi]) * SMM_FIT_CHUNK;
+    const int c_end = min(T, c_begin + SMM_FIT_CHUNK);
     const int cut = a.max_k > 1 ? a.max_k - 1 : 1;              // a run is cut every `cut` frames
     const bool do_cut = a.max_k > 0;
-    extern __shared__ unsigned int s_hist[];                    // frames per class of this video
+    extern __shared__ unsigned int s_hist[];                    // frames per class of this chunk
     __shared__ int s_wmax[4];
+    __shared__ int s_carry;
     for (int i = tid; i < a.n_classes; i += blockDim.x) s_hist[i] = 0;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    int carry = 0;                                              // start of the run that is open at the tile boundary
-    for (int t0 = 0; t0 < T; t0 += 256) {
+    // start of the run containing frame c_begin - 1 (0 when the chunk opens the video): the largest p < c_begin with
+    // p == 0 or y[p] != y[p-1]
+    if (c_begin > 0) {
+        for (int hi = c_begin - 1; hi >= 0; hi -= 256) {
+            const int p = hi - tid;
+            const bool chg = p >= 0 && (p == 0 || y[p] != y[p - 1]);
+            if (chg) atomicMax(&s_carry, p);
+            __syncthreads();
+            if (s_carry > 0 || hi - 255 <= 0) break;            // (uniform: read after the barrier; p == 0 always counts)
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    int carry = s_carry;
+    for (int t0 = c_begin; t0 < c_end; t0 += 256) {
         const int t = t0 + tid;
-        const bool live = t < T;
+        const bool live = t < c_end;
         int64_t lab = -1, before = -1;
         if (live) {
             lab = y[t];
@@ -158,7 +219,13 @@ __global__ void __launch_bounds__(256) smm_span_stats_kernel(SmmFitArgs a)
         if (s_hist[i]) atomicAdd(a.frames + i, (unsigned long long)s_hist[i]);
 }
 
-extern "C" size_t smm_fit_workspace_bytes(int32_t b) { return b > 0 ? sizeof(SmmFitVideo) * (size_t)b + 256 : 0; }
+static size_t fit_off_err(int32_t b) { return (sizeof(SmmFitVideo) * (size_t)b + 63) / 64 * 64; }
+static size_t fit_off_cum(int32_t b) { return fit_off_err(b) + 64; }
+
+extern "C" size_t smm_fit_workspace_bytes(int32_t b)
+{
+    return b > 0 ? fit_off_cum(b) + sizeof(int32_t) * ((size_t)b + 1) + 256 : 0;
+}
 
 extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_t *frame_off, int64_t total_frames,
                                  int32_t d, int32_t n_classes, int32_t max_k, const float *x, const int64_t *labels,
@@ -172,19 +239,24 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
         return SMM_ERR_ARG;
     if (ws_bytes < smm_fit_workspace_bytes(b)) return SMM_ERR_WORKSPACE;
     std::vector<SmmFitVideo> hv(b);
-    int64_t t_max = 0;
+    std::vector<int32_t> cum((size_t)b + 1);
+    int64_t n_chunks = 0;
     for (int i = 0; i < b; ++i) {
         if (lengths[i] < 1 || frame_off[i] < 0 || frame_off[i] + lengths[i] > total_frames || lengths[i] > 0x7FFFFFFF)
             return SMM_ERR_ARG;
         hv[i].frame_off = frame_off[i];
         hv[i].T = (int32_t)lengths[i];
         hv[i].pad = 0;
-        t_max = lengths[i] > t_max ? lengths[i] : t_max;
+        cum[i] = (int32_t)n_chunks;
+        n_chunks += (lengths[i] + SMM_FIT_CHUNK - 1) / SMM_FIT_CHUNK;
     }
+    if (n_chunks > 0x7fffffff) return SMM_ERR_UNSUPPORTED;
+    cum[b] = (int32_t)n_chunks;
     char *base = static_cast<char *>(ws);
-    const size_t o_err = (sizeof(SmmFitVideo) * (size_t)b + 63) / 64 * 64;
+    const size_t o_err = fit_off_err(b);
 #define SMM_FIT_HIP(call) do { if ((call) != hipSuccess) return SMM_ERR_HIP; } while (0)
     SMM_FIT_HIP((hipError_t)smm_upload_meta(base, hv.data(), sizeof(SmmFitVideo) * b, stream));
+    SMM_FIT_HIP((hipError_t)smm_upload_meta(base + fit_off_cum(b), cum.data(), sizeof(int32_t) * ((size_t)b + 1), stream));
     SMM_FIT_HIP(hipMemsetAsync(base + o_err, 0, 64, stream));
     const size_t n = (size_t)n_classes;
     SMM_FIT_HIP(hipMemsetAsync(sum_x, 0, sizeof(double) * n * d, stream));
@@ -204,17 +276,17 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
     a.starts = reinterpret_cast<unsigned long long *>(span_start_counts);
     a.trans = reinterpret_cast<unsigned long long *>(span_transition_counts);
     a.err = reinterpret_cast<int32_t *>(base + o_err);
+    a.cum = reinterpret_cast<const int32_t *>(base + fit_off_cum(b));
     a.d = d;
     a.n_classes = n_classes;
     a.max_k = max_k;
     a.b = b;
-    dim3 grid(b, (unsigned)((t_max + SMM_FIT_ROWS - 1) / SMM_FIT_ROWS));
-    hipLaunchKernelGGL(smm_class_sums_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(smm_span_stats_kernel, dim3(b), dim3(256), sizeof(unsigned int) * n, stream, a);
+    a.n_chunks = (int32_t)n_chunks;
+    // class sums: a persistent grid of <= 4 workgroups per CU (fewer flushes of the one sum-of-squares row)
+    const int g_sum = (int)std::min<int64_t>(n_chunks, 1024);
+    hipLaunchKernelGGL(smm_class_sums_kernel, dim3(g_sum), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(smm_span_stats_kernel, dim3((unsigned)n_chunks), dim3(256), sizeof(unsigned int) * n, stream, a);
     return hipGetLastError() == hipSuccess ? SMM_OK : SMM_ERR_HIP;
 }
 
-extern "C" size_t smm_fit_error_word_offset(int32_t b)
-{
-    return b > 0 ? (sizeof(SmmFitVideo) * (size_t)b + 63) / 64 * 64 : 0;
-}
+extern "C" size_t smm_fit_error_word_offset(int32_t b) { return b > 0 ? fit_off_err(b) : 0; }

@@ -21,7 +21,12 @@ struct SmmEmArgs {
 // the stream has drained (and cannot be captured into a hipGraph); this does neither.  Returns a hipError_t as int.
 int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream);
 
-void smm_launch_emission(const SmmEmArgs &a, int c_need, int t_max, int64_t total_frames, hipStream_t stream);
+// flat grid: blk_cum[i] (device, [b + 1]) = workgroups of the videos order[0..i), built by the host from
+// smm_emission_tiles_per_wave / smm_emission_blocks
+int smm_emission_tiles_per_wave(int64_t total_frames, int b);
+int smm_emission_blocks(int t, int tpw);
+void smm_launch_emission(const SmmEmArgs &a, int c_need, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
+                         hipStream_t stream);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);

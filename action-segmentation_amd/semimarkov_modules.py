@@ -207,12 +207,33 @@ class SemiMarkovModule(nn.Module):
             idx = torch.as_tensor([self.merge_classes[int(ix)] for ix in idx], dtype=torch.long)
         return idx
 
+    def _dev_index(self, kind, valid_classes, device):
+        """Index tensors of a class set on the device, built once: ``vc`` (the class ids), ``merged`` (after
+        merge_classes), ``class_map`` (ids + EOS).  A host -> device copy of a few integers per table and call is a
+        stream synchronisation each; the training step builds six tables per class set."""
+        cache = self.__dict__.setdefault('_index_cache', {})
+        key = (kind, None if valid_classes is None else tuple(int(v) for v in valid_classes), str(device),
+               id(getattr(self, 'merge_classes', None)))
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 256:
+                cache.clear()
+            if kind == 'vc':
+                t = valid_classes.to(device)
+            elif kind == 'merged':
+                t = self._merged(valid_classes).to(device)
+            else:
+                ids = list(range(self.n_classes)) if valid_classes is None else [int(v) for v in valid_classes]
+                t = torch.tensor(ids + [self.n_classes], dtype=torch.int64, device=device)
+            cache[key] = t
+        return t
+
     def initial_log_probs(self, valid_classes, dtype=None):
         logits = self.init_logits if dtype is None else self.init_logits.to(dtype)
         if self.init_constraints is not None:
             logits = logits.masked_fill(self.init_constraints, BIG_NEG)
         if valid_classes is not None:
-            logits = logits[valid_classes.to(logits.device)]
+            logits = logits[self._dev_index('vc', valid_classes, logits.device)]
         return F.log_softmax(logits, dim=0)
 
     def transition_log_probs(self, valid_classes, dtype=None):
@@ -220,7 +241,7 @@ class SemiMarkovModule(nn.Module):
         if self.transition_constraints is not None:
             t = t.masked_fill(self.transition_constraints, BIG_NEG)
         if valid_classes is not None:
-            vc = valid_classes.to(t.device)
+            vc = self._dev_index('vc', valid_classes, t.device)
             t = t[vc][:, vc]
         if not self.allow_self_transitions:
             t = t.masked_fill(torch.eye(t.size(0), device=t.device, dtype=torch.bool), BIG_NEG)
@@ -248,7 +269,7 @@ class SemiMarkovModule(nn.Module):
         return torch.xlogy(k, rate) - rate - torch.lgamma(k + 1)   # Poisson(rate).log_prob(k); row == length
 
     def length_log_probs(self, valid_classes, dtype=None):
-        idx = self._merged(valid_classes).to(self.poisson_log_rates.device)
+        idx = self._dev_index('merged', valid_classes, self.poisson_log_rates.device)
         rates = self.poisson_log_rates if dtype is None else self.poisson_log_rates.to(dtype)
         return self._length_log_probs_with_rates(rates[idx])
 
@@ -363,7 +384,7 @@ class SemiMarkovModule(nn.Module):
             bad = [int(v) for v in vc if not 0 <= int(v) < self.n_classes]
             if bad:
                 raise IndexError("valid_classes %s outside the model's %d classes" % (bad, self.n_classes))
-        idx = self._merged(vc).to(dev)
+        idx = self._dev_index('merged', vc, dev)
         var = torch.diagonal(self.gaussian_cov).to(f64)
         mu = self.gaussian_means.to(f64)[idx]                                   # C x D
         d = mu.size(1)
@@ -374,12 +395,12 @@ class SemiMarkovModule(nn.Module):
         return dict(
             trans=self.transition_log_probs(vc, f64).contiguous(), init=self.initial_log_probs(vc, f64).contiguous(),
             len=self.length_log_probs(vc, f64).contiguous(), w=w, cst=cst.contiguous(),
-            inv_var=(1.0 / var).contiguous(),
-            class_map=torch.tensor(ids + [self.n_classes], dtype=torch.int64, device=dev))
+            inv_var=(1.0 / var).contiguous(), class_map=self._dev_index('class_map', vc, dev))
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop('_table_cache', None)          # device tensors derived from the parameters: rebuilt on demand
+        state.pop('_index_cache', None)
         return state
 
     def _decode_tables(self, valid_classes, device):
@@ -488,6 +509,10 @@ class SemiMarkovModule(nn.Module):
             tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
         else:
             tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
+            key = tuple(id(t) for t in tabs)        # the cached per-group tables are the same objects while the
+            hit = getattr(pc, '_stacked', None)     # parameters have not changed: so is their stack
+            if hit is not None and hit[0] == key:
+                return hit[1]
         n_states = [int(t['init'].numel()) for t in tabs]
         cm = max(n_states)
         pad = lambda t, c, rows=False: F.pad(t, (0, cm - c) + ((0, cm - c) if rows else ()))
@@ -498,7 +523,10 @@ class SemiMarkovModule(nn.Module):
                   cst=torch.stack([pad(t['cst'], c) for t, c in zip(tabs, n_states)]).contiguous(),
                   inv_var=tabs[0]['inv_var'],
                   class_map=torch.stack([F.pad(t['class_map'], (0, cm - c)) for t, c in zip(tabs, n_states)]).contiguous())
-        return st, n_states, cm, tabs[0]['len'].size(0)
+        out = (st, n_states, cm, tabs[0]['len'].size(0))
+        if not differentiable:
+            pc._stacked = (key, out, tabs)          # (tabs: keeps the ids alive)
+        return out
 
     def prepare_packed(self, pc, differentiable=False):
         """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns, and
@@ -563,30 +591,47 @@ class SemiMarkovModule(nn.Module):
         ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
         k_rows = tab['len'].size(0)
         kp = min(k_rows, tmax)
-        out = []
-        sp = spans.detach().cpu()
+        # Segment list on the host (integers only), then ONE gather + segment-sum on the device: no per-segment device
+        # scalars (a Python loop of tiny tensor ops per segment was the cost of --sm_supervised_method gradient-based).
+        sp = spans.detach().cpu().numpy()
+        seg_i, seg_s0, seg_s1, seg_c, tr_i, tr_to, tr_from, init_i, init_c, pen_i, last_i, last_c = ([] for _ in range(12))
         for i in range(b):
             t = int(lengths[i])
             row = sp[i, :t]
-            starts = torch.nonzero(row != -1).flatten().tolist()
+            starts = np.flatnonzero(row != -1).tolist()
             assert starts and starts[0] == 0, "a span encoding starts with a label"
             bounds = starts + [t]
             labs = [local[int(row[s])] for s in starts]
-            total = tab['init'][labs[0]] if (not no_eos or len(labs) > 1) else tab['init'][labs[0]] * 0
-            for j, (s0, s1) in enumerate(zip(bounds[:-1], bounds[1:])):
-                if no_eos and j + 1 == len(labs):
-                    if s0 == t - 1:
-                        total = total + elp[i, t - 1, labs[j]]
-                    break
-                kk = s1 - s0
+            n_scored = len(labs) - 1 if no_eos else len(labs)     # no EOS: the last span has no edge (to_parts)
+            if n_scored > 0:
+                init_i.append(i); init_c.append(labs[0])
+            for j in range(n_scored):
+                kk = bounds[j + 1] - bounds[j]
                 assert 1 <= kk <= kp - 1, "span longer than the model's max span length"
-                total = total + tab['len'][kk, labs[j]] + (cum[i, s1, labs[j]] - cum[i, s0, labs[j]])
+                seg_i.append(i); seg_s0.append(bounds[j]); seg_s1.append(bounds[j + 1]); seg_c.append(labs[j])
                 if j + 1 < len(labs):
-                    total = total + tab['trans'][labs[j + 1], labs[j]]
-            if not no_eos and ends is not None and labs[-1] not in ends[i]:
-                total = total + BIG_NEG
-            out.append(total)
-        return torch.stack(out)
+                    tr_i.append(i); tr_to.append(labs[j + 1]); tr_from.append(labs[j])
+            if no_eos:
+                if bounds[-2] == t - 1:                            # the closing label's emission of the last frame
+                    last_i.append(i); last_c.append(labs[-1])
+            elif ends is not None and labs[-1] not in ends[i]:
+                pen_i.append(i)
+        dev = elp.device
+        li = lambda v: torch.as_tensor(v, dtype=torch.long, device=dev)
+        total = torch.zeros(b, dtype=f64, device=dev)
+        if seg_i:
+            si, s0, s1, sc = li(seg_i), li(seg_s0), li(seg_s1), li(seg_c)
+            total = total.index_add(0, si, tab['len'][s1 - s0, sc] + (cum[si, s1, sc] - cum[si, s0, sc]))
+        if tr_i:
+            total = total.index_add(0, li(tr_i), tab['trans'][li(tr_to), li(tr_from)])
+        if init_i:
+            total = total.index_add(0, li(init_i), tab['init'][li(init_c)])
+        if last_i:
+            ii = li(last_i)
+            total = total.index_add(0, ii, elp[ii, li([int(lengths[i]) - 1 for i in last_i]), li(last_c)])
+        if pen_i:
+            total = total.index_add(0, li(pen_i), torch.full((len(pen_i),), BIG_NEG, dtype=f64, device=dev))
+        return total
 
     def log_partition(self, features, lengths, valid_classes, additional_allowed_ends_per_instance=None,
                       constraints=None, no_eos=False):
@@ -635,8 +680,10 @@ class SemiMarkovModule(nn.Module):
         """Per source batch the mean log-likelihood the reference's ``log_likelihood(spans=None)`` returns for it
         (semimarkov_modules.py:657: ``dist.partition.mean()``): fp64 [n_batches], differentiable."""
         z = self.log_partition_packed(pc)
-        bi = torch.as_tensor(pc.batch_index, device=z.device)
-        nb = int(bi.max()) + 1
+        bi = getattr(pc, '_batch_index_dev', None)
+        if bi is None or bi.device != z.device:
+            bi = pc._batch_index_dev = torch.as_tensor(pc.batch_index, device=z.device)
+        nb = int(max(pc.batch_index)) + 1
         sums = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, z)
         cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
         return sums / cnt

@@ -14,6 +14,17 @@ import torch
 def labels_to_spans(position_labels, max_k):
     """b x N labels -> span encoding: class id at a span start, -1 for its continuation.  A run of one label is
     cut every ``max_k - 1`` frames (the DP only knows segment lengths 1..max_k-1).  utils.py:6-23."""
+    if torch.is_tensor(position_labels) and position_labels.is_cuda:
+        # device tensors stay on the device (the gradient-based supervised fit encodes every batch, semimarkov.py:251)
+        lab = position_labels.detach()
+        b, n = lab.shape
+        idx = torch.arange(n, device=lab.device).unsqueeze(0).expand(b, n)
+        change = torch.ones((b, n), dtype=torch.bool, device=lab.device)
+        change[:, 1:] = lab[:, 1:] != lab[:, :-1]
+        run_start = torch.cummax(torch.where(change, idx, torch.zeros_like(idx)), dim=1).values
+        pos_in_run = idx - run_start
+        cont = (pos_in_run % max(max_k - 1, 1) != 0) if max_k is not None else (pos_in_run != 0)
+        return torch.where(cont, torch.full_like(lab, -1), lab)
     lab = position_labels.detach().cpu().numpy() if torch.is_tensor(position_labels) else np.asarray(position_labels)
     assert not (lab == -1).any(), "position_labels already appear span encoded (have -1)"
     b, n = lab.shape
@@ -36,6 +47,11 @@ def labels_to_spans(position_labels, max_k):
 
 def spans_to_labels(spans):
     """Forward-fill -1 with the running label.  utils.py:51-63."""
+    if torch.is_tensor(spans) and spans.is_cuda:
+        sp = spans.detach()
+        n = sp.size(1)
+        idx = torch.where(sp != -1, torch.arange(n, device=sp.device).unsqueeze(0).expand_as(sp), torch.zeros_like(sp))
+        return torch.gather(sp, 1, torch.cummax(idx, dim=1).values)
     sp = spans.detach().cpu().numpy() if torch.is_tensor(spans) else np.asarray(spans)
     assert (sp[:, 0] != -1).all()
     b, n = sp.shape

@@ -13,6 +13,7 @@
 // Sums are fp64 and leave the workgroup through atomics: the ORDER of the additions (and with it the last bits of the
 // result) is not fixed from run to run; the reference's BLAS-threaded sklearn sums are not either.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/smmdp.h"
@@ -65,6 +66,10 @@ __device__ __forceinline__ void smm_atomic_add(double *p, double v)
 // on CrossTask, so the memory-side atomic units do not queue); the sum of squares -- ONE row for everybody, where
 // per-chunk atomics serialise at ~0.09 TB/s (MI355X_MICROARCH.md, Global float atomics: contention) -- stays in
 // registers across all chunks of the wave, is reduced over the workgroup's waves in LDS and leaves once per workgroup.
+// VEC (D % 4 == 0): every lane loads its 4 columns as ONE 16-byte piece, unconditionally (lanes past the last column
+// re-read column 0 and are ignored) -- with the element-wise fallback in the same kernel the compiler if-converts both
+// paths into per-element conditional loads.
+template <bool VEC>
 __global__ void __launch_bounds__(256) smm_class_sums_kernel(SmmFitArgs a)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -87,48 +92,62 @@ __global__ void __launch_bounds__(256) smm_class_sums_kernel(SmmFitArgs a)
         const int ncol_total = min(256, d - c0);
         const int col = c0 + lane * 4;
         const int ncol = min(4, d - col);                       // <= 0: this lane has no columns in this pass
-        const bool vec = ncol == 4 && (d & 3) == 0;
+        const int colc = ncol > 0 ? col : 0;                    // (VEC: where an idle lane reads)
         double sq[4] = {0, 0, 0, 0};
-        for (int ch = blockIdx.x; ch < a.n_chunks; ch += gridDim.x) {
+        // work items of 512 rows (a quarter of a chunk; 128 rows per wave), dealt round-robin: ~5 per workgroup, so the
+        // last round costs a tenth of the launch instead of a third
+        for (int item = blockIdx.x; item < 4 * a.n_chunks; item += gridDim.x) {
+            const int ch = item >> 2;
             const int vi = smm_fit_find_video(a.cum, a.b, ch);
             const SmmFitVideo mv = a.videos[vi];
-            const int r0 = (ch - a.cum[vi]) * SMM_FIT_CHUNK + wv * (SMM_FIT_CHUNK / 4);
+            const int r0 = (ch - a.cum[vi]) * SMM_FIT_CHUNK + (item & 3) * (SMM_FIT_CHUNK / 4) + wv * (SMM_FIT_CHUNK / 16);
             if (r0 >= mv.T) continue;
-            const int r1 = min(mv.T, r0 + SMM_FIT_CHUNK / 4);
+            const int r1 = min(mv.T, r0 + SMM_FIT_CHUNK / 16);
             const float *x = a.x + (size_t)mv.frame_off * d;
             const int64_t *y = a.labels + mv.frame_off;
             double acc[4] = {0, 0, 0, 0};
             int64_t cur = y[r0];
-            for (int r = r0; r < r1; r += SMM_FIT_UNROLL) {
-                float v[SMM_FIT_UNROLL][4];
-                int64_t lab[SMM_FIT_UNROLL];
+            // two row buffers: the next 8 rows are in flight while these 8 are added up
+            float v[2][SMM_FIT_UNROLL][4];
+            int64_t lab[2][SMM_FIT_UNROLL];
+            auto fetch = [&](int r, float (&vv)[SMM_FIT_UNROLL][4], int64_t (&ll)[SMM_FIT_UNROLL]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
                     const int rr = min(r + u, r1 - 1);          // clamped: the tail re-reads the last row, then skips it
-                    lab[u] = y[rr];
-                    if (vec) {
-                        const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)rr * d + col);
-                        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+                    ll[u] = y[rr];
+                    if constexpr (VEC) {
+                        const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)rr * d + colc);
+                        vv[u][0] = q.x; vv[u][1] = q.y; vv[u][2] = q.z; vv[u][3] = q.w;
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[u][j] = j < ncol ? x[(size_t)rr * d + col + j] : 0.f;
+                        for (int j = 0; j < 4; ++j) vv[u][j] = j < ncol ? x[(size_t)rr * d + col + j] : 0.f;
                     }
                 }
+            };
+            auto consume = [&](int r, const float (&vv)[SMM_FIT_UNROLL][4], const int64_t (&ll)[SMM_FIT_UNROLL]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < SMM_FIT_UNROLL; ++u) {
                     if (r + u >= r1) break;
-                    if (lab[u] != cur) {                         // wave-uniform
+                    if (ll[u] != cur) {                          // wave-uniform
                         if (cur >= 0 && cur < a.n_classes) flush(acc, a.sum_x + (size_t)cur * d, c0, ncol_total);
                         acc[0] = acc[1] = acc[2] = acc[3] = 0;
-                        cur = lab[u];
+                        cur = ll[u];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const double xv = (double)v[u][j];
+                        const double xv = (VEC && ncol <= 0) ? 0.0 : (double)vv[u][j];
                         acc[j] += xv;
                         sq[j] += xv * xv;
                     }
                 }
+            };
+            fetch(r0, v[0], lab[0]);
+            for (int r = r0; r < r1; r += 2 * SMM_FIT_UNROLL) {
+                fetch(r + SMM_FIT_UNROLL, v[1], lab[1]);
+                consume(r, v[0], lab[0]);
+                if (r + SMM_FIT_UNROLL >= r1) break;
+                fetch(r + 2 * SMM_FIT_UNROLL, v[0], lab[0]);
+                consume(r + SMM_FIT_UNROLL, v[1], lab[1]);
             }
             if (cur >= 0 && cur < a.n_classes) flush(acc, a.sum_x + (size_t)cur * d, c0, ncol_total);
         }
@@ -282,9 +301,13 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
     a.max_k = max_k;
     a.b = b;
     a.n_chunks = (int32_t)n_chunks;
-    // class sums: a persistent grid of <= 4 workgroups per CU (fewer flushes of the one sum-of-squares row)
-    const int g_sum = (int)std::min<int64_t>(n_chunks, 1024);
-    hipLaunchKernelGGL(smm_class_sums_kernel, dim3(g_sum), dim3(256), 0, stream, a);
+    // class sums: a persistent grid of 3 workgroups per CU (what the kernel's 167 VGPRs admit: one resident round, and
+    // few flushes of the one sum-of-squares row)
+    int g_sum = 768;
+    if (const char *e = std::getenv("SMM_FIT_GRID")) g_sum = std::atoi(e);     // (tuning aid)
+    g_sum = (int)std::max<int64_t>(1, std::min<int64_t>(4 * n_chunks, g_sum));
+    if ((d & 3) == 0) hipLaunchKernelGGL(smm_class_sums_kernel<true>, dim3(g_sum), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(smm_class_sums_kernel<false>, dim3(g_sum), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(smm_span_stats_kernel, dim3((unsigned)n_chunks), dim3(256), sizeof(unsigned int) * n, stream, a);
     return hipGetLastError() == hipSuccess ? SMM_OK : SMM_ERR_HIP;
 }

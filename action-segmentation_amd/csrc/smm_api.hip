@@ -242,7 +242,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
                 // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few
                 // videos, CUs to spare); on a full GPU their third CU costs the one-CU videos more than it gains
                 // (measured on cfg3: 32 pairs 5.0 ms, 32 triples 5.4 ms)
-                if (n3 > n + (int)must.size() || (n3 > 8 && b + n + (int)must.size() + n3 > n_cu)) continue;
+                if (n3 > n + (int)must.size() || (n3 > 0 && b + n + (int)must.size() + n3 > n_cu)) continue;
                 build(n, n3);
                 const double t = simulate(n);
                 if (std::getenv("SMM_VERBOSE"))

@@ -475,6 +475,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
+    __shared__ int sh_guess[SMM_MAX_STATES_DEV + 1];   // back-trace: the predecessor state last seen / expected for each state
 
     if (T <= 0) return;
     if (spans)
@@ -893,8 +894,30 @@ smm_viterbi_kernel(SmmDpArgs a)
 #define SMM_BT_STAMP(acc) do { } while (0)
 #endif
     if (threadIdx.x == 0) { sh_kmin[0] = 0xffffffffu; sh_kmin[1] = 0xffffffffu; sh_kmin[2] = 0xffffffffu; }
-    __syncthreads();
+    // Phase B depends on phase A (which state's column to scan), and each is a round trip to a history that has long
+    // left the caches (4-5 us per segment under load).  The column of the state that preceded `to` the LAST time (at the
+    // start: the most likely one a priori, arg-max of its transition row) is therefore fetched SPECULATIVELY together
+    // with phase A's rows; when phase A confirms the guess -- nearly always on ordered tasks -- the segment costs one
+    // round trip.  Same expressions, same first-(k, state) order: a wrong guess only costs the second trip.
+    if (threadIdx.x <= (unsigned)C) {
+        const int t2 = threadIdx.x;
+        int bi = C - 1;
+        if (t2 < C) {
+            double bv = SMM_NEG_INF;
+            bi = 0;
+            for (int c2 = 0; c2 < C; ++c2) {
+                const double v2 = trans[(size_t)t2 * cm + c2];
+                if (v2 > bv) { bv = v2; bi = c2; }
+            }
+        } else if (endpen) {
+            for (int c2 = 0; c2 < C; ++c2)
+                if (endpen[c2] == 0.0) bi = c2;
+        }
+        sh_guess[t2] = bi;
+    }
     while (n > 0) {
+        __syncthreads();                                       // sh_guess (written at the end of the previous segment)
+        const int fg = sh_guess[to];
         const int kmax = (kp - 1 < n) ? kp - 1 : n;
         double wgt = 0.0, gmv = SMM_NEG_INF, cnl = 0.0;
         if (lane < C) {
@@ -903,6 +926,14 @@ smm_viterbi_kernel(SmmDpArgs a)
             cnl = hcum[(size_t)n * cm + lane];
             wgt = (to == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to * cm + lane];
             gmv = g0 + wgt;
+        }
+        // speculative first round of phase B for state fg (clamped, unconditional loads: same round trip as phase A)
+        double sp_h, sp_l;
+        {
+            const int kk0 = w * 64 + lane + 1;
+            const int kc = kk0 <= kmax ? kk0 : kmax;
+            sp_h = hh[(size_t)fg * (T + 1) + n - kc];
+            sp_l = len[(size_t)kc * cm + fg];
         }
         const double rmax = smm_row_max16(gmv);
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
@@ -919,7 +950,9 @@ smm_viterbi_kernel(SmmDpArgs a)
             for (int kb = 0; kb < lim; kb += NW * 64) {
                 const int kk = kb + w * 64 + lane + 1;
                 bool hit = false;
-                if (kk <= lim) hit = ((cn + (hcol[n - kk] + len[(size_t)kk * cm + f])) + wf) == best;
+                if (kb == 0 && f == fg) {                       // the guess was right: its first round is already here
+                    if (kk <= lim) hit = ((cn + (sp_h + sp_l)) + wf) == best;
+                } else if (kk <= lim) hit = ((cn + (hcol[n - kk] + len[(size_t)kk * cm + f])) + wf) == best;
                 const unsigned long long m = __ballot(hit);
                 const int slot = round % 3;
                 if (lane == 0 && m) atomicMin(&sh_kmin[slot], (unsigned)(kb + w * 64 + __ffsll(m)));
@@ -942,7 +975,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         const int64_t gid = cmap ? cmap[c] : c;
         if (labels)
             for (int f = s + threadIdx.x; f < n; f += blockDim.x) labels[f] = gid;
-        if (spans && threadIdx.x == 0) spans[s] = gid;
+        if (threadIdx.x == 0) {
+            if (spans) spans[s] = gid;
+            sh_guess[to] = c;                                   // (read behind the barrier at the top of the loop)
+        }
         ++nseg;
         n = s;
         to = c;

@@ -27,7 +27,7 @@ struct SmmDpArgs {
     const double *len;         // [g][k_rows][c_max]
     const double *endpen;      // [b][c_max] or null
     const int64_t *class_map;  // [g][c_max+1] or null
-    double *hist;              // per video: cum[c_max][T+1], h[c_max][T+1], gamma[T+1][c_max]
+    double *hist;              // per video (Viterbi): cum[T+1][C], h[C][T+1], gamma[T+1][C], gangs: A'_long[T+1][c_max]; C = the video's states
     int64_t *spans;            // [b][t_max+1] or null
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null

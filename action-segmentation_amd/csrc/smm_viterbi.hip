@@ -296,8 +296,8 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
     smm_follower_share(C, mv.nfol, fidx, cl, nf);
     if (nf <= 0) return;                                      // (the third workgroup of a gang whose video needs one follower)
     const double *len = a.len + (size_t)g * a.k_rows * cm;
-    double *hh = a.hist + mv.hist_off + (size_t)cm * (T + 1);
-    double *along = a.hist + mv.hist_off + (size_t)3 * cm * (T + 1);
+    double *hh = a.hist + mv.hist_off + (size_t)C * (T + 1);            // history rows are C wide (see the kernel), A'_long rows cm
+    double *along = a.hist + mv.hist_off + (size_t)3 * C * (T + 1);
     int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1 + fidx, *gang_fail = prog_h + 3;
     const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
     __shared__ __attribute__((aligned(16))) double f_h[2][BF][SMM_MAX_STATES_DEV];
@@ -457,10 +457,12 @@ smm_viterbi_kernel(SmmDpArgs a)
     const double *elp = a.elp + (size_t)mv.frame_off * cm;
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
     const int64_t *cmap = a.class_map ? a.class_map + (size_t)g * (cm + 1) : nullptr;
-    double *hcum = a.hist + mv.hist_off;                  // [T+1][cm]  cumE[n][c]
-    double *hh = hcum + (size_t)cm * (T + 1);             // [cm][T+1]  h[n][c], STATE-major: the back-trace scans one
+    // history of this video: rows are C wide (the video's own state count, not the launch's c_max: a launch that mixes
+    // 11- and 23-state tasks would otherwise write twice the bytes for the former)
+    double *hcum = a.hist + mv.hist_off;                  // [T+1][C]  cumE[n][c]
+    double *hh = hcum + (size_t)C * (T + 1);              // [C][T+1]  h[n][c], STATE-major: the back-trace scans one
                                                           // state's column over up to kp-1 positions per segment
-    double *hgam = hh + (size_t)cm * (T + 1);             // [T+1][cm]  gamma[n][c]
+    double *hgam = hh + (size_t)C * (T + 1);              // [T+1][C]  gamma[n][c]
     int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
     int64_t *labels = a.labels ? a.labels + mv.frame_off : nullptr;
 
@@ -647,7 +649,14 @@ smm_viterbi_kernel(SmmDpArgs a)
             lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
             mine[q] = lo[q] >= 0 && e % cm >= cl && e % cm < C;
         }
-        double *along = hgam + (size_t)cm * (T + 1);                       // fourth history array: A'_long rows of the follower
+        double *along = hgam + (size_t)C * (T + 1);                        // fourth history array: A'_long rows of the follower ([T+1][cm])
+        int slo[NE], srw[NE];                                              // history block element e (rows C wide) -> LDS offset, row
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            srw[q] = e / C;
+            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
+        }
         int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1;  // [1], [2]: follower 0, follower 1
         int32_t *gang_fail = prog_h + 3;
         const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
@@ -676,7 +685,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
             for (int x = 0; x < NE; ++x) {
                 const int e = lane + 64 * x;
-                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
             }
         };
         // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes), with
@@ -772,6 +781,13 @@ smm_viterbi_kernel(SmmDpArgs a)
             row[q] = e / cm;
             lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
         }
+        int slo[NE], srw[NE];                                              // history block element e (rows C wide) -> LDS offset, row
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            srw[q] = e / C;
+            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
+        }
         // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
         const int64_t e_last = (int64_t)T * cm - 1;
@@ -792,7 +808,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
             for (int x = 0; x < NE; ++x) {
                 const int e = lane + 64 * x;
-                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
             }
         };
         // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes)
@@ -922,8 +938,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         double wgt = 0.0, gmv = SMM_NEG_INF, cnl = 0.0;
         if (lane < C) {
             // one round trip for everything phase A and B need of position n: gamma row, cumE row, weights
-            const double g0 = hgam[(size_t)n * cm + lane];
-            cnl = hcum[(size_t)n * cm + lane];
+            const double g0 = hgam[(size_t)n * C + lane];
+            cnl = hcum[(size_t)n * C + lane];
             wgt = (to == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to * cm + lane];
             gmv = g0 + wgt;
         }

@@ -178,3 +178,25 @@ def test_no_eos_viterbi_and_log_likelihood_match_reference_path(golden):
     js, _ = m.log_likelihood(feats.float().to(dev), lengths.to(dev), vc, spans=r['spans'][:, :tmax].to(dev), add_eos=False)
     parts = O.to_parts(r['spans'][:, :tmax], scores.shape[-1], scores.shape[2], lengths)
     np.testing.assert_allclose(js.item(), (scores * parts).sum(dim=(1, 2, 3, 4)).mean().item(), rtol=1e-9, atol=1e-6)
+
+
+def test_span_codecs_run_on_the_device():
+    """labels_to_spans / spans_to_labels given device tensors stay on the device (reference semimarkov_utils.py:6-63;
+    the gradient-based supervised fit encodes every batch, semimarkov.py:251) and equal the host statement, including
+    the reference's own vectors (src/models/test_semimarkov.py:251-259)."""
+    from action_segmentation_amd import semimarkov_utils as U
+    dev = torch.device('cuda:0')
+    labels = torch.tensor([[0, 1, 1, 2, 2, 2], [0, 1, 2, 3, 3, 4]])
+    spans = torch.tensor([[0, 1, -1, 2, -1, -1], [0, 1, 2, 3, -1, 4]])
+    got = U.labels_to_spans(labels.to(dev), max_k=None)
+    assert got.is_cuda and torch.equal(got.cpu(), spans)
+    back = U.spans_to_labels(spans.to(dev))
+    assert back.is_cuda and torch.equal(back.cpu(), labels)
+    g = torch.Generator().manual_seed(3)
+    for max_k in (2, 5, 17, None):
+        runs = torch.randint(0, 6, (4, 40), generator=g)
+        lab = torch.repeat_interleave(runs, 7, dim=1)[:, :257]
+        host = U.labels_to_spans(lab, max_k)
+        devv = U.labels_to_spans(lab.to(dev), max_k)
+        assert torch.equal(devv.cpu(), host)
+        assert torch.equal(U.spans_to_labels(devv).cpu(), lab)

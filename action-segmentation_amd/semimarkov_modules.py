@@ -505,6 +505,8 @@ class SemiMarkovModule(nn.Module):
         ``differentiable``: built from the parameters with autograd history (training); otherwise the cached decode
         tables."""
         dev = pc.x.device
+        if differentiable and self.max_k > 1:
+            return self._stacked_tables_batched(pc, dev)
         if differentiable:
             tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
         else:
@@ -527,6 +529,65 @@ class SemiMarkovModule(nn.Module):
         if not differentiable:
             pc._stacked = (key, out, tabs)          # (tabs: keeps the ids alive)
         return out
+
+    def _stacked_tables_batched(self, pc, dev):
+        """The differentiable tables of ALL groups from ~25 batched torch ops (forward; as many backward) instead of a
+        dozen small ops per group: a training step over many tasks spends its host time here otherwise.  Same
+        formulas as ``factor_tables`` / reference :284-414 -- masks before the softmax, columns normalised over `to`,
+        Poisson length table, expanded Gaussian -- on index tensors padded to c_max (padded entries are excluded from
+        every normalisation and come out as 0; the kernels never read them)."""
+        f64 = torch.float64
+        ix = getattr(pc, '_group_index', None)
+        if ix is None or ix['dev'] != str(dev) or ix['merge'] != id(self.merge_classes):
+            n_states = [self.n_classes if g['valid_classes'] is None else len(g['valid_classes']) for g in pc.groups]
+            cm, ng = max(n_states), len(pc.groups)
+            vcp = torch.zeros((ng, cm), dtype=torch.long)
+            mvp = torch.zeros((ng, cm), dtype=torch.long)
+            valid = torch.zeros((ng, cm), dtype=torch.bool)
+            cmap = torch.zeros((ng, cm + 1), dtype=torch.long)
+            for i, (g, c) in enumerate(zip(pc.groups, n_states)):
+                vc = torch.arange(self.n_classes) if g['valid_classes'] is None else g['valid_classes'].long()
+                bad = [int(v) for v in vc if not 0 <= int(v) < self.n_classes]
+                if bad:
+                    raise IndexError("valid_classes %s outside the model's %d classes" % (bad, self.n_classes))
+                assert len(set(vc.tolist())) == c, "valid_classes must be unique"
+                vcp[i, :c] = vc
+                mvp[i, :c] = self._merged(vc)
+                valid[i, :c] = True
+                cmap[i, :c] = vc
+                cmap[i, c] = self.n_classes
+            ix = pc._group_index = dict(dev=str(dev), merge=id(self.merge_classes), n_states=n_states, cm=cm,
+                                        vcp=vcp.to(dev), mvp=mvp.to(dev), valid=valid.to(dev), cmap=cmap.to(dev))
+        vcp, mvp, valid, cm = ix['vcp'], ix['mvp'], ix['valid'], ix['cm']
+        neg_inf = float('-inf')
+        # initial (reference :284-296)
+        il = self.init_logits.to(f64)
+        if self.init_constraints is not None:
+            il = il.masked_fill(self.init_constraints, BIG_NEG)
+        init = F.log_softmax(il[vcp].masked_fill(~valid, neg_inf), dim=1).masked_fill(~valid, 0.0)
+        # transitions [to, from] (reference :298-322): every column normalised over the valid `to`
+        tl = self.transition_logits.to(f64)
+        if self.transition_constraints is not None:
+            tl = tl.masked_fill(self.transition_constraints, BIG_NEG)
+        tm = tl[vcp.unsqueeze(2), vcp.unsqueeze(1)]                           # [G, to, from]
+        if not self.allow_self_transitions:
+            tm = tm.masked_fill(torch.eye(cm, device=dev, dtype=torch.bool).unsqueeze(0), BIG_NEG)
+        tm = tm.masked_fill(~valid.unsqueeze(2), neg_inf)
+        trans = F.log_softmax(tm, dim=1).masked_fill(~(valid.unsqueeze(2) & valid.unsqueeze(1)), 0.0)
+        # lengths (reference :383-414): Poisson(rate).log_prob(k), row == length
+        lr = self.poisson_log_rates.to(f64)[mvp]                                # [G, cm]
+        k = torch.arange(self.max_k, device=dev, dtype=f64).view(1, -1, 1)
+        rate = torch.exp(lr).unsqueeze(1)
+        lens = (torch.xlogy(k, rate) - rate - torch.lgamma(k + 1)).masked_fill(~valid.unsqueeze(1), 0.0)
+        # emission factors (reference :324-381 in expanded form)
+        var = torch.diagonal(self.gaussian_cov).to(f64)
+        mu = self.gaussian_means.to(f64)[mvp]                                   # [G, cm, D]
+        d = mu.size(2)
+        w = (mu / var).transpose(1, 2).masked_fill(~valid.unsqueeze(1), 0.0).contiguous()          # [G, D, cm]
+        cst = (-0.5 * (mu * mu / var).sum(2) - 0.5 * var.log().sum() - 0.5 * d * math.log(2 * math.pi)).masked_fill(~valid, 0.0)
+        st = dict(trans=trans.contiguous(), init=init.contiguous(), len=lens.contiguous(), w=w, cst=cst.contiguous(),
+                  inv_var=(1.0 / var).contiguous(), class_map=ix['cmap'])
+        return st, ix['n_states'], cm, self.max_k
 
     def prepare_packed(self, pc, differentiable=False):
         """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns, and

@@ -96,3 +96,48 @@ def test_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(_lib.SYMBOLS) == declared
     assert lib.smm_strerror(0) == b'ok' and b'workspace' in lib.smm_strerror(-3)
+
+
+@pytest.mark.parametrize('constrain', [False, True])
+def test_batched_group_tables_equal_per_group_tables(constrain):
+    """The batched construction of all groups' factor tables (training path: ~25 torch ops for any number of tasks)
+    equals factor_tables group by group, in value and in gradient."""
+    from action_segmentation_amd import synth
+    from action_segmentation_amd.batching import make_data_loader, pack_batches
+    from action_segmentation_amd.semimarkov import SemiMarkovModel
+    data = synth.SynthDatasplit('tiny', seed=12)
+    args = synth.make_args(data.max_k, cuda=False, batch_size=2, sm_constrain_transitions=constrain,
+                           annotate_background_with_previous=constrain)
+    model = SemiMarkovModel.from_args(args, data)
+    m = model.model
+    with torch.no_grad():
+        m.gaussian_means.normal_(0, 0.3)
+        m.poisson_log_rates.uniform_(1.0, 2.0)
+        m.transition_logits.normal_()
+    pc = pack_batches(list(make_data_loader(args, data, shuffle=False, batch_by_task=True, batch_size=2)), 'cpu', m.max_k)
+    cpu = torch.device('cpu')
+    st, ns, cm, k = m._stacked_tables_batched(pc, cpu)
+    names = ('trans', 'init', 'len', 'w', 'cst')
+    def cut(n, t, gi, c):
+        if n == 'trans':
+            return t[gi, :c, :c]
+        return t[gi, :, :c] if n in ('len', 'w') else t[gi, :c]
+    g = torch.Generator().manual_seed(0)
+    coef = {n: torch.randn(st[n].shape, generator=g, dtype=torch.float64) for n in names}
+    m.zero_grad()
+    sum((st[n] * coef[n]).sum() for n in names).backward()
+    gb = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    tot = 0
+    for gi, grp in enumerate(pc.groups):
+        t = m.factor_tables(grp['valid_classes'], cpu)
+        c = ns[gi]
+        assert t['init'].numel() == c
+        for n in names:
+            torch.testing.assert_close(cut(n, st[n], gi, c), t[n], rtol=1e-13, atol=1e-13)
+            tot = tot + (t[n] * cut(n, coef[n], gi, c)).sum()
+        assert torch.equal(st['class_map'][gi, :c + 1], t['class_map'])
+    tot.backward()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(gb[n], p.grad, rtol=1e-5, atol=1e-6)

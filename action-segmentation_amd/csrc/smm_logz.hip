@@ -40,7 +40,10 @@
 #define SMM_M_EMPTY (-1e30f)     // exponent of an empty slot (finite: M - M' must never be inf - inf)
 
 #ifndef SMM_LZ_B
-#define SMM_LZ_B 4               // positions per hand-over block
+#define SMM_LZ_B 4               // positions per hand-over block (long rings)
+#endif
+#ifndef SMM_LZ_B2_MAX_R
+#define SMM_LZ_B2_MAX_R 2        // rings of up to 64 * this many slots hand over in blocks of 2
 #endif
 
 __device__ __forceinline__ float smm_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -136,11 +139,13 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
-template <int R, int SPW, int NW, int HF>
+// B   positions per hand-over block (K0 = 2 B lengths stay with the chain wave): 4 where the pushers bound the frame time
+//     (long rings: the per-block rescaling of a slot amortises over more candidates), 2 where the chain wave does
+//     (short rings: half the candidates folded serially per position)
+template <int R, int SPW, int NW, int HF, int B>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_logz_kernel(SmmDpArgs a, double *logz)
 {
-    constexpr int B = SMM_LZ_B;
     constexpr int K0 = 2 * B;                              // segment lengths the chain wave evaluates itself (D = 1)
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
@@ -442,8 +447,9 @@ template <int R, int SPW>
 static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int c_need, hipStream_t stream)
 {
     if (spw != SPW) return 0;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8>), dim3(a.b), dim3(512), 0, stream, a, logz);
-    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16>), dim3(a.b), dim3(512), 0, stream, a, logz);
+    constexpr int B = (R <= SMM_LZ_B2_MAX_R) ? 2 : SMM_LZ_B;
+    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8, B>), dim3(a.b), dim3(512), 0, stream, a, logz);
+    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16, B>), dim3(a.b), dim3(512), 0, stream, a, logz);
     return 1;
 }
 

@@ -22,6 +22,7 @@ class SmmShape(ctypes.Structure):
 
 
 SHAPE_NO_EOS = 1
+SHAPE_LOGZ_BOTH = 2
 
 
 class SmmEvalShape(ctypes.Structure):

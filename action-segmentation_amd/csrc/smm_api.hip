@@ -488,6 +488,16 @@ extern "C" int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host,
     a.hist = st.hist; a.err = st.err;
     a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
     if (shape->flags & SMM_SHAPE_NO_EOS) { a.flags |= 8; a.endpen = nullptr; }
+    if (shape->flags & SMM_SHAPE_LOGZ_BOTH) {
+        // forward and time-reversed recursion in one launch: the transposed tables and the reversed runs' closing values
+        // live where smm_logz_bwd_f64 keeps them
+        const size_t g = shape->n_groups, cm = shape->c_max;
+        double *trans_t = st.tabs;
+        smm_launch_transpose(trans, trans_t, (int)g, (int)cm, hs);
+        a.trans_t = trans_t;
+        a.logz_b = trans_t + g * cm * cm;
+        a.flags |= 64;
+    }
     rc = smm_launch_logz(a, logz, ring_regs(st.kp_max), st.c_need, hs);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());
@@ -510,17 +520,19 @@ extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_h
     const size_t g = shape->n_groups, cm = shape->c_max;
     double *trans_t = st.tabs;                 // [g][cm][cm] transposed
     double *logz_b = trans_t + g * cm * cm;    // [b] log Z as closed by the backward recursion (consistency value)
-    smm_launch_transpose(trans, trans_t, (int)g, (int)cm, hs);
-    SmmDpArgs a{};
-    a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
-    a.elp = elp; a.trans = trans_t; a.init = init; a.len = len_scores; a.endpen = endpen;
-    a.hist = st.hist; a.err = st.err;
-    a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
-    a.flags = 2;                               // time-reversed run -> backward messages in the second history half
     const bool no_eos = (shape->flags & SMM_SHAPE_NO_EOS) != 0;
-    if (no_eos) { a.flags |= 8; a.endpen = nullptr; }
-    rc = smm_launch_logz(a, logz_b, ring_regs(st.kp_max), st.c_need, hs);
-    if (rc != SMM_OK) return rc;
+    if (!(shape->flags & SMM_SHAPE_LOGZ_BOTH)) {   // (else: smm_logz_f64 already ran the reversed recursion)
+        smm_launch_transpose(trans, trans_t, (int)g, (int)cm, hs);
+        SmmDpArgs a{};
+        a.videos = st.videos; a.order = st.order; a.n_states = st.n_states;
+        a.elp = elp; a.trans = trans_t; a.init = init; a.len = len_scores; a.endpen = endpen;
+        a.hist = st.hist; a.err = st.err;
+        a.c_max = shape->c_max; a.k_rows = shape->k_rows; a.t_max = shape->t_max; a.b = shape->b;
+        a.flags = 2;                               // time-reversed run -> backward messages in the second history half
+        if (no_eos) { a.flags |= 8; a.endpen = nullptr; }
+        rc = smm_launch_logz(a, logz_b, ring_regs(st.kp_max), st.c_need, hs);
+        if (rc != SMM_OK) return rc;
+    }
     SMM_HIP(hipMemsetAsync(g_trans, 0, sizeof(double) * g * cm * cm, hs));
     SMM_HIP(hipMemsetAsync(g_init, 0, sizeof(double) * g * cm, hs));
     SMM_HIP(hipMemsetAsync(g_len, 0, sizeof(double) * g * shape->k_rows * cm, hs));

@@ -37,8 +37,11 @@ struct SmmDpArgs {
     int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
                                // backward; bit 2: every video with more than 21 states is in the paired prefix;
                                // bit 3 (8): no EOS (add_eos=False; SmmVideo::T = frames - 1); bit 4 (16): recovery launch
-                               // behind a gang launch; bit 5 (32): test hook -- gang 0's followers never show up
+                               // behind a gang launch; bit 5 (32): test hook -- gang 0's followers never show up;
+                               // bit 6 (64): logZ forward and time-reversed runs in one launch (2 workgroups per video)
     int32_t n_pairs;           // the first n_pairs entries of order[] run as leader / follower pairs (smm_viterbi.hip)
+    const double *trans_t;     // logZ, both directions in one launch (flags bit 6): transposed tables [g][c_max][c_max]
+    double *logz_b;            // ... and where the reversed runs put their closing value [b]
     int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
 };
 

@@ -151,7 +151,9 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
     constexpr int MQ = 4 * B;                              // chain wave: h[n] of the last MQ > K0 positions, slot n mod MQ
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
-    const int vid = a.order[blockIdx.x];
+    // flags bit 6: two workgroups per video, the second one runs the time-reversed recursion (independent of the first)
+    const bool both = (a.flags & 64) != 0;
+    const int vid = a.order[both ? blockIdx.x >> 1 : blockIdx.x];
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T - ((a.flags & 8) ? 1 : 0);   // no EOS: the DP covers the frames before the last one (smmdp.h)
     const int g = mv.group;
@@ -161,16 +163,17 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
-    const double *trans = a.trans + (size_t)g * cm * cm;
+    const bool bwd = (a.flags & 2) != 0 || (both && (blockIdx.x & 1));
+    const double *trans = ((both && bwd) ? a.trans_t : a.trans) + (size_t)g * cm * cm;
     const double *init = a.init + (size_t)g * cm;
     const double *len = a.len + (size_t)g * a.k_rows * cm;
     const double *elp = a.elp + (size_t)mv.frame_off * cm;
     const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
-    // bwd (a.flags bit 1): the same recursion on the time-reversed video with the transposed transition table gives
+    if (both && bwd) logz = a.logz_b;
+    // bwd (a.flags bit 1, or the odd workgroups of a two-direction launch): the same recursion on the time-reversed video with the transposed transition table gives
     // the backward messages (see smm_logz_bwd.hip); its history goes to the second half of the video's block.
     // no_eos (a.flags bit 3): add_eos=False of the reference (modules:494-505): T counts the frames BEFORE the last one;
     // the video closes with a transition into the label of frame T, which only emits (no length score, no EOS).
-    const bool bwd = (a.flags & 2) != 0;
     const bool no_eos = (a.flags & 8) != 0;
     double *hcum = a.hist + mv.hist_off + (bwd ? (size_t)3 * cm * (T + 1) : 0);   // [T+1][cm]  cumE[n][c]
     double *hh = hcum + (size_t)cm * (T + 1);             // [T+1][cm]  h[n][c]   (log-weight of "a span of c starts at n" - cumE)
@@ -448,8 +451,9 @@ static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int c_need,
 {
     if (spw != SPW) return 0;
     constexpr int B = (R <= SMM_LZ_B2_MAX_R) ? 2 : SMM_LZ_B;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8, B>), dim3(a.b), dim3(512), 0, stream, a, logz);
-    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16, B>), dim3(a.b), dim3(512), 0, stream, a, logz);
+    const dim3 grid((a.flags & 64) ? 2 * a.b : a.b);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8, B>), grid, dim3(512), 0, stream, a, logz);
+    else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16, B>), grid, dim3(512), 0, stream, a, logz);
     return 1;
 }
 

@@ -178,10 +178,21 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
     return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=_err_view(batch, ws))
 
 
-def logz(batch, elp, trans, init, len_scores, endpen=None, ws=None):
+def _shape_with(batch, extra_flags):
+    """The batch's smm_shape with extra SMM_SHAPE_* bits for one call."""
+    if not extra_flags:
+        return batch.shape
+    s = batch.shape
+    return SmmShape(s.b, s.d, s.n_groups, s.c_max, s.k_rows, s.t_max, s.flags | extra_flags, s.total_frames)
+
+
+def logz(batch, elp, trans, init, len_scores, endpen=None, ws=None, with_backward=False):
     """Log-partition per video (smm_logz_f64).  elp fp64 [total_frames, c_max] -> logZ fp64 [b].
-    ``ws``: a private uint8 workspace tensor (keep it for ``logz_bwd``); default: the shared per-stream one."""
+    ``ws``: a private uint8 workspace tensor (keep it for ``logz_bwd``); default: the shared per-stream one.
+    ``with_backward``: run the time-reversed recursion in the same launch (SMM_SHAPE_LOGZ_BOTH); pass the same to
+    ``logz_bwd``."""
     lib = _lib.load()
+    shape = _shape_with(batch, _lib.SHAPE_LOGZ_BOTH if with_backward else 0)
     dev = elp.device
     f64 = torch.float64
     out = torch.empty(batch.b, dtype=f64, device=dev)
@@ -189,17 +200,19 @@ def logz(batch, elp, trans, init, len_scores, endpen=None, ws=None):
         ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(lib.smm_logz_f64(
-        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.byref(shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
         ctypes.c_void_p(ns), _dev(elp, f64, 'elp'), _dev(trans, f64, 'trans'), _dev(init, f64, 'init'),
         _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'), _dev(out, f64, 'logz'),
         ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     return out
 
 
-def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endpen=None, ws=None):
+def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endpen=None, ws=None, with_backward=False):
     """Gradient of sum_i grad_logz[i] * logZ_i (smm_logz_bwd_f64).  Must follow ``logz`` for the same batch with the
-    same workspace (same device + stream).  -> dict(elp [total_frames, c_max], trans, init, len) fp64."""
+    same workspace (same device + stream).  -> dict(elp [total_frames, c_max], trans, init, len) fp64.
+    ``with_backward``: ``logz`` was called with it (the backward messages are already in the workspace)."""
     lib = _lib.load()
+    shape = _shape_with(batch, _lib.SHAPE_LOGZ_BOTH if with_backward else 0)
     dev = elp.device
     f64 = torch.float64
     g = dict(elp=torch.empty_like(elp), trans=torch.empty_like(trans), init=torch.empty_like(init),
@@ -208,7 +221,7 @@ def logz_bwd(batch, elp, trans, init, len_scores, logz_val, grad_logz=None, endp
         ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
     _lib.check(lib.smm_logz_bwd_f64(
-        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
+        ctypes.byref(shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(kp),
         ctypes.c_void_p(ns), _dev(elp, f64, 'elp'), _dev(trans, f64, 'trans'), _dev(init, f64, 'init'),
         _dev(len_scores, f64, 'len_scores'), _dev(endpen, f64, 'endpen'), _dev(logz_val, f64, 'logz'),
         _dev(grad_logz, f64, 'grad_logz'), _dev(g['elp'], f64, 'g_elp'), _dev(g['trans'], f64, 'g_trans'),

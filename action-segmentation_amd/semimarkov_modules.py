@@ -52,8 +52,11 @@ class _LogPartition(torch.autograd.Function):
     def forward(ctx, batch, runs, x, cons, endpen, w, cst, inv_var, trans, init, len_scores):
         ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=x.device)   # private: survives until backward
         elp64, _ = ops.emission(batch, x, w, cst, inv_var, cons=cons)
-        z = ops.logz(batch, elp64, trans, init, len_scores, endpen=endpen, ws=ws)
-        ctx.batch, ctx.endpen, ctx.ws, ctx.runs = batch, endpen, ws, runs
+        # a gradient will be asked for: the time-reversed recursion (independent of the forward one) rides in the same
+        # launch, one more workgroup per video
+        both = any(ctx.needs_input_grad)
+        z = ops.logz(batch, elp64, trans, init, len_scores, endpen=endpen, ws=ws, with_backward=both)
+        ctx.batch, ctx.endpen, ctx.ws, ctx.runs, ctx.both = batch, endpen, ws, runs, both
         ctx.save_for_backward(x, elp64, trans, init, len_scores, z)
         return z
 
@@ -61,7 +64,7 @@ class _LogPartition(torch.autograd.Function):
     def backward(ctx, gz):
         x, elp64, trans, init, len_scores, z = ctx.saved_tensors
         g = ops.logz_bwd(ctx.batch, elp64, trans, init, len_scores, z, grad_logz=gz.to(torch.float64).contiguous(),
-                         endpen=ctx.endpen, ws=ctx.ws)
+                         endpen=ctx.endpen, ws=ctx.ws, with_backward=ctx.both)
         ge = g['elp']                                   # [frames, C]: posterior state occupancy x upstream
         n_groups, d, cm = trans.size(0), x.size(1), ge.size(1)
         g_w = torch.zeros((n_groups, d, cm), dtype=torch.float64, device=x.device)

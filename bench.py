@@ -439,9 +439,10 @@ def train_step_rate(args, data, model):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         st = torch.cuda.current_stream()
         e[0].record(st)
-        z = ops.logz(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], endpen=pc.endpen, ws=ws)
+        # (as the autograd function launches them: forward and time-reversed recursion in ONE launch, then the marginals)
+        z = ops.logz(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], endpen=pc.endpen, ws=ws, with_backward=True)
         e[1].record(st)
-        ops.logz_bwd(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], z, endpen=pc.endpen, ws=ws)
+        ops.logz_bwd(pc.batch, elp64, tt['trans'], tt['init'], tt['len'], z, endpen=pc.endpen, ws=ws, with_backward=True)
         e[2].record(st)
         torch.cuda.synchronize()
         return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])

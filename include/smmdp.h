@@ -75,6 +75,10 @@ typedef struct smm_shape {
  * frame T-1, which contributes its emission only (no length score); end penalties do not apply (endpen is ignored).
  * Viterbi: spans[i][T-1] holds that label and no EOS id is written; log Z and its gradient likewise.  lengths[i] >= 2. */
 #define SMM_SHAPE_NO_EOS 1
+/* smm_logz_f64 only: also run the time-reversed recursion (the backward messages smm_logz_bwd_f64 needs) in the SAME
+ * launch, one extra workgroup per video.  The two directions are independent, so a batch that does not fill the GPU
+ * gets its gradient's DP for free; pass the same flag to smm_logz_bwd_f64, which then skips its own reversed run. */
+#define SMM_SHAPE_LOGZ_BOTH 2
 
 const char *smm_strerror(int status);
 int smm_last_hip_error(void);

@@ -509,3 +509,26 @@ def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):
     assert ops.gang_timeouts_repaired == before + words[2]
     spans, v = run_oracle(p)
     check(p, {k_: v_.cpu().numpy() for k_, v_ in out.items() if k_ in ('best', 'spans', 'labels', 'n_segs')}, spans, v)
+
+
+@pytest.mark.parametrize('shape', [(3, 40, 6, 8), (2, 300, 17, 130), (4, 70, 5, 20), (2, 1030, 21, 1024)])
+def test_logz_both_directions_in_one_launch(shape):
+    """SMM_SHAPE_LOGZ_BOTH: the time-reversed recursion rides in the forward launch (one more workgroup per video);
+    log Z and every gradient are the bits of the two-launch path."""
+    ops = _ops()
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 1000 + 5, b, tmax, c, k, ends=True)
+    dev = torch.device('cuda:0')
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
+    args = (t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    res = []
+    for both in (False, True):
+        ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=dev)
+        z = ops.logz(batch, *args, endpen=t(p['endpen']), ws=ws, with_backward=both)
+        g = ops.logz_bwd(batch, *args, z, endpen=t(p['endpen']), ws=ws, with_backward=both)
+        torch.cuda.synchronize()
+        res.append((z.cpu().numpy(), {k_: v.cpu().numpy() for k_, v in g.items()}))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    for k_ in res[0][1]:
+        np.testing.assert_allclose(res[1][1][k_], res[0][1][k_], rtol=1e-12, atol=1e-15, err_msg=k_)   # (atomics: order of sums)

@@ -62,6 +62,9 @@ def parse(argv=None):
     p.add_argument('--strong-leg', action='store_true', help='run the strong-scaling leg with one rank too')
     p.add_argument('--no-strong-leg', action='store_true')
     p.add_argument('--no-predict-e2e', action='store_true', help='skip the SemiMarkovModel.predict wall-time figures')
+    p.add_argument('--second-seed', type=int, default=1000,
+                   help='N = 1, cfg3 only: also time the decode of the corpus of this seed (round 1\'s default draw, 11..21 '
+                        'states: no forced gangs) and report it beside the headline; negative: skip')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help="collectives: 'nccl' = RCCL (required for a measurement); 'gloo' only for rehearsals")
     p.add_argument('--share-gpus', action='store_true',
@@ -672,6 +675,15 @@ def main():
                 res["cpu_factored"] = cpu_factored(pc, model)
             except Exception as e:                              # the C oracle needs gcc on the box; report, don't fail
                 res["cpu_factored"] = {"error": str(e)}
+        if world == 1 and a.workload == 'cfg3' and a.second_seed >= 0 and a.second_seed != a.seed and a.scale == 1.0:
+            # the other draw of states per task (not the headline: same shapes, friendlier state counts)
+            data2 = synth.SynthDatasplit(a.workload, seed=a.second_seed, device=dev)
+            _, model2 = fit_model(a, cfg, data2, dev, D, world)
+            pc2 = model2.prepare(data2)
+            dt2, dp2, _ = timed_decode(a, pc2, world)
+            res["other_draw"] = {"seed": a.second_seed, "value": pc2.n_frames * a.steps / dt2, "unit": "frames/s",
+                                 "ms_per_step": dt2 / a.steps * 1e3, "dp_kernel_ms": dp2, "frames": pc2.n_frames,
+                                 "states_per_task": ' '.join(str(c) for c in sorted(pc2.n_states))}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

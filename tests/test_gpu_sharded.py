@@ -151,3 +151,28 @@ def test_bench_two_ranks_rccl():
     two = _bench(['--gpus', '2'] + common)
     assert two['n_gpus'] == 2 and two['backend'] == 'nccl'
     assert one['strong_scaling']['stats'] == two['strong_scaling']['stats']
+
+
+def test_bench_under_torchrun_launcher():
+    """The driver's launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (ranks from the environment; here two ranks on the box's one GPU over gloo)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpus',
+           '--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--no-predict-e2e', '--seed', '5']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['strong_scaling']['n_gpus'] == 2 and line['scaling'] == 'weak'
+    one = _bench(['--gpus', '1', '--strong-leg', '--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1',
+                  '--no-cpu-baseline', '--no-predict-e2e', '--seed', '5'])
+    assert one['strong_scaling']['stats'] == line['strong_scaling']['stats']

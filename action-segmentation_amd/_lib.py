@@ -9,7 +9,7 @@ SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
     "smm_error_word_offset",
     "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
-    "smm_dense_workspace_bytes", "smm_dense_dp_f32",
+    "smm_dense_workspace_bytes", "smm_dense_dp_f32", "smm_dense_marginals_f32",
     "smm_eval_workspace_bytes", "smm_eval_confusion_i64", "smm_eval_videos_i64",
     "smm_fit_workspace_bytes", "smm_fit_error_word_offset", "smm_fit_stats_f64",
 ]

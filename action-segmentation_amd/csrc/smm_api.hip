@@ -561,6 +561,7 @@ extern "C" size_t smm_dense_workspace_bytes(int32_t b, int32_t n1, int32_t k, in
     dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c);
     dense_off(cur, (size_t)b * n1 * k * c);
     dense_off(cur, sizeof(uint16_t) * (size_t)b * (n1 + 1) * c);
+    dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c);      // backward messages (smm_dense_marginals_f32)
     return cur;
 }
 
@@ -586,6 +587,32 @@ extern "C" int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host
     a.edge = scores; a.lengths = dlen; a.v = v; a.spans = spans;
     a.b = b; a.n1 = n1; a.k = k; a.c = c;
     smm_launch_dense(a, semiring != 0, hs);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
+}
+
+extern "C" int smm_dense_marginals_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k,
+                                       int32_t c, const double *v, const double *grad_v, float *marginals, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    if (!scores || !lengths_host || !v || !marginals || !workspace || b < 1 || n1 < 1 || k < 1 || c < 1) return SMM_ERR_ARG;
+    if (c > 255 || k > 65535) return SMM_ERR_UNSUPPORTED;
+    if (workspace_bytes < smm_dense_workspace_bytes(b, n1, k, c)) return SMM_ERR_WORKSPACE;
+    for (int i = 0; i < b; ++i)
+        if (lengths_host[i] < 1 || lengths_host[i] > n1 + 1) return SMM_ERR_ARG;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(workspace);
+    size_t cur = 0;
+    SmmDenseArgs a{};
+    int64_t *dlen = reinterpret_cast<int64_t *>(base + dense_off(cur, sizeof(int64_t) * b));
+    a.alpha = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * k * k * c));
+    a.beta = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c));
+    dense_off(cur, (size_t)b * n1 * k * c);
+    dense_off(cur, sizeof(uint16_t) * (size_t)b * (n1 + 1) * c);
+    double *rmsg = reinterpret_cast<double *>(base + dense_off(cur, sizeof(double) * (size_t)b * (n1 + 1) * c));
+    a.edge = scores; a.lengths = dlen; a.v = const_cast<double *>(v);
+    a.b = b; a.n1 = n1; a.k = k; a.c = c;
+    smm_launch_dense_marginals(a, rmsg, grad_v, marginals, hs);     // (dlen, beta: left by smm_dense_dp_f32, semiring 1)
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }

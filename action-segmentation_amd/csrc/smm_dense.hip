@@ -95,6 +95,78 @@ __global__ void __launch_bounds__(1024) smm_dense_kernel(SmmDenseArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ posterior marginals
+// d logZ / d edge[n, k, to, from] = exp( beta[n][from] + edge[n, k, to, from] + R[n + k][to] - logZ ): what autograd
+// through torch_struct's LogSemiring DP gives the reference (semimarkov.py:286 through modules:624-657), for code that
+// trains through the dense interface.  beta is what the forward kernel left in the workspace;
+//   R[m][to] = log-weight of everything behind "a span of `to` starts at position m":   R[L-1][.] = 0,
+//   R[n][from] = LSE_{k >= 1, n + k <= L - 1, to} ( edge[n, k, to, from] + R[n + k][to] ).
+// One workgroup per instance walks n downwards (thread = (from, slice of the (k, to) pairs), slices merged in LDS);
+// a second, fully parallel kernel writes the marginals.
+__global__ void __launch_bounds__(1024) smm_dense_backward_kernel(SmmDenseArgs a, double *rmsg)
+{
+    const int i = blockIdx.x;
+    const int N1 = a.n1, K = a.k, C = a.c;
+    const int L = (int)a.lengths[i];
+    const float *edge = a.edge + (size_t)i * N1 * K * C * C;
+    double *R = rmsg + (size_t)i * (N1 + 1) * C;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int parts = nth / C > 0 ? nth / C : 1;               // slices of the (k, to) pairs per `from`
+    extern __shared__ double sh[];                              // [parts][C] partial log-sums
+    for (int c = tid; c < (N1 + 1) * C; c += nth) R[c] = (c / C == L - 1) ? 0.0 : SMM_NEG_INF;
+    __syncthreads();
+    const int from = tid % C, part = tid / C;
+    for (int n = L - 2; n >= 0; --n) {
+        double acc = SMM_NEG_INF;
+        if (part < parts) {
+            const int kmax = (K - 1 < L - 1 - n) ? K - 1 : L - 1 - n;
+            const int terms = kmax * C;                         // (k - 1) * C + to
+            for (int q = part; q < terms; q += parts) {
+                const int k = 1 + q / C, to = q - (k - 1) * C;
+                const double v = (double)edge[(((size_t)n * K + k) * C + to) * C + from] + R[(size_t)(n + k) * C + to];
+                acc = smm_lse2d(acc, v);
+            }
+            sh[part * C + from] = acc;
+        }
+        __syncthreads();
+        if (tid < C) {
+            double r = SMM_NEG_INF;
+            for (int p2 = 0; p2 < parts; ++p2) r = smm_lse2d(r, sh[p2 * C + tid]);
+            R[(size_t)n * C + tid] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// grid (n, instance); threads stride over (k, to, from)
+__global__ void __launch_bounds__(256) smm_dense_marginals_kernel(SmmDenseArgs a, const double *rmsg, const double *grad_v, float *out)
+{
+    const int n = blockIdx.x, i = blockIdx.y;
+    const int N1 = a.n1, K = a.k, C = a.c;
+    const int L = (int)a.lengths[i];
+    const size_t base = ((size_t)i * N1 + n) * K * C * C;
+    const double *beta = a.beta + (size_t)i * (N1 + 1) * C + (size_t)n * C;
+    const double *R = rmsg + (size_t)i * (N1 + 1) * C;
+    const double lz = a.v[i];
+    const double up = grad_v ? grad_v[i] : 1.0;
+    for (int q = threadIdx.x; q < K * C * C; q += blockDim.x) {
+        const int k = q / (C * C), to = (q / C) % C, from = q % C;
+        double m = 0.0;
+        if (k >= 1 && n + k <= L - 1)
+            m = up * exp(beta[from] + (double)a.edge[base + q] + R[(size_t)(n + k) * C + to] - lz);
+        out[base + q] = (float)m;
+    }
+}
+
+void smm_launch_dense_marginals(const SmmDenseArgs &a, double *rmsg, const double *grad_v, float *out, hipStream_t stream)
+{
+    int threads = a.k * a.c;
+    threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : ((threads + 63) / 64) * 64);
+    const int parts = threads / a.c > 0 ? threads / a.c : 1;
+    hipLaunchKernelGGL(smm_dense_backward_kernel, dim3(a.b), dim3(threads), sizeof(double) * parts * a.c, stream, a, rmsg);
+    hipLaunchKernelGGL(smm_dense_marginals_kernel, dim3(a.n1, a.b), dim3(256), 0, stream, a, rmsg, grad_v, out);
+}
+
 void smm_launch_dense(const SmmDenseArgs &a, bool log_semiring, hipStream_t stream)
 {
     int threads = a.k * a.c;

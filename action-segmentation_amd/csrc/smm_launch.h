@@ -66,3 +66,5 @@ struct SmmDenseArgs {
     int32_t b, n1, k, c;
 };
 void smm_launch_dense(const SmmDenseArgs &a, bool log_semiring, hipStream_t stream);
+// posterior edge marginals (x upstream gradient) from the beta a LogSemiring smm_launch_dense left in a.beta and a.v
+void smm_launch_dense_marginals(const SmmDenseArgs &a, double *rmsg, const double *grad_v, float *out, hipStream_t stream);

@@ -180,6 +180,15 @@ int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const 
 size_t smm_dense_workspace_bytes(int32_t b, int32_t n1, int32_t k, int32_t c);
 int smm_dense_dp_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k, int32_t c,
                      int32_t semiring, double *v, int64_t *spans, void *workspace, size_t workspace_bytes, void *stream);
+/* Posterior edge marginals of the dense lattice = d sum_i grad_v[i] * logZ_i / d scores -- the gradient the reference
+ * obtains by autograd through torch_struct's LogSemiring DP (src/models/semimarkov/semimarkov.py:286 through
+ * semimarkov_modules.py:624-657).  Must follow smm_dense_dp_f32(semiring = 1) on the same scores with the SAME
+ * workspace (its forward messages are read from there); v = that call's output.
+ *   grad_v     dev fp64 [b] upstream gradient (NULL = ones)
+ *   marginals  dev fp32 [b][n1][k][c][c], overwritten (0 outside each instance's lattice) */
+int smm_dense_marginals_f32(const float *scores, const int64_t *lengths_host, int32_t b, int32_t n1, int32_t k, int32_t c,
+                            const double *v, const double *grad_v, float *marginals,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Evaluation counters of decoded frame labels against ground truth -- the per-frame loops of the reference's

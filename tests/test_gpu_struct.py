@@ -63,3 +63,60 @@ def test_dense_kernel_matches_oracle(seed):
     np.testing.assert_allclose(dist.partition.cpu().numpy(), z.numpy(), rtol=1e-6)
     gold = dist.struct.to_parts(seq, (c, k), lengths)
     np.testing.assert_allclose(dist.log_prob(gold.cuda()).cpu().numpy(), (v - z).numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_dense_partition_gradient_and_log_marginals(seed):
+    """Autograd through the dense boundary (reference: loss.backward() through torch_struct's LogSemiring DP,
+    semimarkov.py:286 / semimarkov_modules.py:652-657) against autograd through the oracle DP, fp64."""
+    from action_segmentation_amd.struct import SemiMarkovCRF, SemiMarkov, LogSemiring
+    g = torch.Generator().manual_seed(100 + seed)
+    b, n, k, c = 3, 24 + 5 * seed, 4 + 3 * seed, 3 + 2 * seed
+    edge = torch.randn(b, n - 1, k, c, c, generator=g)
+    if seed == 3:
+        edge[:, :, :, 1, :] = BIG_NEG                               # a forbidden label
+    lengths = torch.tensor([n, n - 4, 2])
+    z, want = O.marginals(edge.double(), lengths, O.LogSemiring)
+    got = SemiMarkov(LogSemiring).marginals(edge.cuda(), lengths=lengths)
+    assert got.shape == edge.shape and got.dtype == edge.dtype
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=1e-7)
+    # every position but the last is covered by exactly one span: expected span mass per instance = 1 at n = 0
+    np.testing.assert_allclose(got[:, 0].flatten(1).sum(1).cpu().numpy(), np.ones(b), rtol=1e-5)
+    # weighted upstream gradient + chain rule through a parameter
+    w = torch.tensor([0.5, -2.0, 3.0])
+    scale = torch.tensor(0.7, requires_grad=True)
+    e_dev = edge.cuda().requires_grad_(True)
+    dist = SemiMarkovCRF(e_dev * scale.cuda(), lengths=lengths)
+    loss = (dist.partition * w.cuda()).sum()
+    loss.backward()
+    e_ref = edge.double().requires_grad_(True)
+    s_ref = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+    z_ref, _ = O.semimarkov_dp(e_ref * s_ref, lengths, O.LogSemiring)
+    (z_ref * w.double()).sum().backward()
+    np.testing.assert_allclose(e_dev.grad.cpu().numpy(), e_ref.grad.numpy(), rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(scale.grad.item(), s_ref.grad.item(), rtol=1e-4)
+    # log_prob is differentiable too (reference log_likelihood: dist.log_prob(parts).mean())
+    gold = dist.struct.to_parts(SemiMarkovCRF(edge.cuda(), lengths=lengths).struct.from_parts(
+        SemiMarkovCRF(edge.cuda(), lengths=lengths).argmax)[0], (c, k), lengths)
+    e2 = edge.cuda().requires_grad_(True)
+    SemiMarkovCRF(e2, lengths=lengths).log_prob(gold.cuda()).sum().backward()
+    np.testing.assert_allclose(e2.grad.cpu().numpy(), (gold.double() - want).numpy(), rtol=5e-5, atol=1e-6)
+
+
+def test_dense_marginals_reference_shape():
+    """Reference-size lattice (K = 20, C = 13 incl. EOS, N = 300): marginal mass is conserved at every position."""
+    from action_segmentation_amd.struct import SemiMarkov, LogSemiring
+    g = torch.Generator().manual_seed(7)
+    b, n, k, c = 2, 300, 20, 13
+    edge = torch.randn(b, n - 1, k, c, c, generator=g).cuda()
+    lengths = torch.tensor([n, n - 37])
+    m = SemiMarkov(LogSemiring).marginals(edge, lengths=lengths).double()
+    # position p is covered by exactly one span [s, s + k'): sum over spans covering p == 1 (for p < L - 1)
+    per_nk = m.sum(dim=(3, 4))                                      # b x (n-1) x k
+    cover = torch.zeros(b, n - 1, dtype=torch.float64, device=m.device)
+    for kk in range(1, k):
+        for off in range(kk):
+            cover[:, off:] += per_nk[:, :n - 1 - off, kk]
+    for i, L in enumerate(lengths.tolist()):
+        np.testing.assert_allclose(cover[i, :L - 1].cpu().numpy(), np.ones(L - 1), rtol=1e-4)
+        assert float(m[i, L - 1:].abs().sum()) == 0.0

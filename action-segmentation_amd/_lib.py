@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(HERE, "libsmmdp.so")  
 SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
     "smm_error_word_offset",
-    "smm_emission_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
+    "smm_emission_f64", "smm_emission_bwd_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
+    "smm_factor_tables_f64", "smm_factor_tables_bwd_f64",
     "smm_dense_workspace_bytes", "smm_dense_dp_f32", "smm_dense_marginals_f32",
     "smm_eval_workspace_bytes", "smm_eval_confusion_i64", "smm_eval_videos_i64",
     "smm_fit_workspace_bytes", "smm_fit_error_word_offset", "smm_fit_stats_f64",
@@ -19,6 +20,11 @@ class SmmShape(ctypes.Structure):
     _fields_ = [("b", ctypes.c_int32), ("d", ctypes.c_int32), ("n_groups", ctypes.c_int32),
                 ("c_max", ctypes.c_int32), ("k_rows", ctypes.c_int32), ("t_max", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("total_frames", ctypes.c_int64)]
+
+
+class SmmTablesShape(ctypes.Structure):
+    _fields_ = [("n_classes", ctypes.c_int32), ("d", ctypes.c_int32), ("n_groups", ctypes.c_int32),
+                ("c_max", ctypes.c_int32), ("k_rows", ctypes.c_int32), ("allow_self_transitions", ctypes.c_int32)]
 
 
 SHAPE_NO_EOS = 1

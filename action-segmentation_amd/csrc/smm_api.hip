@@ -274,7 +274,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
 // the entry points that launch that kernel ask for it)
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                  const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                 bool want_gangs = false)
+                 bool want_gangs = false, int cum_chunk = 0)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
     if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
@@ -317,6 +317,8 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     std::stable_sort(ho, ho + s->b, [&](int a, int b) {
         return (int64_t)hv[a].T * n_states[hv[a].group] > (int64_t)hv[b].T * n_states[hv[b].group];
     });
+    // (chunk table for the emission chain rule: by group, so that a workgroup's run of chunks rarely changes group)
+    if (cum_chunk > 0) std::stable_sort(ho, ho + s->b, [&](int a, int b) { return hv[a].group < hv[b].group; });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
     out->n_pairs = 0;
     out->pairs_cover_big = false;
@@ -328,7 +330,8 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         int64_t cum = 0;
         for (int i = 0; i < s->b; ++i) {
             hc[i] = (int32_t)cum;
-            cum += smm_emission_blocks(hv[ho[i]].T, out->em_tpw);
+            // (cum_chunk: the table counts chunks of that many frames instead -- smm_emission_bwd_f64)
+            cum += cum_chunk > 0 ? (hv[ho[i]].T + cum_chunk - 1) / cum_chunk : smm_emission_blocks(hv[ho[i]].T, out->em_tpw);
         }
         if (cum > 0x7fffffff) return SMM_ERR_UNSUPPORTED;
         hc[s->b] = (int32_t)cum;
@@ -415,6 +418,28 @@ extern "C" int smm_emission_f64(const smm_shape *shape, const int64_t *lengths_h
                    hs, &st);
     if (rc != SMM_OK) return rc;
     return run_emission(shape, st, x, w, cst, inv_var, cons, elp64, elp32, hs);
+}
+
+extern "C" int smm_emission_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                                    const int32_t *group_host, const int32_t *n_states_host, const float *x,
+                                    const double *g_elp, double *g_w, double *g_cst, double *g_inv_var,
+                                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    Staged st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (!x || !g_elp || !g_w || !g_cst || !g_inv_var || !shape || shape->d < 1) return SMM_ERR_ARG;
+    int rc = stage(shape, lengths_host, frame_offset_host, group_host, nullptr, n_states_host, workspace, workspace_bytes,
+                   hs, &st, false, smm_emission_bwd_chunk());
+    if (rc != SMM_OK) return rc;
+    const size_t g = shape->n_groups, cm = shape->c_max, d = shape->d;
+    SMM_HIP(hipMemsetAsync(g_w, 0, sizeof(double) * g * cm * d, hs));
+    SMM_HIP(hipMemsetAsync(g_cst, 0, sizeof(double) * g * cm, hs));
+    SMM_HIP(hipMemsetAsync(g_inv_var, 0, sizeof(double) * d, hs));
+    SmmEmBwdArgs a{st.videos, st.order, st.n_states, st.em_cum, x, g_elp, g_w, g_cst, g_inv_var,
+                   shape->d, shape->c_max, shape->b, st.em_blocks};
+    smm_launch_emission_bwd(a, st.c_need, hs);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
 }
 
 extern "C" int smm_viterbi_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,

@@ -507,6 +507,106 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ chain rule (training)
+// elp[t][c] = cst[g][c] + sum_d x[t][d] w[g][d][c] - 0.5 sum_d x[t][d]^2 inv_var[d]   ==>   with ge = dL/d elp:
+//   g_w[g][c][d] = sum_t x[t][d] ge[t][c]      g_cst[g][c] = sum_t ge[t][c]      g_iv[d] = -0.5 sum_t x[t][d]^2 sum_c ge[t][c]
+// (t over the frames of the videos of group g).  Replaces what autograd does behind the reference's
+// emission_log_probs (semimarkov_modules.py:324-381) in loss.backward() (semimarkov.py:286); it was six skinny fp64
+// torch GEMMs (K = frames, M x N = D x C) plus fp64 copies of x -- 1.5 ms of a 4 ms training step on cfg4.
+// Thread = feature column (a wave's loads of one frame are 256 contiguous bytes), C fp64 accumulators in registers; the
+// ge rows of a 64-frame tile sit in LDS and are read as broadcasts.  Column D is the constant-1 feature: its sums are
+// g_cst.  A workgroup owns a contiguous range of 256-frame chunks and leaves through atomics when the group changes
+// (consecutive lanes = consecutive d of one class row: 512 contiguous bytes per atomic instruction).
+#define SMM_EB_CHUNK 256
+#define SMM_EB_TILE 64
+
+int smm_emission_bwd_chunk() { return SMM_EB_CHUNK; }
+
+template <int CT>
+__global__ void __launch_bounds__(256) smm_emission_bwd_kernel(SmmEmBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double s_ge[SMM_EB_TILE * CT];
+    __shared__ double s_rs[SMM_EB_TILE];
+    const int tid = threadIdx.x;
+    const int D = a.d, cm = a.c_max;
+    const int ipw = (a.n_chunks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int it0 = blockIdx.x * ipw, it1 = min(a.n_chunks, it0 + ipw);
+    for (int c0 = 0; c0 <= D; c0 += 256) {                       // column passes (one for D < 256)
+        const int col = c0 + tid;
+        const bool real = col < D, ones = col == D;
+        const int colc = real ? col : 0;                         // (idle lanes read column 0 and drop the result)
+        double acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+        double ivacc = 0.0;
+        int cur_g = -1, cur_c = 0;
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (cur_g >= 0 && (real || ones)) {
+                double *dst = real ? a.g_w + (size_t)cur_g * cm * D + col : a.g_cst + (size_t)cur_g * cm;
+                const size_t step = real ? (size_t)D : 1;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (c < cur_c) __hip_atomic_fetch_add(dst + c * step, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = 0.0;
+        };
+        for (int it = it0; it < it1; ++it) {
+            const int slot = smm_em_find_video(a.cum, a.b, it);
+            const SmmVideo mv = a.videos[a.order[slot]];
+            if (mv.group != cur_g) {
+                flush();
+                cur_g = mv.group;
+                cur_c = min(a.n_states[cur_g], CT);
+            }
+            const int r0 = (it - a.cum[slot]) * SMM_EB_CHUNK, r1 = min(mv.T, r0 + SMM_EB_CHUNK);
+            for (int t0 = r0; t0 < r1; t0 += SMM_EB_TILE) {
+                const int nt = min(SMM_EB_TILE, r1 - t0);
+                const double *__restrict__ ge = a.g_elp + (size_t)(mv.frame_off + t0) * cm;
+                const float *__restrict__ xp = a.x + (size_t)(mv.frame_off + t0) * D + colc;
+                __syncthreads();                                 // the previous tile has been consumed
+                for (int i = tid; i < SMM_EB_TILE * CT; i += 256) {
+                    const int f = i / CT, c = i - f * CT;
+                    s_ge[i] = (f < nt && c < cur_c) ? ge[(size_t)f * cm + c] : 0.0;
+                }
+                __syncthreads();
+                if (tid < SMM_EB_TILE) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) r += s_ge[tid * CT + ((c + tid) % CT)];   // (rotated: spreads the banks)
+                    s_rs[tid] = r;
+                }
+                __syncthreads();
+                for (int f = 0; f < nt; f += 8) {
+                    float xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = xp[(size_t)min(f + u, nt - 1) * D];   // rows past nt: ge row is 0
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double xd = ones ? 1.0 : (double)xv[u];
+                        const double *gr = s_ge + (f + u) * CT;  // (f + u < 64: rows past nt are zero)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[c] = __builtin_fma(xd, gr[c], acc[c]);
+                        ivacc = __builtin_fma(xd * xd, s_rs[f + u], ivacc);
+                    }
+                }
+            }
+        }
+        flush();
+        if (real) __hip_atomic_fetch_add(a.g_iv + col, -0.5 * ivacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+}
+
+void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stream)
+{
+    const int grid = a.n_chunks < 1024 ? a.n_chunks : 1024;
+    if (c_need <= 8) hipLaunchKernelGGL(smm_emission_bwd_kernel<8>, dim3(grid), dim3(256), 0, stream, a);
+    else if (c_need <= 16) hipLaunchKernelGGL(smm_emission_bwd_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL(smm_emission_bwd_kernel<24>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(smm_emission_bwd_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
+}
+
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream)
 {
     if (n == 0) return;

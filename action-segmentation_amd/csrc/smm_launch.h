@@ -28,6 +28,22 @@ int smm_emission_blocks(int t, int tpw);
 void smm_launch_emission(const SmmEmArgs &a, int c_need, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
                          hipStream_t stream);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
+
+// chain rule through the emission scorer (smm_emission.hip): outputs must be zero at launch
+struct SmmEmBwdArgs {
+    const SmmVideo *videos;
+    const int32_t *order;    // [b]
+    const int32_t *n_states;
+    const int32_t *cum;      // [b + 1] chunks of smm_emission_bwd_chunk() frames before each video of `order`
+    const float *x;          // [total_frames][d]
+    const double *g_elp;     // [total_frames][c_max]
+    double *g_w;             // [g][c_max][d]   (class-major)
+    double *g_cst;           // [g][c_max]
+    double *g_iv;            // [d]
+    int32_t d, c_max, b, n_chunks;
+};
+int smm_emission_bwd_chunk();
+void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
 // follow-up of a launch with gangs: decodes, on one CU each, the videos whose gang gave up (no-op kernels otherwise)

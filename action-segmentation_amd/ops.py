@@ -135,6 +135,93 @@ def emission(batch, x, w, cst, inv_var, cons=None, want64=True, want32=False, ou
     return elp64, elp32
 
 
+def emission_bwd(batch, x, g_elp, ws=None):
+    """Chain rule through the emission scorer (smm_emission_bwd_f64): g_elp fp64 [total_frames, c_max] ->
+    (g_w [n_groups, d, c_max] (a transposed view of the kernel's class-major output), g_cst [n_groups, c_max],
+    g_inv_var [d]), all fp64."""
+    lib = _lib.load()
+    dev = x.device
+    f64 = torch.float64
+    g, cm, d = batch.n_groups, batch.c_max, int(x.size(1))
+    if d != batch.d or x.size(0) < batch.total_frames or tuple(g_elp.shape) != (batch.total_frames, cm):
+        raise ValueError("emission_bwd: x [>= total_frames, batch.d] and g_elp [total_frames, c_max] expected")
+    g_w = torch.empty((g, cm, d), dtype=f64, device=dev)
+    g_cst = torch.empty((g, cm), dtype=f64, device=dev)
+    g_iv = torch.empty(d, dtype=f64, device=dev)
+    if ws is None:
+        ws = workspace(batch.workspace_bytes(), dev)
+    ln, fo, gr, _, ns = batch.host_ptrs()
+    _lib.check(lib.smm_emission_bwd_f64(
+        ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(fo), ctypes.c_void_p(gr), ctypes.c_void_p(ns),
+        _dev(x, torch.float32, 'x'), _dev(g_elp, f64, 'g_elp'), _dev(g_w, f64, 'g_w'), _dev(g_cst, f64, 'g_cst'),
+        _dev(g_iv, f64, 'g_inv_var'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
+    return g_w.transpose(1, 2), g_cst, g_iv
+
+
+class TablesMeta:
+    """Which class sets a launch's parameter groups are (device index tensors, built once per PackedCorpus):
+    classes / merged int64 [g, c_max], n_states int32 [g]; plus the scalars of smm_tables_shape."""
+
+    def __init__(self, classes, merged, n_states, n_classes, d, k_rows, allow_self_transitions):
+        self.classes, self.merged, self.n_states = classes, merged, n_states
+        g, cm = classes.shape
+        self.g, self.cm, self.n, self.d, self.k_rows = int(g), int(cm), int(n_classes), int(d), int(k_rows)
+        self.shape = _lib.SmmTablesShape(self.n, self.d, self.g, self.cm, self.k_rows, 1 if allow_self_transitions else 0)
+
+
+def _u8(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous() or t.element_size() != 1:
+        raise ValueError("%s: a contiguous 1-byte device tensor is expected" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def factor_tables(meta, init_logits, transition_logits, poisson_log_rates, gaussian_means, gaussian_cov,
+                  init_constraints=None, transition_constraints=None):
+    """fp32 parameters -> fp64 tables of every group (smm_factor_tables_f64):
+    dict(trans [g,cm,cm], init [g,cm], len [g,K,cm], w [g,d,cm], cst [g,cm], inv_var [d])."""
+    lib = _lib.load()
+    dev, f64, f32 = init_logits.device, torch.float64, torch.float32
+    g, cm, d, k = meta.g, meta.cm, meta.d, meta.k_rows
+    if tuple(gaussian_means.shape) != (meta.n, d) or tuple(gaussian_cov.shape) != (d, d) or \
+            tuple(transition_logits.shape) != (meta.n, meta.n):
+        raise ValueError("factor_tables: parameter shapes do not match the TablesMeta")
+    t = dict(trans=torch.empty((g, cm, cm), dtype=f64, device=dev), init=torch.empty((g, cm), dtype=f64, device=dev),
+             len=torch.empty((g, k, cm), dtype=f64, device=dev), w=torch.empty((g, d, cm), dtype=f64, device=dev),
+             cst=torch.empty((g, cm), dtype=f64, device=dev), inv_var=torch.empty(d, dtype=f64, device=dev))
+    _lib.check(lib.smm_factor_tables_f64(
+        ctypes.byref(meta.shape), _dev(init_logits, f32, 'init_logits'), _dev(transition_logits, f32, 'transition_logits'),
+        _dev(poisson_log_rates, f32, 'poisson_log_rates'), _dev(gaussian_means, f32, 'gaussian_means'),
+        _dev(gaussian_cov, f32, 'gaussian_cov'), _u8(init_constraints, 'init_constraints'),
+        _u8(transition_constraints, 'transition_constraints'), _dev(meta.classes, torch.int64, 'classes'),
+        _dev(meta.merged, torch.int64, 'merged'), _dev(meta.n_states, torch.int32, 'n_states'),
+        _dev(t['trans'], f64, 'trans'), _dev(t['init'], f64, 'init'), _dev(t['len'], f64, 'len'), _dev(t['w'], f64, 'w'),
+        _dev(t['cst'], f64, 'cst'), _dev(t['inv_var'], f64, 'inv_var'), _stream()))
+    return t
+
+
+def factor_tables_bwd(meta, poisson_log_rates, gaussian_means, gaussian_cov, trans, init, g_trans, g_init, g_len,
+                      g_w_class_major, g_cst, init_constraints=None, transition_constraints=None):
+    """Gradients of the tables -> fp64 gradients of (init_logits [n], transition_logits [n,n], poisson_log_rates [n],
+    gaussian_means [n,d])  (smm_factor_tables_bwd_f64).  g_w_class_major: [g, c_max, d]."""
+    lib = _lib.load()
+    dev, f64, f32 = trans.device, torch.float64, torch.float32
+    n, d = meta.n, meta.d
+    out = (torch.empty(n, dtype=f64, device=dev), torch.empty((n, n), dtype=f64, device=dev),
+           torch.empty(n, dtype=f64, device=dev), torch.empty((n, d), dtype=f64, device=dev))
+    _lib.check(lib.smm_factor_tables_bwd_f64(
+        ctypes.byref(meta.shape), _dev(poisson_log_rates, f32, 'poisson_log_rates'), _dev(gaussian_means, f32, 'gaussian_means'),
+        _dev(gaussian_cov, f32, 'gaussian_cov'), _u8(init_constraints, 'init_constraints'),
+        _u8(transition_constraints, 'transition_constraints'), _dev(meta.classes, torch.int64, 'classes'),
+        _dev(meta.merged, torch.int64, 'merged'), _dev(meta.n_states, torch.int32, 'n_states'),
+        _dev(trans, f64, 'trans'), _dev(init, f64, 'init'), _dev(g_trans, f64, 'g_trans'), _dev(g_init, f64, 'g_init'),
+        _dev(g_len, f64, 'g_len'), _dev(g_w_class_major, f64, 'g_w'), _dev(g_cst, f64, 'g_cst'),
+        _dev(out[0], f64, 'g_init_logits'), _dev(out[1], f64, 'g_transition_logits'), _dev(out[2], f64, 'g_poisson_log_rates'),
+        _dev(out[3], f64, 'g_gaussian_means'), _stream()))
+    return out
+
+
 def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True,
             labels_on_host=False, labels_out=None):
     """Viterbi on emission scores.  elp fp64 (smm_viterbi_f64) or fp32 (smm_viterbi_f32, tables fp32 too).

@@ -44,9 +44,9 @@ def sliding_sum(inputs, k):
 class _LogPartition(torch.autograd.Function):
     """log Z of every video of one launch as a differentiable function of the fp64 factor tables (emission factors w,
     cst; transition, initial and length tables; stacked per parameter group).  Forward: smm_emission_f64 +
-    smm_logz_f64; backward: smm_logz_bwd_f64 (posterior marginals) + the chain rule through
-    elp = cst + x.w - 0.5 x^2.inv_var as small torch GEMMs, one per run of frames that share a group.
-    ``runs``: [(group, first frame, end frame)] covering every frame that belongs to a video."""
+    smm_logz_f64; backward: smm_logz_bwd_f64 (posterior marginals) + smm_emission_bwd_f64 (the chain rule through
+    elp = cst + x.w - 0.5 x^2.inv_var, one pass over the features).
+    ``runs``: unused (kept for callers of the round-1 signature)."""
 
     @staticmethod
     def forward(ctx, batch, runs, x, cons, endpen, w, cst, inv_var, trans, init, len_scores):
@@ -65,18 +65,37 @@ class _LogPartition(torch.autograd.Function):
         x, elp64, trans, init, len_scores, z = ctx.saved_tensors
         g = ops.logz_bwd(ctx.batch, elp64, trans, init, len_scores, z, grad_logz=gz.to(torch.float64).contiguous(),
                          endpen=ctx.endpen, ws=ctx.ws, with_backward=ctx.both)
-        ge = g['elp']                                   # [frames, C]: posterior state occupancy x upstream
-        n_groups, d, cm = trans.size(0), x.size(1), ge.size(1)
-        g_w = torch.zeros((n_groups, d, cm), dtype=torch.float64, device=x.device)
-        g_cst = torch.zeros((n_groups, cm), dtype=torch.float64, device=x.device)
-        g_iv = torch.zeros(d, dtype=torch.float64, device=x.device)
-        for grp, f0, f1 in ctx.runs:
-            xd = x[f0:f1].to(torch.float64)
-            gr = ge[f0:f1]
-            g_w[grp] += xd.t() @ gr                     # [D, C]
-            g_cst[grp] += gr.sum(0)
-            g_iv += -0.5 * ((xd * xd) * gr.sum(1, keepdim=True)).sum(0)
+        # chain rule through elp = cst + x.w - 0.5 x^2.inv_var: one pass over x (smm_emission_bwd_f64)
+        g_w, g_cst, g_iv = ops.emission_bwd(ctx.batch, x, g['elp'], ws=ctx.ws)
         return None, None, None, None, None, g_w, g_cst, g_iv, g['trans'], g['init'], g['len']
+
+
+class _FactorTables(torch.autograd.Function):
+    """The fp64 factor tables of every parameter group of a launch as ONE differentiable node: smm_factor_tables_f64
+    forward, smm_factor_tables_bwd_f64 backward (csrc/smm_tables.hip), instead of ~45 small torch ops each way.
+    Returns (trans, init, len, w, cst, inv_var); inv_var carries no gradient (the covariance is not trained,
+    reference :149)."""
+
+    @staticmethod
+    def forward(ctx, meta, init_cons, trans_cons, init_logits, transition_logits, poisson_log_rates, gaussian_means,
+                gaussian_cov):
+        t = ops.factor_tables(meta, init_logits, transition_logits, poisson_log_rates, gaussian_means, gaussian_cov,
+                              init_cons, trans_cons)
+        ctx.meta, ctx.init_cons, ctx.trans_cons = meta, init_cons, trans_cons
+        ctx.save_for_backward(poisson_log_rates, gaussian_means, gaussian_cov, t['trans'], t['init'])
+        ctx.mark_non_differentiable(t['inv_var'])
+        return t['trans'], t['init'], t['len'], t['w'], t['cst'], t['inv_var']
+
+    @staticmethod
+    def backward(ctx, g_trans, g_init, g_len, g_w, g_cst, _g_iv):
+        log_rates, means, cov, trans, init = ctx.saved_tensors
+        cont = lambda t: None if t is None else t.contiguous()
+        # the emission chain rule hands g_w over as a transposed view of its class-major buffer: undo the view
+        g_w_cm = None if g_w is None else g_w.transpose(1, 2).contiguous()
+        gi, gt, gr, gm = ops.factor_tables_bwd(ctx.meta, log_rates, means, cov, trans, init, cont(g_trans), cont(g_init),
+                                               cont(g_len), g_w_cm, cont(g_cst), ctx.init_cons, ctx.trans_cons)
+        f32 = torch.float32
+        return None, None, None, gi.to(f32), gt.to(f32), gr.to(f32), gm.to(f32), None
 
 
 class SemiMarkovModule(nn.Module):
@@ -533,9 +552,10 @@ class SemiMarkovModule(nn.Module):
             pc._stacked = (key, out, tabs)          # (tabs: keeps the ids alive)
         return out
 
-    def _stacked_tables_batched(self, pc, dev):
-        """The differentiable tables of ALL groups from ~25 batched torch ops (forward; as many backward) instead of a
-        dozen small ops per group: a training step over many tasks spends its host time here otherwise.  Same
+    def _stacked_tables_batched(self, pc, dev, use_hip=None):
+        """The differentiable tables of ALL groups of a launch.  fp32 parameters on the GPU: one HIP launch forward and
+        one backward (``_FactorTables``, csrc/smm_tables.hip).  Otherwise (``use_hip=False``: the statement the HIP
+        kernels are tested against) ~25 batched torch ops instead of a dozen small ops per group.  Same
         formulas as ``factor_tables`` / reference :284-414 -- masks before the softmax, columns normalised over `to`,
         Poisson length table, expanded Gaussian -- on index tensors padded to c_max (padded entries are excluded from
         every normalisation and come out as 0; the kernels never read them)."""
@@ -562,6 +582,22 @@ class SemiMarkovModule(nn.Module):
             ix = pc._group_index = dict(dev=str(dev), merge=id(self.merge_classes), n_states=n_states, cm=cm,
                                         vcp=vcp.to(dev), mvp=mvp.to(dev), valid=valid.to(dev), cmap=cmap.to(dev))
         vcp, mvp, valid, cm = ix['vcp'], ix['mvp'], ix['valid'], ix['cm']
+        params = (self.init_logits, self.transition_logits, self.poisson_log_rates, self.gaussian_means, self.gaussian_cov)
+        if use_hip is None:
+            use_hip = dev.type == 'cuda' and cm <= 32 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                                                              for p in params)
+        if use_hip:
+            meta = ix.get('meta')
+            if meta is None:
+                meta = ix['meta'] = ops.TablesMeta(vcp, mvp, torch.tensor(ix['n_states'], dtype=torch.int32).to(dev),
+                                                   self.n_classes, self.feature_dim, self.max_k,
+                                                   self.allow_self_transitions)
+            ic, tc = self.init_constraints, self.transition_constraints
+            trans, init, lens, w, cst, inv_var = _FactorTables.apply(
+                meta, None if ic is None else ic.detach().contiguous(), None if tc is None else tc.detach().contiguous(),
+                *params)
+            st = dict(trans=trans, init=init, len=lens, w=w, cst=cst, inv_var=inv_var, class_map=ix['cmap'])
+            return st, ix['n_states'], cm, self.max_k
         neg_inf = float('-inf')
         # initial (reference :284-296)
         il = self.init_logits.to(f64)

@@ -118,6 +118,22 @@ int smm_emission_f64(const smm_shape *shape, const int64_t *lengths_host, const 
                      double *elp64, float *elp32, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Chain rule through the emission scorer (training): with g_elp = dL/d elp (smm_logz_bwd_f64's output),
+ *   g_w[g][c][d] = sum_t x[t][d] g_elp[t][c]      g_cst[g][c] = sum_t g_elp[t][c]
+ *   g_inv_var[d] = -0.5 sum_t x[t][d]^2 sum_c g_elp[t][c]              (t over the frames of the videos of group g)
+ * -- what autograd does behind emission_log_probs (modules:324-381) in the reference's loss.backward()
+ * (src/models/semimarkov/semimarkov.py:286).  Outputs are overwritten.
+ *   g_w        dev fp64 [n_groups][c_max][d]   CLASS-major (the layout of the reference's gaussian_means; the
+ *              transpose of smm_emission_f64's w)
+ *   g_cst      dev fp64 [n_groups][c_max];   g_inv_var  dev fp64 [d]
+ * Sums leave the workgroups through fp64 atomics: the last bits depend on the order of arrival.
+ */
+int smm_emission_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
+                         const int32_t *group_host, const int32_t *n_states_host,
+                         const float *x, const double *g_elp, double *g_w, double *g_cst, double *g_inv_var,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Viterbi decode on emission scores (fp64 path).
  *   elp       dev fp64 [total_frames][c_max]
  *   spans     dev int64 [b][t_max + 1]  span encoding of modules:679-691: global class id at each span start,
@@ -168,6 +184,41 @@ int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_host, const 
                      const double *endpen, const double *logz, const double *grad_logz,
                      double *g_elp, double *g_trans, double *g_init, double *g_len,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Factor tables of every parameter group from the model parameters (training steps), and their chain rule.
+ * One launch each instead of the differentiable torch ops behind initial_log_probs (modules:284-296),
+ * transition_log_probs (:298-322), _length_log_probs_with_rates (:383-414) and the expanded emission_log_probs
+ * (:324-381); layouts as the entry points above read them, columns past a group's state count are 0.
+ * Every pointer is a DEVICE pointer; nothing is staged and the host never waits.
+ *   parameters: init_logits [n], transition_logits [n][n] ([to][from]), poisson_log_rates [n], gaussian_means [n][d],
+ *               gaussian_cov [d][d] (its diagonal: tied diagonal covariance), fp32 like the reference's nn.Parameters
+ *   init_constraints [n] / transition_constraints [n][n]: bytes, 1 = forbidden (set_transition_constraints,
+ *               modules:160-193), or NULL
+ *   classes [g][c_max]: class id of each local state (valid_classes);  merged [g][c_max]: its parameter row after
+ *               merge_classes;  n_states [g] int32
+ * smm_factor_tables_bwd_f64: g_* of the tables in (NULL = no gradient through that table; g_w_class_major is
+ * [g][c_max][d], smm_emission_bwd_f64's layout), fp64 gradients of the parameters out (overwritten; sums over groups
+ * leave through fp64 atomics).  trans / init: the forward call's outputs.
+ */
+typedef struct smm_tables_shape {
+    int32_t n_classes, d, n_groups, c_max, k_rows;
+    int32_t allow_self_transitions;
+} smm_tables_shape;
+int smm_factor_tables_f64(const smm_tables_shape *shape, const float *init_logits, const float *transition_logits,
+                          const float *poisson_log_rates, const float *gaussian_means, const float *gaussian_cov,
+                          const uint8_t *init_constraints, const uint8_t *transition_constraints,
+                          const int64_t *classes, const int64_t *merged, const int32_t *n_states,
+                          double *trans, double *init, double *len_scores, double *w, double *cst, double *inv_var,
+                          void *stream);
+int smm_factor_tables_bwd_f64(const smm_tables_shape *shape, const float *poisson_log_rates, const float *gaussian_means,
+                              const float *gaussian_cov, const uint8_t *init_constraints,
+                              const uint8_t *transition_constraints, const int64_t *classes, const int64_t *merged,
+                              const int32_t *n_states, const double *trans, const double *init,
+                              const double *g_trans, const double *g_init, const double *g_len,
+                              const double *g_w_class_major, const double *g_cst,
+                              double *g_init_logits, double *g_transition_logits, double *g_poisson_log_rates,
+                              double *g_gaussian_means, void *stream);
 
 /*
  * The reference's inner boundary as it stands: semiring DP over DENSE potentials, for lattices small enough to be

@@ -26,3 +26,9 @@ for i in range(4):
     t0 = time.perf_counter(); step(); print('packed step %d: %.2f ms' % (i, (time.perf_counter() - t0) * 1e3), flush=True)
 pr = cProfile.Profile(); pr.enable(); step(); pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step()
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
+ev = prof.key_averages()
+print('ops', sum(e.count for e in ev), 'cuda kernels', sum(e.count for e in ev if e.device_type.name == 'CUDA'))

@@ -200,3 +200,47 @@ def test_span_codecs_run_on_the_device():
         devv = U.labels_to_spans(lab.to(dev), max_k)
         assert torch.equal(devv.cpu(), host)
         assert torch.equal(U.spans_to_labels(devv).cpu(), lab)
+
+
+@pytest.mark.parametrize('variant', ['plain', 'constrained', 'merged', 'self'])
+def test_factor_tables_kernel_matches_torch_tables(variant):
+    """smm_factor_tables_f64 / _bwd_f64 (one launch each way) against the batched differentiable torch statement of
+    reference :284-414 on the same parameters: table values and parameter gradients, several class sets of different
+    sizes sharing classes, with transition constraints / merge_classes / self transitions."""
+    import types
+    from action_segmentation_amd.semimarkov_modules import SemiMarkovModule
+    torch.manual_seed(5)
+    n_classes, d, k = 14, 37, 70
+    kw = {}
+    if variant == 'constrained':
+        kw = dict(allowed_starts={0, 3, 7}, allowed_ends={2, 5},
+                  allowed_transitions={i: {(i + 1) % n_classes, (i + 3) % n_classes, (i + 6) % n_classes}
+                                       for i in range(n_classes)})
+    if variant == 'merged':
+        kw = dict(merge_classes={i: (0 if i in (0, 4, 9) else i) for i in range(n_classes)})
+    m = SemiMarkovModule(make_args(k), n_classes, d, allow_self_transitions=(variant == 'self'), **kw).cuda()
+    with torch.no_grad():
+        m.init_logits.normal_(); m.transition_logits.normal_(); m.poisson_log_rates.uniform_(0.5, 3.5)
+        m.gaussian_means.normal_()
+        m.gaussian_cov.copy_(torch.diag(0.5 + torch.rand(d)))
+    dev = torch.device('cuda:0')
+    groups = [dict(valid_classes=None if v is None else torch.tensor(v)) for v in
+              ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [0, 5, 4], [13, 2, 9, 0, 7], None)]
+    names = ('trans', 'init', 'len', 'w', 'cst', 'inv_var')
+    grads, tabs = {}, {}
+    for use_hip in (False, True):
+        pc = types.SimpleNamespace(groups=groups)
+        m.zero_grad()
+        st, n_states, cm, k_rows = m._stacked_tables_batched(pc, dev, use_hip=use_hip)
+        assert (cm, k_rows) == (14, k) and n_states == [12, 3, 5, 14]
+        g = torch.Generator(device='cpu').manual_seed(3)
+        loss = sum((st[n] * torch.randn(st[n].shape, generator=g, dtype=torch.float64).to(dev)).sum() for n in names)
+        loss.backward()
+        tabs[use_hip] = {n: st[n].detach().cpu().numpy() for n in names}
+        grads[use_hip] = {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None}
+    for n in names:
+        np.testing.assert_allclose(tabs[True][n], tabs[False][n], rtol=1e-13, atol=1e-12, err_msg=n)
+    assert set(grads[True]) == set(grads[False]) == {'init_logits', 'transition_logits', 'poisson_log_rates', 'gaussian_means'}
+    for n in grads[False]:
+        np.testing.assert_allclose(grads[True][n], grads[False][n], rtol=2e-5, atol=1e-5 * np.abs(grads[False][n]).max(),
+                                   err_msg=n)

@@ -331,6 +331,43 @@ def test_emission_matches_oracle(cfg):
         np.testing.assert_allclose(e32[i, :t], ref[i, :t], rtol=2e-7, atol=1e-6)
 
 
+@pytest.mark.parametrize('cfg', [(7, 700, 200, (12, 21, 5)), (3, 90, 40, (7,)), (4, 300, 257, (30, 17)),
+                                 (5, 520, 256, (9, 24, 16, 3)), (40, 37, 12, (4, 8))])
+def test_emission_chain_rule_matches_torch(cfg):
+    """smm_emission_bwd_f64 (what autograd does behind emission_log_probs in the reference's loss.backward()) against
+    the same sums as fp64 torch GEMMs; ragged videos, several parameter groups, gaps on the frame axis."""
+    ops = _ops()
+    b, tmax, d, states = cfg
+    g = np.random.default_rng(b * 31 + d)
+    n_groups, cm = len(states), max(states)
+    lengths = g.integers(max(1, tmax // 3), tmax + 1, size=b); lengths[0] = tmax
+    group = g.integers(0, n_groups, size=b).astype(np.int32); group[:n_groups] = np.arange(n_groups)[:b]
+    gap = g.integers(0, 5, size=b)
+    frame_off = np.concatenate([[0], np.cumsum(lengths + gap)[:-1]]) + 3
+    total = int(frame_off[-1] + lengths[-1] + 2)
+    dev = torch.device('cuda:0')
+    x = torch.tensor(g.standard_normal((total, d)).astype(np.float32) * 3, device=dev)
+    ge = torch.tensor(g.standard_normal((total, cm)), dtype=torch.float64, device=dev)
+    batch = ops.Batch(lengths, list(states), 4, c_max=cm, frame_offset=frame_off, group=group, t_max=tmax,
+                      total_frames=total, d=d)
+    g_w, g_cst, g_iv = ops.emission_bwd(batch, x, ge)
+    assert g_w.shape == (n_groups, d, cm)
+    w_ref = torch.zeros((n_groups, d, cm), dtype=torch.float64, device=dev)
+    c_ref = torch.zeros((n_groups, cm), dtype=torch.float64, device=dev)
+    iv_ref = torch.zeros(d, dtype=torch.float64, device=dev)
+    for i in range(b):
+        f0, f1, gi = int(frame_off[i]), int(frame_off[i] + lengths[i]), int(group[i])
+        c = states[gi]
+        xd, gr = x[f0:f1].double(), ge[f0:f1, :c]
+        w_ref[gi, :, :c] += xd.t() @ gr
+        c_ref[gi, :c] += gr.sum(0)
+        iv_ref += -0.5 * ((xd * xd) * gr.sum(1, keepdim=True)).sum(0)
+    scale = float(w_ref.abs().max())
+    np.testing.assert_allclose(g_w.cpu().numpy(), w_ref.cpu().numpy(), rtol=1e-11, atol=1e-11 * scale)
+    np.testing.assert_allclose(g_cst.cpu().numpy(), c_ref.cpu().numpy(), rtol=1e-11, atol=1e-11 * scale)
+    np.testing.assert_allclose(g_iv.cpu().numpy(), iv_ref.cpu().numpy(), rtol=1e-11, atol=1e-11 * float(iv_ref.abs().max()))
+
+
 @pytest.mark.parametrize('shape', [(3, 12, 3, 4), (2, 40, 6, 8), (2, 5, 3, 8), (4, 70, 5, 20), (2, 130, 16, 64),
                                    (3, 200, 7, 65), (2, 300, 17, 130), (2, 600, 14, 300), (1, 1300, 12, 1024),
                                    (2, 150, 32, 40), (2, 64, 4, 2),

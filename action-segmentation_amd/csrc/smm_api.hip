@@ -236,7 +236,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     } else {
         double best_t = 1e300;
         // (host time is on the caller's critical path: a handful of candidates, ~b heap operations each)
-        static const int n3s[] = {0, 2, 4, 8};
+        static const int n3s[] = {0, 1, 2, 4, 8};
         for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
             for (int n3 : n3s) {
                 // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few

@@ -423,6 +423,7 @@ class SemiMarkovModule(nn.Module):
         state = dict(self.__dict__)
         state.pop('_table_cache', None)          # device tensors derived from the parameters: rebuilt on demand
         state.pop('_index_cache', None)
+        state.pop('_single_group', None)         # (index tensors + the ctypes shape of the table kernels)
         return state
 
     def _decode_tables(self, valid_classes, device):
@@ -743,20 +744,28 @@ class SemiMarkovModule(nn.Module):
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
         assert int(lengths_host.max()) == tmax
         self._check_no_eos_lengths(lengths_host, no_eos)
-        tab = self.factor_tables(valid_classes, dev)
-        c = tab['init'].numel()
-        batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=b * tmax, d=d,
-                          no_eos=no_eos)
+        if self.max_k > 1:
+            # one-group stack (HIP table kernels for fp32 parameters on the GPU); the index tensors are kept per class set
+            cache = self.__dict__.setdefault('_single_group', {})
+            key = None if valid_classes is None else tuple(int(v) for v in valid_classes)
+            one = cache.get(key)
+            if one is None:
+                import types
+                one = cache[key] = types.SimpleNamespace(groups=[dict(valid_classes=valid_classes)])
+            st, n_states, c, k_rows = self._stacked_tables_batched(one, dev)
+        else:
+            tab = self.factor_tables(valid_classes, dev)
+            c, k_rows = tab['init'].numel(), tab['len'].size(0)
+            st = {n: tab[n].unsqueeze(0).contiguous() for n in ('w', 'cst', 'trans', 'init', 'len')}
+            st['inv_var'] = tab['inv_var'].contiguous()
+        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos)
         x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
         cons = None
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
         endpen = None if no_eos else self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
-        runs = [(0, i * tmax, i * tmax + int(t)) for i, t in enumerate(lengths_host)]    # (padding frames carry no gradient)
-        return _LogPartition.apply(batch, runs, x, cons, endpen, tab['w'].unsqueeze(0).contiguous(),
-                                   tab['cst'].unsqueeze(0).contiguous(), tab['inv_var'].contiguous(),
-                                   tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
-                                   tab['len'].unsqueeze(0).contiguous())
+        return _LogPartition.apply(batch, None, x, cons, endpen, st['w'], st['cst'], st['inv_var'], st['trans'],
+                                   st['init'], st['len'])
 
     def log_partition_packed(self, pc):
         """log Z of every video of a PackedCorpus (any number of single-task batches, any mix of tasks) in ONE launch
@@ -766,14 +775,7 @@ class SemiMarkovModule(nn.Module):
         self._require_device(pc.x, 'log_partition_packed')
         self.prepare_packed(pc, differentiable=True)
         t = pc.tables
-        runs, cur = [], None
-        for g, off, n in zip(pc.group, pc.frame_offset, pc.lengths):      # runs of frames that share a group
-            if cur is not None and cur[0] == g and cur[2] == off:
-                cur[2] = off + n
-            else:
-                cur = [g, off, off + n]
-                runs.append(cur)
-        return _LogPartition.apply(pc.batch, [tuple(r) for r in runs], pc.x, pc.cons, pc.endpen, t['w'], t['cst'],
+        return _LogPartition.apply(pc.batch, None, pc.x, pc.cons, pc.endpen, t['w'], t['cst'],
                                    t['inv_var'], t['trans'], t['init'], t['len'])
 
     def log_likelihood_packed(self, pc):

@@ -142,6 +142,7 @@ class SemiMarkovModel(object):
                         loss_b = -ll
                         loss_b.mean().backward()
                         vals = loss_b.detach().cpu().tolist()
+                        self._check_finite(vals, batch_ix)
                         losses += vals
                         train_nll += sum(v * len(b['lengths']) for v, b in zip(vals, pending))
                         pending = []
@@ -157,6 +158,7 @@ class SemiMarkovModel(object):
                 loss = -ll - log_det
                 pending.append(loss)
                 losses.append(loss.item())
+                self._check_finite(losses[-1:], batch_ix)
                 train_nll += -ll.item() * len(lengths)
                 if len(pending) >= args.batch_accumulation:
                     (sum(pending) / len(pending)).backward()
@@ -168,6 +170,14 @@ class SemiMarkovModel(object):
             if callback_fn:
                 callback_fn(epoch, {'train_loss': train_loss, 'train_nll_frame_avg': train_nll / max(num_frames, 1),
                                     'train_kl_vid_avg': 0.0, 'train_recon_bound': train_nll / max(num_frames, 1)})
+
+    @staticmethod
+    def _check_finite(values, batch_ix):
+        """A NaN / inf that reaches the DP kernels (features, or parameters that diverged) comes back as a non-finite
+        log-likelihood: stop instead of stepping the optimiser on it."""
+        if not all(np.isfinite(v) for v in values):
+            raise FloatingPointError("non-finite training loss %s at batch %d (NaN / inf in the features or the "
+                                     "parameters reached the log-partition kernels)" % (values, batch_ix))
 
     # ------------------------------------------------------------------ constraints (reference :135-157)
     def make_additional_allowed_ends(self, tasks, lengths):
@@ -255,13 +265,11 @@ class SemiMarkovModel(object):
         # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
         torch.cuda.current_stream().synchronize()
-        labels = out['labels'].numpy().copy()
+        labels = out['labels'].numpy().copy()       # (the pinned staging buffer is reused by the next decode)
         ops.check_decoded(pc.batch, out)
-        preds = {}
-        for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
-            preds[name] = labels[off:off + t]
-            assert self.model.n_classes not in preds[name], "predictions should not contain EOS"
-        return preds
+        # one pass over the whole frame axis instead of one scan per video (frames no video covers hold -1)
+        assert int(labels.max(initial=-1)) < self.model.n_classes, "predictions should not contain EOS"
+        return {name: labels[off:off + t] for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths)}
 
     def predict(self, test_data, fused=True, shard=None):
         """``{video: int64[T]}``.  ``shard=(rank, world)`` (default: the torch.distributed group when one is up) limits the

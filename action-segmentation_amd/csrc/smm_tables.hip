@@ -119,14 +119,28 @@ __global__ void __launch_bounds__(256) smm_tables_kernel(SmmTabArgs a)
                 const int d = i / cm, c = i - d * cm;
                 a.w[(size_t)g * D * cm + i] = c < C ? (double)a.means[(size_t)mv[c] * D + d] / (double)a.cov[(size_t)d * (D + 1)] : 0.0;
             }
-            if (tid < cm) {
-                double s = 0.0, lv = 0.0;
-                if (tid < C)
-                    for (int d = 0; d < D; ++d) {
-                        const double var = (double)a.cov[(size_t)d * (D + 1)], mu = (double)a.means[(size_t)mv[tid] * D + d];
+            // cst: 8 slices of the feature axis per state, merged in LDS; sum_d log var over the whole workgroup
+            __shared__ double s_part[8][32], s_lv[4];
+            {
+                double lv = 0.0;
+                for (int d = tid; d < D; d += 256) lv += log((double)a.cov[(size_t)d * (D + 1)]);
+                lv = smm_wave_sum(lv);
+                if ((tid & 63) == 0) s_lv[tid >> 6] = lv;
+                const int c = tid & 31, r = tid >> 5;
+                double s = 0.0;
+                if (c < C)
+                    for (int d = r; d < D; d += 8) {
+                        const double var = (double)a.cov[(size_t)d * (D + 1)], mu = (double)a.means[(size_t)mv[c] * D + d];
                         s += mu * mu / var;
-                        lv += log(var);
                     }
+                s_part[r][c] = s;
+            }
+            __syncthreads();
+            if (tid < cm) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += s_part[q][tid & 31];
+                const double lv = (s_lv[0] + s_lv[1]) + (s_lv[2] + s_lv[3]);
                 a.cst[(size_t)g * cm + tid] = tid < C ? -0.5 * s - 0.5 * lv - 0.5 * D * 1.8378770664093453 : 0.0;   // log(2 pi)
             }
             if (g == 0)
@@ -155,19 +169,19 @@ __global__ void __launch_bounds__(256) smm_tables_kernel(SmmTabArgs a)
                 a.len[((size_t)g * a.k_rows + k) * cm + c] = v;
             }
         } else if (a.g_len) {
-            __shared__ double s_part[8][32];
+            __shared__ double s_glen[8][32];
             const int c = tid & 31, r = tid >> 5;
             double acc = 0.0;
             if (c < C) {
                 const double rate = exp((double)a.log_rates[mv[c]]);
                 for (int k = k0 + r; k < k1; k += 8) acc += a.g_len[((size_t)g * a.k_rows + k) * cm + c] * ((double)k - rate);
             }
-            s_part[r][c] = acc;
+            s_glen[r][c] = acc;
             __syncthreads();
             if (tid < C) {
                 double s = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s += s_part[q][tid];
+                for (int q = 0; q < 8; ++q) s += s_glen[q][tid];
                 smm_tab_atomic(a.g_log_rates + mv[tid], s);
             }
         }

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg3 -- 
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-predict-e2e > gpurun_out/pmc_$c.log 2>&1
 done
-python scripts/pmc_summary.py gpurun_out cfg3 > /dev/null
+python scripts/pmc_summary.py gpurun_out cfg3 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of \`python bench.py --steps 2 --warmup 1\` (scripts/gpu_r2_final.sh), kernels as of commit ${SMM_COMMIT:-unknown}" > /dev/null
 rm -rf gpurun_out/prof_cfg4
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg4 -- python bench.py --workload cfg4 --steps 3 --warmup 1 --no-cpu-baseline --no-predict-e2e > gpurun_out/prof_cfg4.log 2>&1
 python - <<'PY'

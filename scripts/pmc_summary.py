@@ -28,6 +28,8 @@ for k, v in res.items():
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_summary.json')
 allr = json.load(open(path)) if os.path.exists(path) else {}
 allr[workload] = dict(out)
+if len(sys.argv) > 3:          # provenance label (the caller knows the commit; the GPU box has no .git)
+    allr[workload]['_source'] = sys.argv[3]
 if 'smm_viterbi_kernel' in out:
     allr[workload]['smm_viterbi_kernel_hbm_bytes_per_launch'] = out['smm_viterbi_kernel']['hbm_bytes_per_launch']
 os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -202,7 +202,7 @@ def test_span_codecs_run_on_the_device():
         assert torch.equal(U.spans_to_labels(devv).cpu(), lab)
 
 
-@pytest.mark.parametrize('variant', ['plain', 'constrained', 'merged', 'self'])
+@pytest.mark.parametrize('variant', ['plain', 'constrained', 'merged', 'self', 'big'])
 def test_factor_tables_kernel_matches_torch_tables(variant):
     """smm_factor_tables_f64 / _bwd_f64 (one launch each way) against the batched differentiable torch statement of
     reference :284-414 on the same parameters: table values and parameter gradients, several class sets of different
@@ -210,7 +210,7 @@ def test_factor_tables_kernel_matches_torch_tables(variant):
     import types
     from action_segmentation_amd.semimarkov_modules import SemiMarkovModule
     torch.manual_seed(5)
-    n_classes, d, k = 14, 37, 70
+    n_classes, d, k = (14, 37, 70) if variant != 'big' else (45, 300, 1024)
     kw = {}
     if variant == 'constrained':
         kw = dict(allowed_starts={0, 3, 7}, allowed_ends={2, 5},
@@ -224,15 +224,17 @@ def test_factor_tables_kernel_matches_torch_tables(variant):
         m.gaussian_means.normal_()
         m.gaussian_cov.copy_(torch.diag(0.5 + torch.rand(d)))
     dev = torch.device('cuda:0')
-    groups = [dict(valid_classes=None if v is None else torch.tensor(v)) for v in
-              ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [0, 5, 4], [13, 2, 9, 0, 7], None)]
+    sets = ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [0, 5, 4], [13, 2, 9, 0, 7], None)
+    if variant == 'big':            # 32 states (the kernels' maximum), the full length table, D > 256
+        sets = (list(range(3, 35)), [44, 0, 17], list(range(20, 43)))
+    groups = [dict(valid_classes=None if v is None else torch.tensor(v)) for v in sets]
     names = ('trans', 'init', 'len', 'w', 'cst', 'inv_var')
     grads, tabs = {}, {}
     for use_hip in (False, True):
         pc = types.SimpleNamespace(groups=groups)
         m.zero_grad()
         st, n_states, cm, k_rows = m._stacked_tables_batched(pc, dev, use_hip=use_hip)
-        assert (cm, k_rows) == (14, k) and n_states == [12, 3, 5, 14]
+        assert (cm, k_rows, n_states) == ((14, k, [12, 3, 5, 14]) if variant != 'big' else (32, k, [32, 3, 23]))
         g = torch.Generator(device='cpu').manual_seed(3)
         loss = sum((st[n] * torch.randn(st[n].shape, generator=g, dtype=torch.float64).to(dev)).sum() for n in names)
         loss.backward()

@@ -64,22 +64,43 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
     const int c = tid & 31, j = tid >> 5, nj = nth >> 5;
     const int cs = (T + nj - 1) / nj;
     const int t0 = j * cs, t1 = (t0 + cs < T) ? t0 + cs : T;
-    auto delta = [&](int t) -> double {      // O(T C) terms: full fp64 exp
-        const double ps = exp(F_h[(size_t)t * cm + c] + F_cum[(size_t)t * cm + c] + B_g[(size_t)(T - t) * cm + c] - lz);
-        if (t == 0) return ps;
-        return ps - exp(F_g[(size_t)t * cm + c] + B_h[(size_t)(T - t) * cm + c] + B_cum[(size_t)(T - t) * cm + c] - lz);
-    };
+    // Pass 1 leaves delta(t) in g_elp and the chunk sums in LDS; pass 2 turns them into running sums.  Eight positions
+    // per round, their 6 x 8 loads issued before the first exp: one trip to the history per round instead of one per
+    // position (the loop was latency-bound: 64 dependent trips per thread at T = 2048).
     double sum = 0.0;
-    if (c < C)
-        for (int t = t0; t < t1; ++t) sum += delta(t);
+    if (c < C) {
+        for (int t = t0; t < t1; t += 8) {
+            double fs[8], fe[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = (t + u < t1) ? t + u : t1 - 1;
+                fs[u] = F_h[(size_t)tt * cm + c] + F_cum[(size_t)tt * cm + c] + B_g[(size_t)(T - tt) * cm + c] - lz;
+                fe[u] = F_g[(size_t)tt * cm + c] + B_h[(size_t)(T - tt) * cm + c] + B_cum[(size_t)(T - tt) * cm + c] - lz;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t + u >= t1) break;
+                const double d = (t + u == 0) ? exp(fs[u]) : exp(fs[u]) - exp(fe[u]);      // O(T C) terms: full fp64 exp
+                sum += d;
+                a.g_elp[(size_t)(mv.frame_off + t + u) * cm + c] = d;
+            }
+        }
+    }
     if (j < 32) part[c][j] = sum;
     __syncthreads();
     if (c < C) {
         double run = 0.0;
         for (int q = 0; q < j && q < 32; ++q) run += part[c][q];
-        for (int t = t0; t < t1; ++t) {
-            run += delta(t);
-            a.g_elp[(size_t)(mv.frame_off + t) * cm + c] = up * run;
+        for (int t = t0; t < t1; t += 8) {
+            double d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = a.g_elp[(size_t)(mv.frame_off + ((t + u < t1) ? t + u : t1 - 1)) * cm + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t + u >= t1) break;
+                run += d[u];
+                a.g_elp[(size_t)(mv.frame_off + t + u) * cm + c] = up * run;
+            }
         }
     }
     // (e) no EOS (add_eos=False): the closing transition into the label of frame T, which only emits:
@@ -104,38 +125,52 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
         const int to = pair / C, from = pair - to * C;
         const double tw = trans[(size_t)to * cm + from] - lz;
         double acc = 0.0;
+#pragma unroll 8
         for (int n = 1 + sl; n < T; n += ng)
             acc += smm_expd(F_g[(size_t)n * cm + from] + tw + B_g[(size_t)(T - n) * cm + to]);
         atomicAdd(&a.g_trans[(size_t)g * cm * cm + (size_t)to * cm + from], up * acc);
     }
 }
 
-// d/d len[k][c]: grid (k tiles of 256, s tiles of SCH, b * c_max); lane = k
-#define SMM_GLEN_SCH 2048
-__global__ void __launch_bounds__(256) smm_glen_kernel(SmmBwdArgs a)
+// d/d len[k][c]: grid (b * c_max, s tiles of SCH, k tiles of KT); thread = (k, slice of the s tile).  KT = the
+// launch's largest length rounded up to a power of two (32..256): at K = 64 a lane-per-k layout would leave three
+// quarters of the workgroup idle and a 2048-position loop in every thread; the slices are merged in LDS.
+#define SMM_GLEN_SCH 512
+__global__ void __launch_bounds__(256) smm_glen_kernel(SmmBwdArgs a, int kt)
 {
+    __shared__ double s_acc[256];
     const int cm = a.c_max;
-    const int vid = blockIdx.z / cm, c = blockIdx.z - vid * cm;
+    const int vid = blockIdx.x / cm, c = blockIdx.x - vid * cm;     // (x: the only grid dimension that goes past 65 535)
     const SmmVideo mv = a.videos[vid];
     const int T = mv.T - a.no_eos, g = mv.group;
-    if (c >= a.n_states[g]) return;
-    const int k = 1 + blockIdx.x * 256 + threadIdx.x;
-    const int s0 = blockIdx.y * SMM_GLEN_SCH;
-    if (s0 >= T) return;
+    if (c >= a.n_states[g]) return;                                 // (uniform per workgroup)
+    const int kk = threadIdx.x % kt, sl = threadIdx.x / kt, ns = 256 / kt;
+    const int k = 1 + blockIdx.z * kt + kk;
+    const int st = blockIdx.y * SMM_GLEN_SCH;
+    if (st >= T) return;
     const int kmax = (mv.kp - 1 < T) ? mv.kp - 1 : T;
     const size_t blk = (size_t)cm * (T + 1);
     const double *F_cum = a.hist + mv.hist_off;
     const double *hT0 = F_cum + 6 * blk + (size_t)c * (T + 1);      // F_h[s][c] over s
     const double *hT1 = hT0 + blk;                                  // B_h[j][c] over j
     const double base = F_cum[(size_t)T * cm + c] - a.logz[vid];    // cumE[T][c] - logZ
-    if (k > kmax) return;
-    const double lk = a.len[((size_t)g * a.k_rows + k) * cm + c] + base;
-    const int s1 = (s0 + SMM_GLEN_SCH < T - k + 1) ? s0 + SMM_GLEN_SCH : T - k + 1;   // s + k <= T
     double acc = 0.0;
-    for (int s = s0; s < s1; ++s) acc += smm_expd(hT0[s] + lk + hT1[T - s - k]);
-    if (acc != 0.0) {
-        const double up = a.grad_logz ? a.grad_logz[vid] : 1.0;
-        atomicAdd(&a.g_len[((size_t)g * a.k_rows + k) * cm + c], up * acc);
+    if (k <= kmax) {
+        const double lk = a.len[((size_t)g * a.k_rows + k) * cm + c] + base;
+        const int per = SMM_GLEN_SCH / ns;
+        const int s0 = st + sl * per;
+        const int s1 = (s0 + per < T - k + 1) ? s0 + per : T - k + 1;   // s + k <= T
+#pragma unroll 8
+        for (int s = s0; s < s1; ++s) acc += smm_expd(hT0[s] + lk + hT1[T - s - k]);
+    }
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && k <= kmax) {
+        for (int q = 1; q < ns; ++q) acc += s_acc[q * kt + kk];
+        if (acc != 0.0) {
+            const double up = a.grad_logz ? a.grad_logz[vid] : 1.0;
+            atomicAdd(&a.g_len[((size_t)g * a.k_rows + k) * cm + c], up * acc);
+        }
     }
 }
 
@@ -147,6 +182,8 @@ void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStre
 void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream)
 {
     hipLaunchKernelGGL(smm_marginals_kernel, dim3(a.b), dim3(1024), 0, stream, a);
-    dim3 grid((kp_max - 1 + 255) / 256, (t_max + SMM_GLEN_SCH - 1) / SMM_GLEN_SCH, a.b * a.c_max);
-    if (kp_max >= 2) hipLaunchKernelGGL(smm_glen_kernel, grid, dim3(256), 0, stream, a);
+    int kt = 32;
+    while (kt < 256 && kt < kp_max - 1) kt *= 2;
+    dim3 grid(a.b * a.c_max, (t_max + SMM_GLEN_SCH - 1) / SMM_GLEN_SCH, (kp_max - 1 + kt - 1) / kt);
+    if (kp_max >= 2) hipLaunchKernelGGL(smm_glen_kernel, grid, dim3(256), 0, stream, a, kt);
 }

@@ -37,6 +37,9 @@ __global__ void smm_transpose2d_kernel(const double *src, double *dst, int g, in
     }
 }
 
+// grid (videos, slabs of SMM_GTRANS_SLAB positions): every workgroup takes its slab of the transition sums (d); slab 0
+// also does everything that needs the whole video in one workgroup (a, b, c, e)
+#define SMM_GTRANS_SLAB 512
 __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
 {
     const int vid = blockIdx.x;
@@ -52,6 +55,25 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
     const double *trans = a.trans + (size_t)g * cm * cm;
     const int tid = threadIdx.x, nth = blockDim.x;
 
+    if ((int)blockIdx.y * SMM_GTRANS_SLAB >= T) return;
+    // (d) d/d trans: threads = (pair, slice of this slab's n)
+    {
+        const int P = C * C;
+        const int ng = nth / P;
+        if (ng >= 1 && tid < ng * P) {
+            const int pair = tid % P, sl = tid / P;
+            const int to = pair / C, from = pair - to * C;
+            const double tw = trans[(size_t)to * cm + from] - lz;
+            const int n0 = 1 + (int)blockIdx.y * SMM_GTRANS_SLAB;
+            const int n1 = (n0 + SMM_GTRANS_SLAB < T) ? n0 + SMM_GTRANS_SLAB : T;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int n = n0 + sl; n < n1; n += ng)
+                acc += smm_expd(F_g[(size_t)n * cm + from] + tw + B_g[(size_t)(T - n) * cm + to]);
+            atomicAdd(&a.g_trans[(size_t)g * cm * cm + (size_t)to * cm + from], up * acc);
+        }
+    }
+    if (blockIdx.y != 0) return;
     // (a) state-major copies: hT0[c][s] = F_h[s][c], hT1[c][j] = B_h[j][c]
     for (size_t i = tid; i < blk; i += nth) {
         const int n = (int)(i / cm), c = (int)(i - (size_t)n * cm);
@@ -117,19 +139,6 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
     if (tid < C)
         atomicAdd(&a.g_init[(size_t)g * cm + tid],
                   up * exp(F_h[tid] + F_cum[tid] + B_g[(size_t)T * cm + tid] - lz));
-    // (d) d/d trans: threads = (pair, slice of n)
-    const int P = C * C;
-    const int ng = nth / P;
-    if (ng >= 1 && tid < ng * P) {
-        const int pair = tid % P, sl = tid / P;
-        const int to = pair / C, from = pair - to * C;
-        const double tw = trans[(size_t)to * cm + from] - lz;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int n = 1 + sl; n < T; n += ng)
-            acc += smm_expd(F_g[(size_t)n * cm + from] + tw + B_g[(size_t)(T - n) * cm + to]);
-        atomicAdd(&a.g_trans[(size_t)g * cm * cm + (size_t)to * cm + from], up * acc);
-    }
 }
 
 // d/d len[k][c]: grid (b * c_max, s tiles of SCH, k tiles of KT); thread = (k, slice of the s tile).  KT = the
@@ -181,7 +190,7 @@ void smm_launch_transpose(const double *src, double *dst, int g, int cm, hipStre
 
 void smm_launch_marginals(const SmmBwdArgs &a, int t_max, int kp_max, hipStream_t stream)
 {
-    hipLaunchKernelGGL(smm_marginals_kernel, dim3(a.b), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(smm_marginals_kernel, dim3(a.b, (t_max + SMM_GTRANS_SLAB - 1) / SMM_GTRANS_SLAB), dim3(1024), 0, stream, a);
     int kt = 32;
     while (kt < 256 && kt < kp_max - 1) kt *= 2;
     dim3 grid(a.b * a.c_max, (t_max + SMM_GLEN_SCH - 1) / SMM_GLEN_SCH, (kp_max - 1 + kt - 1) / kt);

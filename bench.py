@@ -453,10 +453,13 @@ def train_step_rate(args, data, model):
     out = {}
     for name, fn in (('packed', packed), ('per_batch', per_batch)):
         fn()
-        t0 = time.perf_counter()
-        fn()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": frames / dt, "unit": "frames/s", "ms": dt * 1e3}
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            dts.append(time.perf_counter() - t0)
+        dt = sorted(dts)[1]                                   # median of three passes
+        out[name] = {"value": frames / dt, "unit": "frames/s", "ms": dt * 1e3, "passes_ms": [round(d * 1e3, 3) for d in dts]}
     kernels_only()
     fwd_ms, bwd_ms = kernels_only()
     # algorithmic HBM bytes of the forward + backward DP: elp 8C read twice, two histories 24C each written,

@@ -75,6 +75,33 @@ int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream
     return (int)hipGetLastError();
 }
 
+// Zero fill by a kernel of ours instead of hipMemsetAsync: a memset node captured into a hipGraph came back from the
+// SECOND replay on with a 16-byte pattern of stale kernel arguments instead of zeros (ROCm 7.2, found by
+// tests/test_gpu_graph.py: error words and gang counters full of pointers) -- kernel nodes replay correctly.
+__global__ void __launch_bounds__(256) smm_zero_kernel(uint32_t *p, size_t nwords)
+{
+    const size_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2;    // words before 16-byte alignment
+    const size_t h = head < nwords ? head : nwords;
+    const size_t nq = (nwords - h) >> 2;                                               // 16-byte pieces
+    uint4 *q = reinterpret_cast<uint4 *>(p + h);
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    for (size_t i = tid; i < nq; i += nth) q[i] = make_uint4(0, 0, 0, 0);
+    if (tid < h) p[tid] = 0;
+    const size_t tail0 = h + 4 * nq;
+    if (tid < nwords - tail0) p[tail0 + tid] = 0;
+}
+
+int smm_zero_async(void *dst_dev, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return (int)hipSuccess;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(dst_dev) & 3)) return (int)hipMemsetAsync(dst_dev, 0, bytes, stream);   // (never: every buffer here is made of 4- or 8-byte words)
+    const size_t nwords = bytes >> 2;
+    size_t blocks = (nwords / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(smm_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint32_t *>(dst_dev), nwords);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ planning
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -342,7 +369,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream);
     // the error word and the gang counters behind them start at zero
     SMM_HIP((hipError_t)smm_upload_meta(base, host.data(), p.o_err, stream));
-    SMM_HIP(hipMemsetAsync(base + p.o_err, 0, p.meta_bytes - p.o_err, stream));
+    SMM_HIP((hipError_t)smm_zero_async(base + p.o_err, p.meta_bytes - p.o_err, stream));
     out->videos = reinterpret_cast<SmmVideo *>(base);
     out->order = reinterpret_cast<int32_t *>(base + p.o_order);
     out->n_states = reinterpret_cast<int32_t *>(base + p.o_nstates);
@@ -432,9 +459,9 @@ extern "C" int smm_emission_bwd_f64(const smm_shape *shape, const int64_t *lengt
                    hs, &st, false, smm_emission_bwd_chunk());
     if (rc != SMM_OK) return rc;
     const size_t g = shape->n_groups, cm = shape->c_max, d = shape->d;
-    SMM_HIP(hipMemsetAsync(g_w, 0, sizeof(double) * g * cm * d, hs));
-    SMM_HIP(hipMemsetAsync(g_cst, 0, sizeof(double) * g * cm, hs));
-    SMM_HIP(hipMemsetAsync(g_inv_var, 0, sizeof(double) * d, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_w, sizeof(double) * g * cm * d, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_cst, sizeof(double) * g * cm, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_inv_var, sizeof(double) * d, hs));
     SmmEmBwdArgs a{st.videos, st.order, st.n_states, st.em_cum, x, g_elp, g_w, g_cst, g_inv_var,
                    shape->d, shape->c_max, shape->b, st.em_blocks};
     smm_launch_emission_bwd(a, st.c_need, hs);
@@ -558,10 +585,10 @@ extern "C" int smm_logz_bwd_f64(const smm_shape *shape, const int64_t *lengths_h
         rc = smm_launch_logz(a, logz_b, ring_regs(st.kp_max), st.c_need, hs);
         if (rc != SMM_OK) return rc;
     }
-    SMM_HIP(hipMemsetAsync(g_trans, 0, sizeof(double) * g * cm * cm, hs));
-    SMM_HIP(hipMemsetAsync(g_init, 0, sizeof(double) * g * cm, hs));
-    SMM_HIP(hipMemsetAsync(g_len, 0, sizeof(double) * g * shape->k_rows * cm, hs));
-    SMM_HIP(hipMemsetAsync(g_elp, 0, sizeof(double) * (size_t)shape->total_frames * cm, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_trans, sizeof(double) * g * cm * cm, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_init, sizeof(double) * g * cm, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_len, sizeof(double) * g * shape->k_rows * cm, hs));
+    SMM_HIP((hipError_t)smm_zero_async(g_elp, sizeof(double) * (size_t)shape->total_frames * cm, hs));
     SmmBwdArgs m{st.videos, st.n_states, trans, len_scores, st.hist, logz, grad_logz, g_elp, g_trans, g_init, g_len,
                  shape->c_max, shape->k_rows, shape->b, elp, no_eos ? 1 : 0};
     smm_launch_marginals(m, shape->t_max, st.kp_max, hs);

@@ -342,7 +342,7 @@ extern "C" int smm_eval_confusion_i64(const smm_eval_shape *s, const int64_t *le
     a.local_of = local_of;
     a.confusion = confusion;
     const size_t w = (size_t)s->c_max + 1;
-    if (hipMemsetAsync(confusion, 0, sizeof(int64_t) * s->n_groups * w * w, stream) != hipSuccess) return SMM_ERR_HIP;
+    if (smm_zero_async(confusion, sizeof(int64_t) * s->n_groups * w * w, stream) != (int)hipSuccess) return SMM_ERR_HIP;
     dim3 grid(s->b, (s->t_max + SMM_EVAL_CHUNK - 1) / SMM_EVAL_CHUNK);
     hipLaunchKernelGGL(smm_eval_confusion_kernel, grid, dim3(SMM_EVAL_THREADS), sizeof(unsigned int) * w * w, stream, a);
     return hipGetLastError() == hipSuccess ? SMM_OK : SMM_ERR_HIP;

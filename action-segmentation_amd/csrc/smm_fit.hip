@@ -276,14 +276,14 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
 #define SMM_FIT_HIP(call) do { if ((call) != hipSuccess) return SMM_ERR_HIP; } while (0)
     SMM_FIT_HIP((hipError_t)smm_upload_meta(base, hv.data(), sizeof(SmmFitVideo) * b, stream));
     SMM_FIT_HIP((hipError_t)smm_upload_meta(base + fit_off_cum(b), cum.data(), sizeof(int32_t) * ((size_t)b + 1), stream));
-    SMM_FIT_HIP(hipMemsetAsync(base + o_err, 0, 64, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(base + o_err, 64, stream));
     const size_t n = (size_t)n_classes;
-    SMM_FIT_HIP(hipMemsetAsync(sum_x, 0, sizeof(double) * n * d, stream));
-    SMM_FIT_HIP(hipMemsetAsync(sum_x2, 0, sizeof(double) * d, stream));
-    SMM_FIT_HIP(hipMemsetAsync(frame_counts, 0, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP(hipMemsetAsync(span_counts, 0, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP(hipMemsetAsync(span_start_counts, 0, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP(hipMemsetAsync(span_transition_counts, 0, sizeof(int64_t) * n * n, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(sum_x, sizeof(double) * n * d, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(sum_x2, sizeof(double) * d, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(frame_counts, sizeof(int64_t) * n, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(span_counts, sizeof(int64_t) * n, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(span_start_counts, sizeof(int64_t) * n, stream));
+    SMM_FIT_HIP((hipError_t)smm_zero_async(span_transition_counts, sizeof(int64_t) * n * n, stream));
     SmmFitArgs a{};
     a.videos = reinterpret_cast<const SmmFitVideo *>(base);
     a.x = x;

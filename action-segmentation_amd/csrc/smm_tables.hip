@@ -234,10 +234,10 @@ extern "C" int smm_factor_tables_bwd_f64(const smm_tables_shape *s, const float 
         return SMM_ERR_ARG;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const size_t n = s->n_classes;
-    if (hipMemsetAsync(g_init_logits, 0, sizeof(double) * n, hs) != hipSuccess ||
-        hipMemsetAsync(g_transition_logits, 0, sizeof(double) * n * n, hs) != hipSuccess ||
-        hipMemsetAsync(g_poisson_log_rates, 0, sizeof(double) * n, hs) != hipSuccess ||
-        hipMemsetAsync(g_gaussian_means, 0, sizeof(double) * n * s->d, hs) != hipSuccess)
+    if (smm_zero_async(g_init_logits, sizeof(double) * n, hs) != (int)hipSuccess ||
+        smm_zero_async(g_transition_logits, sizeof(double) * n * n, hs) != (int)hipSuccess ||
+        smm_zero_async(g_poisson_log_rates, sizeof(double) * n, hs) != (int)hipSuccess ||
+        smm_zero_async(g_gaussian_means, sizeof(double) * n * s->d, hs) != (int)hipSuccess)
         return SMM_ERR_HIP;
     SmmTabArgs a{};
     a.log_rates = poisson_log_rates; a.means = gaussian_means; a.cov = gaussian_cov;

@@ -569,3 +569,43 @@ def test_logz_both_directions_in_one_launch(shape):
     np.testing.assert_array_equal(res[0][0], res[1][0])
     for k_ in res[0][1]:
         np.testing.assert_allclose(res[1][1][k_], res[0][1][k_], rtol=1e-12, atol=1e-15, err_msg=k_)   # (atomics: order of sums)
+
+
+def test_many_short_videos_past_the_16_bit_grid_limits():
+    """3000 videos x 24 states: b * c_max = 72 000 workgroups in the length-gradient kernel's grid (grid.y / grid.z stop
+    at 65 535), 3000 one-workgroup videos in every DP launch.  Decode, log Z and the gradients of a packed launch must
+    equal those of the same videos launched 60 at a time."""
+    ops = _ops()
+    b, tmax, c, k = 3000, 12, 24, 6
+    p = make_problem(77, b, tmax, c, k, min_len=3)
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    elp = t(p['elp'].reshape(b * tmax, c))
+    tabs = (t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+
+    def run(idx):
+        idx = np.asarray(idx)
+        batch = ops.Batch(p['lengths'][idx], [c], k, c_max=c, frame_offset=idx.astype(np.int64) * tmax, t_max=tmax,
+                          total_frames=b * tmax)
+        ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=dev)
+        dec = ops.viterbi(batch, elp, *tabs, want_spans=True, want_labels=True)
+        z = ops.logz(batch, elp, *tabs, ws=ws, with_backward=True)
+        g = ops.logz_bwd(batch, elp, *tabs, z, ws=ws, with_backward=True)
+        torch.cuda.synchronize()
+        ops.check_decoded(batch, dec)
+        return dec, z, g
+
+    dec, z, g = run(np.arange(b))
+    g_len = torch.zeros_like(g['len']); g_trans = torch.zeros_like(g['trans'])
+    for lo in range(0, b, 60):
+        idx = np.arange(lo, min(b, lo + 60))
+        d2, z2, g2 = run(idx)
+        np.testing.assert_array_equal(dec['spans'][idx].cpu().numpy(), d2['spans'].cpu().numpy())
+        np.testing.assert_array_equal(dec['best'][idx].cpu().numpy(), d2['best'].cpu().numpy())
+        np.testing.assert_allclose(z[idx].cpu().numpy(), z2.cpu().numpy(), rtol=1e-12)
+        for i in idx:
+            f0, f1 = i * tmax, i * tmax + int(p['lengths'][i])
+            np.testing.assert_allclose(g['elp'][f0:f1].cpu().numpy(), g2['elp'][f0:f1].cpu().numpy(), rtol=1e-9, atol=1e-12)
+        g_len += g2['len']; g_trans += g2['trans']
+    np.testing.assert_allclose(g['len'].cpu().numpy(), g_len.cpu().numpy(), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(g['trans'].cpu().numpy(), g_trans.cpu().numpy(), rtol=1e-8, atol=1e-9)

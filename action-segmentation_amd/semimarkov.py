@@ -265,10 +265,13 @@ class SemiMarkovModel(object):
         # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
         torch.cuda.current_stream().synchronize()
-        labels = out['labels'].numpy().copy()       # (the pinned staging buffer is reused by the next decode)
+        # (the pinned staging buffer is reused by the next decode: copy out of it -- torch's copy and reduction run on
+        # all host cores, numpy's on one: 20 MB of labels per cfg3 decode)
+        lab_t = out['labels'].clone()
         ops.check_decoded(pc.batch, out)
         # one pass over the whole frame axis instead of one scan per video (frames no video covers hold -1)
-        assert int(labels.max(initial=-1)) < self.model.n_classes, "predictions should not contain EOS"
+        assert lab_t.numel() == 0 or int(lab_t.max()) < self.model.n_classes, "predictions should not contain EOS"
+        labels = lab_t.numpy()
         return {name: labels[off:off + t] for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths)}
 
     def predict(self, test_data, fused=True, shard=None):

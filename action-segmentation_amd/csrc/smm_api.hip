@@ -177,7 +177,10 @@ static double frame_ns_single(int c)
 {
     int nv[7];
     for (int r = 0; r < 7; ++r) nv[r] = c > r ? (c - r + 6) / 7 : 0;
-    const int load = std::max(std::max(nv[0] + nv[4], nv[1] + nv[5]), nv[2] + nv[3]);
+    const int sw = smm_rebalanced_rank(c);                  // (smm_device.h: the kernel's wave <-> rank mapping)
+    if (sw >= 0) std::swap(nv[sw], nv[6]);
+    // SIMDs: ranks (0,4), (1,5), (2,3) and chain wave (+ its partner's mover duty: ~2.5 states) + rank 6
+    const double load = std::max(std::max<double>(std::max(nv[0] + nv[4], nv[1] + nv[5]), nv[2] + nv[3]), 2.5 + nv[6]);
     return std::max(310.0, 73.0 * load) + 15.0;
 }
 

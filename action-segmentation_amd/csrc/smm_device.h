@@ -45,6 +45,17 @@ struct SmmDpArgs {
     int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
 };
 
+// One-CU videos on 8 waves: the rank (0..6) that trades places with the chain wave's partner (rank 6, the lightest) so
+// that no SIMD carries two of the fuller pusher waves; -1: none.  Ranks below C % 7 own one state more and the waves of
+// ranks (0,4), (1,5), (2,3) share a SIMD: with FOUR fuller ranks (18 states: 3+2 | 3+2 | 3+3 | chain+2) the partner
+// takes rank 3 instead (3+2 | 3+2 | 3+2 | chain+3: 438 -> 402 ns per frame).  With ONE fuller rank (15 states) the same
+// trade measured worse (391 against 365 ns: the chain wave and the mover duty of its partner weigh ~2.5 states).
+// Shared with the host's cost model (smm_api.hip: frame_ns_single).
+__host__ __device__ inline int smm_rebalanced_rank(int c)
+{
+    return (c >= 14 && c % 7 == 4) ? 3 : -1;
+}
+
 // ---- 64-bit register helpers -------------------------------------------------------------------
 __device__ __forceinline__ double smm_pack(int lo, int hi) { return __hiloint2double(hi, lo); }
 

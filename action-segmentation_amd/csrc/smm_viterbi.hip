@@ -763,7 +763,12 @@ smm_viterbi_kernel(SmmDpArgs a)
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
         // owns the fewest states
         int rank = w - 1;
-        if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+        if (NW == 8) {
+            rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+            // ... unless that leaves one SIMD with two of the fuller waves (smm_device.h: smm_rebalanced_rank)
+            const int swap = smm_rebalanced_rank(C);
+            if (swap >= 0) rank = (rank == swap) ? NP - 1 : ((rank == NP - 1) ? swap : rank);
+        }
         // (12 waves: every pusher owns SPW states, nothing to rebalance)
         const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);

@@ -399,7 +399,7 @@ static int run_emission(const smm_shape *s, const Staged &st, const float *x, co
                         const double *inv_var, const float *cons, double *elp64, float *elp32, hipStream_t stream)
 {
     if (!x || !w || !cst || !inv_var || s->d < 1 || (!elp64 && !elp32)) return SMM_ERR_ARG;
-    if ((size_t)((s->d + 15) & ~15) * (st.c_need <= 16 ? 21 : 33) * sizeof(double) > 160 * 1024)
+    if ((size_t)((s->d + 15) & ~15) * (st.c_need <= 16 ? 21 : 37) * sizeof(double) > 160 * 1024)
         return SMM_ERR_UNSUPPORTED;   // the group's weight table must fit the CU's LDS (D <= 640 at 32 states)
     SmmEmArgs a{st.videos, st.order, st.n_states, x, w, cst, inv_var, cons, elp64, elp32, s->d, s->c_max, s->b};
     smm_launch_emission(a, st.c_need, st.em_tpw, st.em_blocks, st.em_cum, s->total_frames, stream);

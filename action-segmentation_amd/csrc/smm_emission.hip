@@ -45,18 +45,23 @@ __device__ __forceinline__ int smm_em_find_video(const int32_t *__restrict__ cum
 // NT   state tiles of 16 (1: C <= 16, 2: C <= 32)        VEC  D % 4 == 0: 16-byte loads of x
 // CONS narration constraints are added (they travel through the same pipeline as x: a load in the epilogue would make
 //      the wave wait for every x load in flight)
-template <int NT, bool VEC, bool CONS>
+// NG  (NT = 2) 4-state groups behind the first 16 states that the launch's largest class set needs: 1..4
+template <int NT, bool VEC, bool CONS, int NG>
 __global__ void __launch_bounds__(SMM_EM_WAVES * 64)
 smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
                     float *__restrict__ elp32, int D, int cm, int tpw, const int32_t *__restrict__ blk_cum, int nvid)
 {
-    // LDS: this group's weights (zero padded) in the order the lanes read them, then inv_var[D16].
-    //   NT = 2: row d = 16 pairs {w[d][fr], w[d][16+fr]} (one ds_read_b128 per lane and MFMA pair; rows 256 B: the four
-    //           k groups of a macro-step read rows 4 apart = 1 KB apart, conflict-free in ds_read_b128's lane groups)
-    //   NT = 1: row d = 16 doubles, row stride 20 doubles (160 B: rows 4 apart land 128 B apart modulo the 256-B bank
-    //           span, so the two k groups of a ds_read_b64 half-wave do not collide)
+    // LDS: this group's weights (zero padded), row d = w[d][0 .. 16 NT), then inv_var[D16].  Row stride 20 (NT = 1) /
+    // 36 (NT = 2) doubles: rows 4 apart -- the two k groups of a ds_read_b64 half-wave -- land 128 B apart modulo the
+    // 256-B bank span and do not collide.
+    // NT = 2 (17..32 states): states 0..15 are one 16x16x4 tile as for NT = 1; states 16.. go through
+    // v_mfma_f64_4x4x4_4b_f64 in groups of FOUR: its four blocks are the four 4-frame groups of the tile, all with the
+    // same B (A[i][k] of block b: lane 16 k + 4 b + i -- the lane <-> (frame, k) mapping of the A operand above, so the
+    // x registers serve both forms; B[k][j]: lane 16 k + 4 b + j; D[i][j]: lane 16 i + 4 b + j).  16 cycles per group
+    // and 4 features against 64 for a second 16-state tile (same FLOP rate at a quarter of the granularity,
+    // profiles/round2_ubench_mfma_f64_4x4.txt): 21..24 states cost 96 cycles instead of 128, 17..20 cost 80.
     extern __shared__ __attribute__((aligned(16))) double wl[];
     // flat grid: blk_cum[i] = workgroups of the videos order[0..i) (longest videos first: no long workgroup starts late)
     const int slot = smm_em_find_video(blk_cum, nvid, blockIdx.x);
@@ -70,20 +75,21 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
     const int nbv = blk_cum[slot + 1] - blk_cum[slot];
     const int D16 = (D + 15) & ~15;
-    constexpr int WS = (NT == 2) ? 32 : 20;                          // LDS row stride (doubles)
-    const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // state tiles this video really needs
+    constexpr int WS = (NT == 2) ? 36 : 20;                          // LDS row stride (doubles)
+    const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // more than the first 16-state tile?
+    const int ng1 = (NT == 2 && C > 16) ? (C - 13) >> 2 : 0;         // groups of 4 states behind it: ceil((C - 16) / 4)
     double *ivl = wl + (size_t)D16 * WS;
     {
         const double *__restrict__ w = wall + (size_t)g * D * cm;
         for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
-            const int d = i / (16 * NT), r = i - d * (16 * NT);
-            const int c = (NT == 2) ? (r >> 1) + 16 * (r & 1) : r;  // NT = 2: pairs {fr, 16 + fr}
-            wl[(size_t)d * WS + r] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
+            const int d = i / (16 * NT), c = i - d * (16 * NT);
+            wl[(size_t)d * WS + c] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
         }
         for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
     }
     __syncthreads();
     const int fr = lane & 15, kq = lane >> 4;
+    const int jj = lane & 3, row1 = (fr & 12) + kq;                  // 4x4x4 result: state 16 + 4 g + jj of frame row1
     const float *__restrict__ xv = xall + (size_t)mv.frame_off * D;
     const double *__restrict__ cst = cstall + (size_t)g * cm;
 
@@ -110,10 +116,15 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
             for (int i = 0; i < 4; ++i) {
                 const int ff = f0 + kq + 4 * i;
                 const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
+                cb[i] = cons[rowo + (fr < cm ? fr : cm - 1)];
+            }
+            if constexpr (NT == 2) {                                 // states 16 + 4 g + jj of frame row1 (4x4x4 result layout)
+                const int ff = f0 + row1;
+                const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int c = 16 * t + fr;
-                    cb[4 * t + i] = cons[rowo + (c < cm ? c : cm - 1)];
+                for (int g4 = 0; g4 < NG; ++g4) {
+                    const int c = 16 + 4 * g4 + jj;
+                    cb[4 + g4] = cons[rowo + (c < cm ? c : cm - 1)];
                 }
             }
         }
@@ -142,30 +153,26 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
 
     // compute side
     int ct = 0, cc = 0;
-    smm_d4 acc[NT];
+    smm_d4 acc = (smm_d4){0.0, 0.0, 0.0, 0.0};
+    constexpr int G1 = (NT == 2) ? NG : 1;                           // (NT = 1: unused dummies)
+    double acc1[G1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+    for (int g4 = 0; g4 < G1; ++g4) acc1[g4] = 0.0;
     double q = 0.0;
-    double cstv[NT];
+    const double cstv = (fr < C) ? cst[fr] : 0.0;
+    double cst1[G1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) cstv[t] = (16 * t + fr < C) ? cst[16 * t + fr] : 0.0;
-    // B operands of one macro-step: 4 x {w[d][fr], w[d][16 + fr]}, d = 16 ms + 4 kq + j.  They are read from LDS one
+    for (int g4 = 0; g4 < G1; ++g4) cst1[g4] = (NT == 2 && 16 + 4 * g4 + jj < C) ? cst[16 + 4 * g4 + jj] : 0.0;
+    // B operands of the 16x16x4 tile for one macro-step, d = 16 ms + 4 kq + j: w[d][fr].  They are read from LDS one
     // macro-step ahead of the MFMAs that use them (wcur lives across consume() calls and across tiles: the weights do
-    // not depend on the tile), so an MFMA never waits for its own LDS read.  inv_var[d] is read at the top of the
-    // macro-step and used after its MFMAs have been issued.
-    double wcur[4][NT];
-    auto load_ops = [&](int ms, double (&wv)[4][NT]) {
+    // not depend on the tile), so an MFMA never waits for its own LDS read.  The operands of the 4x4x4 groups,
+    // w[d][16 + 4 g + jj], are read at the top of their j step and used behind its 16x16x4 instruction (64 cycles of
+    // cover) -- prefetching them a macro-step ahead as well would cost 16 NG registers and the second workgroup per CU.
+    // inv_var[d] is read at the top of the macro-step and used after its MFMAs have been issued.
+    double wcur[4];
+    auto load_ops = [&](int ms, double (&wv)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = 16 * ms + 4 * kq + j;
-            if constexpr (NT == 2) {
-                const double2 t2 = *reinterpret_cast<const double2 *>(&wl[(size_t)d * WS + 2 * fr]);
-                wv[j][0] = t2.x;
-                wv[j][NT - 1] = t2.y;
-            } else {
-                wv[j][0] = wl[(size_t)d * WS + fr];
-            }
-        }
+        for (int j = 0; j < 4; ++j) wv[j] = wl[(size_t)(16 * ms + 4 * kq + j) * WS + fr];
     };
     load_ops(0, wcur);
     auto consume = [&](const float4 (&buf)[4], const float (&cb)[CONS ? 4 * NT : 1]) {
@@ -173,28 +180,31 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
         for (int m = 0; m < 4; ++m) {
             const int ms = 4 * cc + m;
             if (ms < nms) {
-                double wnext[4][NT], iv4[4];
+                double wnext[4], iv4[4];
                 load_ops(ms + 1 < nms ? ms + 1 : 0, wnext);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) iv4[j] = ivl[16 * ms + 4 * kq + j];
                 double av[4];
                 av[0] = (double)buf[m].x; av[1] = (double)buf[m].y; av[2] = (double)buf[m].z; av[3] = (double)buf[m].w;
-                if (nt == 2) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
-                        acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][NT - 1], acc[NT - 1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    double wg[G1];
+                    if constexpr (NT == 2) {
+#pragma unroll
+                        for (int g4 = 0; g4 < NG; ++g4)
+                            wg[g4] = wl[(size_t)(16 * ms + 4 * kq + j) * WS + 16 + 4 * (g4 < ng1 ? g4 : 0) + jj];
                     }
-                } else {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j], acc, 0, 0, 0);
+                    if constexpr (NT == 2) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j][0], acc[0], 0, 0, 0);
+                        for (int g4 = 0; g4 < NG; ++g4)
+                            if (g4 < ng1) acc1[g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[j], wg[g4], acc1[g4], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     q = fma(av[j] * iv4[j], av[j], q);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) wcur[j][t] = wnext[j][t];
+                    wcur[j] = wnext[j];
                 }
             }
         }
@@ -208,22 +218,31 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
             const int row = kq + 4 * i;                              // frame of accumulator register i
             const double qr = __shfl(q, row);
             const int ff = f0 + row;
-            if (ff < T) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int c = 16 * t + fr;
-                    if (c < C) {
-                        const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
-                        double v = (cstv[t] + acc[t][i]) - 0.5 * qr;
-                        if constexpr (CONS) v += (double)cb[4 * t + i];
-                        if (elp64) elp64[o] = v;
-                        if (elp32) elp32[o] = (float)v;
-                    }
-                }
+            if (ff < T && fr < C) {
+                const size_t o = (size_t)(mv.frame_off + ff) * cm + fr;
+                double v = (cstv + acc[i]) - 0.5 * qr;
+                if constexpr (CONS) v += (double)cb[i];
+                if (elp64) elp64[o] = v;
+                if (elp32) elp32[o] = (float)v;
             }
         }
+        if constexpr (NT == 2) {                                     // 4x4x4 groups: frame row1, states 16 + 4 g + jj
+            const double qr = __shfl(q, row1);
+            const int ff = f0 + row1;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+            for (int g4 = 0; g4 < NG; ++g4) {
+                const int c = 16 + 4 * g4 + jj;
+                if (g4 < ng1 && ff < T && c < C) {
+                    const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
+                    double v = (cst1[g4] + acc1[g4]) - 0.5 * qr;
+                    if constexpr (CONS) v += (double)cb[4 + g4];
+                    if (elp64) elp64[o] = v;
+                    if (elp32) elp32[o] = (float)v;
+                }
+                acc1[g4] = 0.0;
+            }
+        }
+        acc = (smm_d4){0.0, 0.0, 0.0, 0.0};
         q = 0.0;
         cc = 0;
         ++ct;
@@ -452,7 +471,8 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
 {
     const int d16 = (a.d + 15) & ~15;
     dim3 grid(n_blocks), block(SMM_EM_WAVES * 64);
-    const size_t lds_w = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);        // weights + inv_var
+    const size_t lds_w = sizeof(double) * d16 * (ct <= 16 ? 21 : 37);        // weights (row stride 20 / 36) + inv_var
+    const size_t lds_w2 = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);       // (v2's layout)
     const bool vec = (a.d & 3) == 0;
     // v2 (x staged through LDS in whole lines): row stride == 8 (mod 16) floats, >= D
     int rs = (a.d / 16) * 16 + 8;
@@ -462,7 +482,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
     // v2 is opt-in (SMM_EMISSION_V2=1): measured on cfg3 (rocprofv3, profiles/round2_emission_v1_v2.txt) it takes 0.77 ms
     // against v1's 0.62 ms -- its LDS footprint (weights + 8 tile buffers = 157 KB) leaves ONE 8-wave workgroup per CU
     // where v1 runs two, and the kernel turned out not to be bound by the 64-byte row pieces of v1's loads.
-    const bool v2 = vec && nld <= 20 && lds_w + lds_x <= 160 * 1024 && std::getenv("SMM_EMISSION_V2");
+    const bool v2 = vec && nld <= 20 && lds_w2 + lds_x <= 160 * 1024 && std::getenv("SMM_EMISSION_V2");
     const int nsel = nld <= 4 ? 0 : (nld <= 8 ? 1 : (nld <= 13 ? 2 : 3));     // compiled load counts: 4, 8, 13, 20
     auto go1 = [&](auto kern) {
         if (lds_w > 48 * 1024)
@@ -471,7 +491,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
                            a.elp64, a.elp32, a.d, a.c_max, tpw, blk_cum, a.b);
     };
     auto go2 = [&](auto kern) {
-        const size_t lds = lds_w + lds_x;
+        const size_t lds = lds_w2 + lds_x;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
@@ -494,17 +514,29 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
 #undef SMM_EM_V2
         return;
     }
-    const int sel = (ct <= 16 ? 0 : 4) + (vec ? 2 : 0) + (a.cons ? 1 : 0);
-    switch (sel) {
-    case 0: go1(smm_emission_kernel<1, false, false>); break;
-    case 1: go1(smm_emission_kernel<1, false, true>); break;
-    case 2: go1(smm_emission_kernel<1, true, false>); break;
-    case 3: go1(smm_emission_kernel<1, true, true>); break;
-    case 4: go1(smm_emission_kernel<2, false, false>); break;
-    case 5: go1(smm_emission_kernel<2, false, true>); break;
-    case 6: go1(smm_emission_kernel<2, true, false>); break;
-    default: go1(smm_emission_kernel<2, true, true>); break;
+    const int ng = ct <= 16 ? 0 : (ct - 13) >> 2;                            // 4-state groups behind the first 16 states
+#define SMM_EM_V1(NG_)                                                                          \
+    switch ((vec ? 2 : 0) + (a.cons ? 1 : 0)) {                                                 \
+    case 0: go1(smm_emission_kernel<2, false, false, NG_>); break;                             \
+    case 1: go1(smm_emission_kernel<2, false, true, NG_>); break;                              \
+    case 2: go1(smm_emission_kernel<2, true, false, NG_>); break;                              \
+    default: go1(smm_emission_kernel<2, true, true, NG_>); break;                              \
     }
+    switch (ng) {
+    case 0:
+        switch ((vec ? 2 : 0) + (a.cons ? 1 : 0)) {
+        case 0: go1(smm_emission_kernel<1, false, false, 0>); break;
+        case 1: go1(smm_emission_kernel<1, false, true, 0>); break;
+        case 2: go1(smm_emission_kernel<1, true, false, 0>); break;
+        default: go1(smm_emission_kernel<1, true, true, 0>); break;
+        }
+        break;
+    case 1: SMM_EM_V1(1) break;
+    case 2: SMM_EM_V1(2) break;
+    case 3: SMM_EM_V1(3) break;
+    default: SMM_EM_V1(4) break;
+    }
+#undef SMM_EM_V1
 }
 
 // ------------------------------------------------------------------------------------------------ chain rule (training)

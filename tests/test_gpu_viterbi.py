@@ -305,7 +305,10 @@ def test_multi_group_ragged_batch():
             vi += 1
 
 
-@pytest.mark.parametrize('cfg', [(3, 70, 5, 7), (2, 300, 200, 20), (1, 129, 64, 32), (2, 64, 33, 9)])
+@pytest.mark.parametrize('cfg', [(3, 70, 5, 7), (2, 300, 200, 20), (1, 129, 64, 32), (2, 64, 33, 9),
+                                 # 17..32 states: first 16 on the 16x16x4 MFMA, the rest in 4-state groups on the 4x4x4 form
+                                 (2, 200, 200, 23), (2, 100, 40, 17), (1, 90, 48, 27), (2, 77, 36, 25), (2, 50, 24, 21),
+                                 (1, 40, 17, 29)])
 def test_emission_matches_oracle(cfg):
     ops = _ops()
     b, tmax, d, c = cfg

@@ -248,17 +248,33 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
         ++ct;
     };
 
-    // two chunk buffers: one in flight while the other feeds the MFMAs (a third would push the kernel past 128 VGPRs,
-    // i.e. from two workgroups per CU to one)
+    // chunk buffers: without constraints THREE (two chunks = 8 KB per wave in flight while the third feeds the MFMAs;
+    // 102 + 16 VGPRs at NG = 2, still two workgroups per CU), with constraints two (their registers take the room)
     float4 b0[4], b1[4];
     float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1];
-    fetch(b0, c0);
-    for (int it = 0; it < total; it += 2) {
-        fetch(b1, c1);
-        consume(b0, c0);
-        if (it + 1 >= total) break;
+    if constexpr (!CONS && VEC) {
+        float4 b2[4];
         fetch(b0, c0);
-        consume(b1, c1);
+        fetch(b1, c0);
+        for (int it = 0; it < total; it += 3) {
+            fetch(b2, c0);
+            consume(b0, c0);
+            if (it + 1 >= total) break;
+            fetch(b0, c0);
+            consume(b1, c0);
+            if (it + 2 >= total) break;
+            fetch(b1, c0);
+            consume(b2, c0);
+        }
+    } else {
+        fetch(b0, c0);
+        for (int it = 0; it < total; it += 2) {
+            fetch(b1, c1);
+            consume(b0, c0);
+            if (it + 1 >= total) break;
+            fetch(b0, c0);
+            consume(b1, c1);
+        }
     }
 }
 

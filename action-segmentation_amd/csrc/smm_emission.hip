@@ -248,33 +248,18 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
         ++ct;
     };
 
-    // chunk buffers: without constraints THREE (two chunks = 8 KB per wave in flight while the third feeds the MFMAs;
-    // 102 + 16 VGPRs at NG = 2, still two workgroups per CU), with constraints two (their registers take the room)
+    // two chunk buffers: one in flight while the other feeds the MFMAs.  (A third -- the 4x4x4 form left the registers for
+    // it -- measured 1 % SLOWER on the same box, cfg2 and cfg3: two chunks per wave x 16 waves per CU already cover the
+    // latency; the extra prologue fetch only delays the first MFMA.)
     float4 b0[4], b1[4];
     float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1];
-    if constexpr (!CONS && VEC) {
-        float4 b2[4];
+    fetch(b0, c0);
+    for (int it = 0; it < total; it += 2) {
+        fetch(b1, c1);
+        consume(b0, c0);
+        if (it + 1 >= total) break;
         fetch(b0, c0);
-        fetch(b1, c0);
-        for (int it = 0; it < total; it += 3) {
-            fetch(b2, c0);
-            consume(b0, c0);
-            if (it + 1 >= total) break;
-            fetch(b0, c0);
-            consume(b1, c0);
-            if (it + 2 >= total) break;
-            fetch(b1, c0);
-            consume(b2, c0);
-        }
-    } else {
-        fetch(b0, c0);
-        for (int it = 0; it < total; it += 2) {
-            fetch(b1, c1);
-            consume(b0, c0);
-            if (it + 1 >= total) break;
-            fetch(b0, c0);
-            consume(b1, c1);
-        }
+        consume(b1, c1);
     }
 }
 

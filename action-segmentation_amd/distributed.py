@@ -81,6 +81,30 @@ def broadcast_parameters(module, src=0):
                 t.copy_(buf.to(t.device))
 
 
+def all_reduce_gradients(parameters, average=False):
+    """Sum (or mean) of the gradients over the ranks, as ONE collective on a flat fp32/fp64 buffer (five small tensors:
+    SURVEY.md 8e, "a gradient all-reduce of the 5 small parameter tensors per step").  Parameters without a gradient
+    on this rank (it had no batch of that step) count as zeros.  No-op for a single process."""
+    if not active():
+        return
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return
+    with torch.no_grad():
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1).to(torch.float64) for p in params])
+        flat = all_reduce_tensor(flat)
+        if average:
+            flat = flat / dist.get_world_size()
+        i = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[i:i + n].view_as(p.grad).to(p.grad.dtype))
+            i += n
+
+
 def shard_batches(batches, costs, rank, world):
     """Greedy longest-processing-time assignment of whole (single-task) batches to ranks.
 

@@ -111,6 +111,19 @@ class SemiMarkovModel(object):
         # same mean over batches of the batch-mean -log Z, so the step is the reference's step.
         packed = (not use_labels) and args.batch_accumulation > 1
         train_cons = self._train_constraints(train_data)
+        # Data-parallel training under torch.distributed: every rank walks the same shuffled batch order
+        # (the sampler's RNG is seeded identically), the batches of one optimiser step are dealt round-robin to the
+        # ranks, each rank back-propagates the sum of its batches' losses / --batch_accumulation, and ONE all-reduce
+        # sums the gradients of the five parameter tensors: the step is the single-process step.  (One batch per step,
+        # --batch_accumulation 1, cannot be split: the ranks then repeat the batch and average, which keeps their
+        # parameters bit-identical although the kernels' atomics round differently from run to run.)
+        from . import distributed
+        dp = distributed.active()
+        if dp:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            distributed.broadcast_parameters(self.model)
+        trained = [p for p in self.model.parameters() if p.requires_grad]
         for epoch in range(args.epochs):
             start_time = time.time()
             self.model.train()
@@ -122,6 +135,8 @@ class SemiMarkovModel(object):
                     print('Epoch: %02d, Batch: %03d/%03d, loss: %.4f, recon: %.4f, Throughput: %.2f vid / sec' % (
                         epoch, batch_ix, len(loader), train_nll / num_videos, train_nll / num_frames,
                         num_videos / (time.time() - start_time)))
+                if dp:
+                    distributed.all_reduce_gradients(trained, average=not packed)
                 if args.max_grad_norm is not None:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(), args.max_grad_norm)
                 optimizer.step()
@@ -136,12 +151,18 @@ class SemiMarkovModel(object):
                 if packed:
                     pending.append(batch)
                     if len(pending) >= args.batch_accumulation:
-                        pc = pack_batches(pending, self.device, self.model.max_k, constraints_fn=train_cons,
-                                          additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
-                        ll = self.model.log_likelihood_packed(pc)              # [batches]
-                        loss_b = -ll
-                        loss_b.mean().backward()
-                        vals = loss_b.detach().cpu().tolist()
+                        mine = list(range(rank, len(pending), world)) if dp else list(range(len(pending)))
+                        vals_t = torch.zeros(len(pending), dtype=torch.float64, device=self.device)
+                        if mine:
+                            pc = pack_batches([pending[i] for i in mine], self.device, self.model.max_k, constraints_fn=train_cons,
+                                              additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
+                            ll = self.model.log_likelihood_packed(pc)          # [this rank's batches]
+                            loss_b = -ll
+                            (loss_b.sum() / len(pending)).backward()           # == mean over the step's batches once summed over ranks
+                            vals_t[torch.as_tensor(mine, device=self.device)] = loss_b.detach()
+                        if dp:
+                            vals_t = distributed.all_reduce_tensor(vals_t)
+                        vals = vals_t.cpu().tolist()
                         self._check_finite(vals, batch_ix)
                         losses += vals
                         train_nll += sum(v * len(b['lengths']) for v, b in zip(vals, pending))

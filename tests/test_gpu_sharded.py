@@ -176,3 +176,42 @@ def test_bench_under_torchrun_launcher():
     one = _bench(['--gpus', '1', '--strong-leg', '--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1',
                   '--no-cpu-baseline', '--no-predict-e2e', '--seed', '5'])
     assert one['strong_scaling']['stats'] == line['strong_scaling']['stats']
+
+
+def _train(world, accum, tmp_path):
+    import socket
+    out = str(tmp_path / ('train_w%d_a%d.json' % (world, accum)))
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    script = os.path.join(ROOT, 'scripts', 'dp_train_check.py')
+    if world == 1:
+        cmd = [sys.executable, script, out, str(accum)]
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), script, out, str(accum)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize('accum', [4, 1])
+def test_data_parallel_training_reproduces_the_single_process_parameters(accum, tmp_path):
+    """unsupervised training shards over the ranks with one gradient all-reduce per optimiser step.  Two
+    ranks (gloo, both on the box's GPU) must end where one process ends: with --batch_accumulation 4 each rank
+    back-propagates two of the four batches of a step (packed launch); with 1 the ranks repeat the batch and average.
+    (The kernels' fp64 atomics round differently from run to run: equal to 1e-6, not bit for bit.)"""
+    one = _train(1, accum, tmp_path)
+    two = _train(2, accum, tmp_path)
+    assert one['world'] == 1 and two['world'] == 2
+    for (e1, l1), (e2, l2) in zip(one['logs'], two['logs']):
+        assert e1 == e2 and abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1)), (one['logs'], two['logs'])
+    moved = 0
+    for name, v1 in one['state'].items():
+        a, b = np.asarray(v1), np.asarray(two['state'][name])
+        np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-6, err_msg=name)
+        moved += float(np.abs(a).sum())
+    assert len(one['logs']) == 2 and moved > 0

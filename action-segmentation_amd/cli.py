@@ -87,7 +87,7 @@ def evaluate(model, data, name, args=None, verbose=True):
     by_task = accuracy_corpus(data, preds, optimal_assignment_for(args) if args is not None else False,
                               seed=getattr(args, 'seed', 0) if args is not None else 0, reduce=_reduce())
     stats = summarise(by_task, STAT_KEYS, prefix=name + '_')
-    if verbose:
+    if verbose and int(os.environ.get('RANK', 0)) == 0:
         print(', '.join(STAT_KEYS))
         print(', '.join('%.4f' % stats[name + '_' + k] for k in STAT_KEYS))
     return preds, stats
@@ -171,7 +171,9 @@ def main(argv=None):
     if not args.cuda:
         raise SystemExit("--cuda is required: the semi-Markov path has no CPU back-end in this build")
     from . import distributed
-    distributed.init()                                      # torchrun: one rank per GPU, decode sharded by video
+    # torchrun: one rank per GPU over RCCL, decode sharded by video, training data-parallel (SMM_DIST_BACKEND=gloo: a
+    # rehearsal with several ranks on one GPU)
+    distributed.init(backend=os.environ.get('SMM_DIST_BACKEND') or None)
     cfg_name = args.dataset.split(':', 1)[1]
     split_name = 'synthetic'
     torch.manual_seed(args.seed)

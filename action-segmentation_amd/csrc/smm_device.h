@@ -107,6 +107,15 @@ __device__ __forceinline__ double smm_max_halves(double x)
     return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
 }
 
+// max(x[lane], x[lane ^ 16]) in every lane: one v_permlane16_swap per 32-bit half (rows 1 <-> 0 and 3 <-> 2 trade places)
+__device__ __forceinline__ double smm_max_rows16(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
+}
+
 // Max over each DPP row (16 consecutive lanes) of an unsigned; every lane of the row receives it.
 // v_max_u32 with a rotated DPP source, 4 levels.  (2 wait states between a VALU write and a DPP read of
 // the same VGPR: hipcc pads nothing inside asm, so the s_nop's are part of the sequence.)

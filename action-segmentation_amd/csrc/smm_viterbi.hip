@@ -395,7 +395,10 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 }
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
-// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8, 12 or 16)
+// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per lane group of the chain wave: 8, 12 or 16
+//     (two groups of 32 lanes) or 4 (launches of at most 16 states without gangs: FOUR groups of 16 lanes, merged by a
+//     v_permlane16_swap on top of the v_permlane32_swap: 8 instructions fewer per position, same-box A/B: cfg2 DP -1 %,
+//     cfg4 DP -2.8 %)
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
 // CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
@@ -514,7 +517,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         // The serial chain is the critical path of a block; its SIMD partner is a pusher wave with an endless
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
-        const int to = lane & 31, half = lane >> 5;
+        constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
+        const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
         const bool live = to < C;
         double tr[HF];                                    // trans[to][half*HF + i]
 #pragma unroll
@@ -605,7 +609,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                                 bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
                             }
                         }
-                        const double beta = smm_max_halves(smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3])));
+                        double bm = smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3]));
+                        if constexpr (HF == 4) bm = smm_max_rows16(bm);
+                        const double beta = smm_max_halves(bm);
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % M] = hcur;
                         st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
@@ -1043,7 +1049,7 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
     }
     if (a.n_pairs > 0) return 0;                                 // (the host only pairs for the configuration above)
     // HF: source states per half of the chain wave (2 HF >= states)
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 4, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
     return 1;

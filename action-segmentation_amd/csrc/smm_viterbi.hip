@@ -517,6 +517,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // The serial chain is the critical path of a block; its SIMD partner is a pusher wave with an endless
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
+        constexpr bool GAMROW = (B > 4) || (R < 4);       // a separate gamma broadcast row (see the position loop)
         constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
         const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
         const bool live = to < C;
@@ -583,12 +584,15 @@ smm_viterbi_kernel(SmmDpArgs a)
                     const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
                     cum = cumn;
                     const double gm = cum + acc;
-                    st_gam[0] = gm;
+                    // The transition reads gamma back from its history staging row (one LDS store less per position:
+                    // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
+                    // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
+                    if constexpr (GAMROW) st_gam[0] = gm;
                     st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
                     st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
                     if (n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
-                        const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
+                        const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HF] : &sh_g[jj & 1][i][half * HF]);
                         double2 gv[HF / 2];
 #pragma unroll
                         for (int q = 0; q < HF / 2; ++q) gv[q] = gp[q];
@@ -615,6 +619,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % M] = hcur;
                         st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
+                    } else if constexpr (!GAMROW) {
+                        st_gam[0] = gm;                                      // gamma[T][.] for the closing step below
                     }
                 }
                 if constexpr (CP) {

@@ -477,6 +477,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ __attribute__((aligned(16))) double sh_along[PAIR ? 2 : 1][PAIR ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
+    __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
@@ -498,6 +499,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             if (PAIR) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[PAIR ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
         sh_gam[c] = SMM_NEG_INF;
+        sh_gfin[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
             hcum[c] = 0.0;
             if (lead) smm_st_agent(&hh[(size_t)c * (T + 1)], init[c]);             // (a pair's follower reads h rows)
@@ -518,6 +520,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
         constexpr bool GAMROW = (B > 4) || (R < 4);       // a separate gamma broadcast row (see the position loop)
+        constexpr bool TAILFREE = R < 16;                  // no bounds tests inside a block (see the position loop)
         constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
         const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
         const bool live = to < C;
@@ -539,6 +542,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
         // s_and_saveexec / branch / s_or groups per position) on the serial path.
         double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
+        double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
         double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
         double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
         double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
@@ -579,8 +583,14 @@ smm_viterbi_kernel(SmmDpArgs a)
                 double cumn = cum + ev[0];
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
+                    // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
+                    // also those past T in the tail of the last block (their rows are never stored, published or read):
+                    // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
+                    // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
+                    // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
+                    // shares the chain wave's SIMD): those keep the tests.
                     const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
-                    if (n > T) break;
+                    if constexpr (!TAILFREE) { if (n > T) break; }
                     const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
                     cum = cumn;
                     const double gm = cum + acc;
@@ -590,7 +600,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if constexpr (GAMROW) st_gam[0] = gm;
                     st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
                     st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
-                    if (n < T) {
+                    if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
+                    if (TAILFREE || n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HF] : &sh_g[jj & 1][i][half * HF]);
                         double2 gv[HF / 2];
@@ -619,8 +630,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % M] = hcur;
                         st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
-                    } else if constexpr (!GAMROW) {
-                        st_gam[0] = gm;                                      // gamma[T][.] for the closing step below
                     }
                 }
                 if constexpr (CP) {
@@ -878,7 +887,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
 
     // -------------------------------------------------------------------------------- last position
-    // sh_gam holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
+    // sh_gfin holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
     if (PAIR && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
         smm_publish(a.pair_flags + 4 * pair, T);
@@ -889,7 +898,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         if (lane <= last) {
             for (int c = 0; c < C; ++c) {
                 const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c];
-                f = fmax(f, sh_gam[c] + wgt);
+                f = fmax(f, sh_gfin[c] + wgt);
             }
             if (no_eos) f = f + elp[(size_t)T * cm + lane];   // the closing label only emits frame T
             else if (lane < C) f = f + SMM_BIG_NEG;

@@ -186,6 +186,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
+    __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
     __shared__ double sh_h0[SMM_MAX_STATES_DEV];
 
@@ -220,6 +221,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again: the chain wave's dead lanes must not read LDS garbage)
         }
         sh_gam[c] = SMM_NEG_INF;
+        sh_gfin[c] = SMM_NEG_INF;
         if (c < C) { hcum[c] = 0.0; hh[c] = h0; }
     }
     __syncthreads();
@@ -247,6 +249,8 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
         double cum = 0.0;
         // both halves compute every position; the upper half stores to a junk array (no exec juggling on the serial path)
         double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
+        double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
+        constexpr bool TAILFREE = R < 16;                  // no bounds tests inside a block (smm_viterbi.hip, the same loop)
         double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
         double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
         double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
@@ -284,7 +288,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     const int n = j * B + 1 + i;           // position; n mod MQ == (jj*B + 1 + i) mod MQ
-                    if (n > T) break;
+                    if constexpr (!TAILFREE) { if (n > T) break; }
                     // A[n] = LSE( (pm, ps), h[n-1] + len[1] )
                     const double x1 = hq[(jj * B + i + 4 * MQ) % MQ] + lk[1];
                     const double mx = smm_fmax(pm, x1);
@@ -296,7 +300,8 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     st_gam[0] = gm;
                     st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
                     st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
-                    if (n < T) {
+                    if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
+                    if (TAILFREE || n < T) {
                         // beta[to] = LSE_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HF]);
                         double2 gv[HF / 2];
@@ -420,24 +425,24 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     }
 
     // -------------------------------------------------------------------------------- last position
-    // sh_gam holds gamma[T][.]
+    // sh_gfin holds gamma[T][.]
     __syncthreads();
     if (w == 0) {
         double f = SMM_NEG_INF;
         if (!bwd) {
             if (no_eos) {
                 if (lane < C) {
-                    for (int c = 0; c < C; ++c) f = smm_lse2(f, sh_gam[c] + trans[(size_t)lane * cm + c]);
+                    for (int c = 0; c < C; ++c) f = smm_lse2(f, sh_gfin[c] + trans[(size_t)lane * cm + c]);
                     f = f + elp[(size_t)T * cm + lane];   // the closing label only emits frame T
                 }
             } else if (lane <= C) {
                 for (int c = 0; c < C; ++c) {
                     const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c] + SMM_BIG_NEG;
-                    f = smm_lse2(f, sh_gam[c] + wgt);
+                    f = smm_lse2(f, sh_gfin[c] + wgt);
                 }
             }
         } else if (lane < C) {
-            f = sh_gam[lane] + init[lane];               // closes the recursion: must reproduce log Z
+            f = sh_gfin[lane] + init[lane];               // closes the recursion: must reproduce log Z
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) f = smm_lse2(f, __shfl_xor(f, off));

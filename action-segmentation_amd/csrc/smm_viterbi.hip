@@ -118,8 +118,10 @@ __device__ __forceinline__ void smm_push(double (&A)[R], double (&L)[R], double 
 // this block is kept for the next one.
 template <int R, int B, int D>
 __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], double &hd, const double *h_blk,
-                                               double *a_blk, int j, int jj, int lane)
+                                               double *a_blk, int j, int jj, int lane, const double &ninf)
 {
+    // ninf: -inf in a register pair the caller keeps alive (one v_mov_b64 per cleared slot; the literal would cost two
+    // v_mov_b32 each, 12 VALU slots per block of a 3-state pusher)
     constexpr int RING = 64 * R;
     double hv[B];
 #pragma unroll
@@ -140,7 +142,7 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
             for (int i = 0; i < B; ++i) {
                 const int r = ((jj + 1) * B + i) % R;
                 a_blk[i * SMM_MAX_STATES_DEV] = A[r];
-                A[r] = SMM_NEG_INF;
+                A[r] = ninf;
             }
         }
     } else if constexpr (B % R == 0) {
@@ -150,7 +152,7 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 a_blk[(d * R + r) * SMM_MAX_STATES_DEV] = A[r];
-                A[r] = SMM_NEG_INF;
+                A[r] = ninf;
             }
         }
     } else {
@@ -159,7 +161,7 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
             const int r = ((jj + 1) * B + i) % R;
             if (lane == (((j + 1) * B + i) & (RING - 1)) / R) {
                 a_blk[i * SMM_MAX_STATES_DEV] = A[r];
-                A[r] = SMM_NEG_INF;
+                A[r] = ninf;
             }
         }
     }
@@ -513,6 +515,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     // (registers for one block, then LDS) and stores cumE, h and gamma a block after the chain wave produced them.
     // A block is B*cm contiguous doubles in HBM and B rows of SMM_MAX_STATES_DEV in LDS.
     constexpr int NE = (B * SMM_MAX_STATES_DEV + 63) / 64;   // elements per lane
+    double ninf = SMM_NEG_INF;                             // kept in a register pair (smm_ring_block)
+    asm volatile("" : "+v"(ninf));
     const int J = (T + B - 1) / B;                         // blocks; one barrier each, in every wave
     if (w == 0) {
         // ============================================================================ chain wave
@@ -633,7 +637,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     }
                 }
                 if constexpr (CP) {
-                    if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane);
+                    if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
                 }
                 SMM_BLOCK_BARRIER();                                       // end of block j
             }
@@ -760,13 +764,13 @@ smm_viterbi_kernel(SmmDpArgs a)
                 for (int js = 0; js < SPS; ++js) {
                     const int c = js * NP + rank;
                     if (c >= C) break;
-                    smm_ring_block<RS, B, D>(As[js], Ls[js], hds[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
+                    smm_ring_block<RS, B, D>(As[js], Ls[js], hds[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
 #pragma unroll
                 for (int js = 0; js < SPL; ++js) {
                     const int c = js * NP + rank;
                     if (c >= cl) break;
-                    smm_ring_block<R, B, D>(Al[js], Ll[js], hdl[js], &sh_h[(jj + 1) & 1][0][c], &sh_along[(jj + 1) & 1][0][c], j, jj, lane);
+                    smm_ring_block<R, B, D>(Al[js], Ll[js], hdl[js], &sh_h[(jj + 1) & 1][0][c], &sh_along[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
                 SMM_BLOCK_BARRIER();                             // end of block j
             }
@@ -872,7 +876,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 for (int js = 0; js < SPW; ++js) {
                     if (js >= nv) break;
                     const int c = js * NP + rank;
-                    smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane);
+                    smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
                 SMM_BLOCK_BARRIER();                             // end of block j
             }

@@ -29,7 +29,9 @@ typedef double smm_d4 __attribute__((ext_vector_type(4)));
 typedef float smm_f4 __attribute__((ext_vector_type(4)));
 
 #define SMM_EM_WAVES 8
-#define SMM_EM_TILES_PER_WAVE 8
+#ifndef SMM_EM_TILES_PER_WAVE
+#define SMM_EM_TILES_PER_WAVE 4   // same-box A/B on cfg3 (scripts/ab_prof.sh): 2: 0.611 ms, 3: 0.598, 4: 0.593, 8: 0.601, 16: 0.64
+#endif
 
 // largest i in [0, n) with cum[i] <= b   (cum[0] = 0, cum ascending, cum[n] = grid size)
 __device__ __forceinline__ int smm_em_find_video(const int32_t *__restrict__ cum, int n, int b)
@@ -455,7 +457,7 @@ __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
 
 int smm_emission_tiles_per_wave(int64_t total_frames, int b)
 {
-    // up to 8 tiles per wave (amortises the LDS fill of the weights), fewer when that would leave CUs without a
+    // up to SMM_EM_TILES_PER_WAVE tiles per wave (amortises the LDS fill of the weights), fewer when that would leave CUs without a
     // workgroup: aim at >= 2 workgroups on each of the 256 CUs
     int64_t tpw = (total_frames / 16 + b) / (512 * SMM_EM_WAVES);
     return (int)(tpw < 1 ? 1 : (tpw > SMM_EM_TILES_PER_WAVE ? SMM_EM_TILES_PER_WAVE : tpw));

@@ -198,7 +198,9 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     int forced = -1, forced3 = -1;
     if (const char *e = std::getenv("SMM_PAIRS")) forced = std::atoi(e);
     if (const char *e = std::getenv("SMM_TRIPLES")) forced3 = std::atoi(e);
-    if (kp_max <= 512 || c_need > 23 || std::getenv("SMM_NW")) return 0;   // gangs exist for 1024-slot rings, 8 waves
+    // gangs exist for 1024-slot rings, 8 waves; a leader's short rings hold 28 states (24..28: always a triple, whose two
+    // followers split the long rings)
+    if (kp_max <= 512 || c_need > 28 || std::getenv("SMM_NW")) return 0;
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
@@ -230,8 +232,10 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
         gangs.insert(gangs.end(), opt.begin(), opt.begin() + n);
         std::stable_sort(gangs.begin(), gangs.end(), [&](int32_t x, int32_t y) { return gang_ns(x, 1) > gang_ns(y, 1); });
         nf.assign(gangs.size(), 1);
+        for (size_t i = 0; i < gangs.size(); ++i)
+            if (states(gangs[i]) > 23) nf[i] = 2;                             // (one follower holds 16 long rings)
         for (size_t i = 0; i < gangs.size() && n3 > 0; ++i)
-            if (states(gangs[i]) > 16) { nf[i] = 2; --n3; }
+            if (states(gangs[i]) > 16 && nf[i] == 1) { nf[i] = 2; --n3; }
     };
     std::vector<double> cu(n_cu);
     auto simulate = [&](int n) {                                             // list schedule in grid order
@@ -266,7 +270,7 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     } else {
         double best_t = 1e300;
         // (host time is on the caller's critical path: a handful of candidates, ~b heap operations each)
-        static const int n3s[] = {0, 1, 2, 4, 8};
+        static const int n3s[] = {0, 1, 2, 4, 8, 16, 32, 64};
         for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
             for (int n3 : n3s) {
                 // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few

@@ -440,7 +440,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     const int C = a.n_states[g];
     if (recover) {
         constexpr int cap = (NW - 1) * SPW + CP;
-        const bool mine = (NW == 8) ? C <= cap : (C > 21 && C <= cap);
+        // (8 waves: <= 21 states; 12 waves: 22..23; 16 waves, spilling: 24..28, which only ever ran as triples)
+        const bool mine = (NW == 8) ? C <= cap : ((NW == 12) ? (C > 21 && C <= cap) : (C > 23 && C <= cap));
         if (NW == 8 && threadIdx.x == 0) atomicAdd(a.err + 1, 1);          // gangs that timed out
         if (!mine) return;
     }
@@ -1086,9 +1087,9 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
     if constexpr (R == 16) {
-        // 22..23 states, every such video paired by the host (a.flags bit 2): the 8-wave kernel, whose pair leaders hold
-        // 28 short-range states and whose single workgroups only ever see <= 21
-        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 23 && nw == 8)
+        // 22..28 states, every such video in a gang (a.flags bit 2; 24..28: a triple): the 8-wave kernel, whose gang leaders
+        // hold 28 short-range states and whose single workgroups only ever see <= 21
+        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 28 && nw == 8)
             return launch_if<16, 3, 8>(a, 3, 8, c_need, stream) ? SMM_OK : SMM_ERR_UNSUPPORTED;
     }
     if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
@@ -1138,6 +1139,8 @@ void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t st
     else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, SMM_B>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 16, 0, SMM_B>), grid, dim3(512), 0, stream, a);
     if (c_need > 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), grid, dim3(12 * 64), 0, stream, a);
+    if (c_need > 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
+    else if (c_need > 23) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 12, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
 }
 
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)

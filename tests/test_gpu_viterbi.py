@@ -524,8 +524,46 @@ def test_no_eos_needs_two_frames():
         ops.viterbi(ops.Batch([1, 5], [3], 4, t_max=5, total_frames=10, no_eos=True), z(10, 3), z(1, 3, 3), z(1, 3), z(1, 4, 3))
 
 
+@pytest.mark.parametrize('c', [24, 26, 28])
+def test_viterbi_24_to_28_states_ride_in_triples(c, monkeypatch):
+    """24..28 states at K > 512 used to fall to the spilling 16-wave configuration (about 8x slower): a gang leader's short
+    rings hold 28 states and two followers split the long rings, so such videos are always triples now.  Bit-exact
+    against the C twin, next to a 13-state task on single workgroups, and identical to the spilling path (gangs off)."""
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    k, cm = 1024, c
+    cs = [c, 13]
+    group = np.array([0, 1, 0, 1], dtype=np.int32)
+    lengths = np.array([1400, 1500, 1100, 600], dtype=np.int64)
+    tmax, b = int(lengths.max()), len(lengths)
+    probs = [make_problem(300 + i, 1, tmax, cs[g], k, c_max=cm, ends=(i % 2 == 0)) for i, g in enumerate(group)]
+    tabs = [make_problem(400 + g, 1, 8, cc, k, c_max=cm) for g, cc in enumerate(cs)]
+    elp = np.stack([p['elp'][0] for p in probs])
+    endpen = np.stack([p['endpen'][0] if p['endpen'] is not None else np.zeros(cm) for p in probs])
+    for i, g in enumerate(group):
+        endpen[i, cs[g]:] = -1e9
+    batch = ops.Batch(lengths, cs, k, c_max=cm, t_max=tmax, total_frames=b * tmax, group=group)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    args = (t(elp.reshape(b * tmax, cm)), t(np.stack([x['trans'] for x in tabs])), t(np.stack([x['init'] for x in tabs])),
+            t(np.stack([x['lens'] for x in tabs])), t(endpen))
+    out = ops.viterbi(batch, *args)
+    torch.cuda.synchronize()
+    ops.check_decoded(batch, out)
+    got = {kk: v.cpu().numpy() for kk, v in out.items() if kk in ('best', 'spans', 'labels', 'n_segs')}
+    for i, g in enumerate(group):
+        cc = cs[g]
+        spans, v = F.viterbi(elp[i:i + 1, :, :cc], lengths[i:i + 1], tabs[g]['trans'][:cc, :cc], tabs[g]['init'][:cc],
+                             tabs[g]['lens'][:, :cc], endpen[i:i + 1, :cc])
+        assert got['best'][i] == v[0]
+    monkeypatch.setenv('SMM_PAIRS', '0')                            # gangs off: the spilling configuration
+    slow = ops.viterbi(batch, *args)
+    torch.cuda.synchronize()
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(got[key], slow[key].cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------------- gang recovery
-@pytest.mark.parametrize('c', [13, 23])
+@pytest.mark.parametrize('c', [13, 23, 26])
 def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):
     """A gang whose follower workgroups never become resident (test hook: SmmDpArgs::flags bit 5 -- gang 0's followers
     return at once and the leader's waits are short) gives up, flags itself, and the recovery launch behind the main

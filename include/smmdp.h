@@ -49,7 +49,7 @@ extern "C" {
 typedef enum smm_status {
     SMM_OK = 0,
     SMM_ERR_ARG = -1,          /* null pointer / non-positive size / inconsistent metadata */
-    SMM_ERR_UNSUPPORTED = -2,  /* shape outside the compiled kernels (c_max > 32, k_rows > 1024; logz: k_rows > 512 with > 14 states) */
+    SMM_ERR_UNSUPPORTED = -2,  /* shape outside the compiled kernels (c_max > 32, k_rows > 1024) */
     SMM_ERR_WORKSPACE = -3,    /* workspace too small */
     SMM_ERR_HIP = -4,          /* a HIP runtime call failed (smm_last_hip_error() has the code) */
     SMM_ERR_NO_DEVICE = -5     /* no gfx950 device visible */

@@ -198,9 +198,9 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     int forced = -1, forced3 = -1;
     if (const char *e = std::getenv("SMM_PAIRS")) forced = std::atoi(e);
     if (const char *e = std::getenv("SMM_TRIPLES")) forced3 = std::atoi(e);
-    // gangs exist for 1024-slot rings, 8 waves; a leader's short rings hold 28 states (24..28: always a triple, whose two
-    // followers split the long rings)
-    if (kp_max <= 512 || c_need > 28 || std::getenv("SMM_NW")) return 0;
+    // gangs exist for 1024-slot rings, 8 waves; a leader's short rings hold every state (24..32: always a triple, whose
+    // two followers split the long rings, 16 each at most)
+    if (kp_max <= 512 || c_need > 32 || std::getenv("SMM_NW")) return 0;
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;

@@ -440,8 +440,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     const int C = a.n_states[g];
     if (recover) {
         constexpr int cap = (NW - 1) * SPW + CP;
-        // (8 waves: <= 21 states; 12 waves: 22..23; 16 waves, spilling: 24..28, which only ever ran as triples)
-        const bool mine = (NW == 8) ? C <= cap : ((NW == 12) ? (C > 21 && C <= cap) : (C > 23 && C <= cap));
+        // (8 waves: <= 21 states; 12 waves: 22..23; 16 waves, spilling: 24..30 with 2 states per wave, 31..32 with 3 --
+        // those only ever ran as triples)
+        const bool mine = (NW == 8) ? C <= cap : ((NW == 12) ? (C > 21 && C <= cap) : ((SPW == 2) ? (C > 23 && C <= cap) : C > 30));
         if (NW == 8 && threadIdx.x == 0) atomicAdd(a.err + 1, 1);          // gangs that timed out
         if (!mine) return;
     }
@@ -646,10 +647,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         SMM_PROF_OUT();
     } else if (PAIR && lead) {
         // ============================================================================ pusher waves of a pair's leader
-        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21 and long range
+        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21, rank+28 and long range
         // (128 <= k <= kp-1, 1024-slot rings) of states rank, rank+7 below cl.  The follower's long-range A' rows come
         // back through HBM; four pusher waves move the HBM traffic (below).
-        constexpr int SPS = 4, SPL = 2, RS = 2;
+        constexpr int SPS = 5, SPL = 2, RS = 2;               // (5 x 7 short rings: up to 32 states; 2 long rings per pusher)
         const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
         const int kshort = (kp - 1 < SMM_KS) ? kp - 1 : SMM_KS;
         double As[SPS][RS], Ls[SPS][RS], hds[SPS];
@@ -1087,9 +1088,9 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
     if constexpr (R == 16) {
-        // 22..28 states, every such video in a gang (a.flags bit 2; 24..28: a triple): the 8-wave kernel, whose gang leaders
-        // hold 28 short-range states and whose single workgroups only ever see <= 21
-        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 28 && nw == 8)
+        // 22..32 states, every such video in a gang (a.flags bit 2; 24..32: a triple): the 8-wave kernel, whose gang leaders
+        // hold 35 short-range states and whose single workgroups only ever see <= 21
+        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 32 && nw == 8)
             return launch_if<16, 3, 8>(a, 3, 8, c_need, stream) ? SMM_OK : SMM_ERR_UNSUPPORTED;
     }
     if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
@@ -1139,6 +1140,7 @@ void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t st
     else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, SMM_B>), grid, dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 16, 0, SMM_B>), grid, dim3(512), 0, stream, a);
     if (c_need > 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), grid, dim3(12 * 64), 0, stream, a);
+    if (c_need > 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
     if (c_need > 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
     else if (c_need > 23) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 12, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
 }

@@ -7,7 +7,7 @@ from action_segmentation_amd import ops
 import test_gpu_viterbi as TV
 dev = torch.device('cuda:0')
 t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
-for c in (24, 26, 28, 23):
+for c in (24, 28, 30, 32, 23):
     b, T = 32, 4096
     p = TV.make_problem(7, b, T, c, 1024)
     p['lengths'][:] = T

@@ -524,10 +524,10 @@ def test_no_eos_needs_two_frames():
         ops.viterbi(ops.Batch([1, 5], [3], 4, t_max=5, total_frames=10, no_eos=True), z(10, 3), z(1, 3, 3), z(1, 3), z(1, 4, 3))
 
 
-@pytest.mark.parametrize('c', [24, 26, 28])
-def test_viterbi_24_to_28_states_ride_in_triples(c, monkeypatch):
-    """24..28 states at K > 512 used to fall to the spilling 16-wave configuration (about 8x slower): a gang leader's short
-    rings hold 28 states and two followers split the long rings, so such videos are always triples now.  Bit-exact
+@pytest.mark.parametrize('c', [24, 26, 28, 29, 31, 32])
+def test_viterbi_24_to_32_states_ride_in_triples(c, monkeypatch):
+    """24..32 states at K > 512 used to fall to the spilling 16-wave configuration (12-16x slower): a gang leader's short
+    rings hold every state and two followers split the long rings, so such videos are always triples now.  Bit-exact
     against the C twin, next to a 13-state task on single workgroups, and identical to the spilling path (gangs off)."""
     ops = _ops()
     dev = torch.device('cuda:0')
@@ -563,7 +563,7 @@ def test_viterbi_24_to_28_states_ride_in_triples(c, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------- gang recovery
-@pytest.mark.parametrize('c', [13, 23, 26])
+@pytest.mark.parametrize('c', [13, 23, 26, 31])
 def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):
     """A gang whose follower workgroups never become resident (test hook: SmmDpArgs::flags bit 5 -- gang 0's followers
     return at once and the leader's waits are short) gives up, flags itself, and the recovery launch behind the main

@@ -471,5 +471,5 @@ def fit_stats(x, labels, lengths, frame_offset, n_classes, max_k):
         _dev(out['span_transition_counts'], torch.int64, 'span_transition_counts'),
         ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     off = lib.smm_fit_error_word_offset(b)
-    out['_err'] = ws[off:off + 4].view(torch.int32)
-    return out
+    out['_err'] = ws[off:off + 4].view(torch.int32).clone()     # (a copy, stream-ordered behind the kernels: the shared
+    return out                                                   #  workspace may be reused by the next call)

@@ -1,0 +1,195 @@
+/*
+ * oracle/prune_probe.c -- EXPERIMENT (test infrastructure, never shipped): how much of the long segment-length range
+ * of the factored Viterbi DP can be skipped EXACTLY with a bound test?
+ *
+ * The DP (oracle/smm_oracle.c) needs  A[n][c] = max_{k=1..kmax} ( h[n-k][c] + len[k][c] ).  A candidate block
+ * (targets n0 .. n0+TB-1) x (lengths kb .. kb+KB-1) of one state cannot change any A[n][c] of the block when
+ *     max_{sources s of the block} h[s][c]  +  max_{k in the block} len[k][c]   <=   min_{targets n} acc[n]
+ * where acc[n] is the running maximum over the candidates already evaluated for target n (a lower bound of A[n][c]).
+ * max is exact, so skipping such a block changes no bit of the result; the back-trace re-evaluates the candidates of
+ * the optimal path only.  Lengths are walked in ascending order (the most recent sources first: h[s][c] = beta - cumE
+ * grows while c is not the best explanation of the frames).
+ *
+ * This file measures the surviving fraction of blocks on real lattices (scripts/probe_prune.py feeds it the cfg3
+ * corpus).  Source maxima are taken over 64-ALIGNED source blocks (what a kernel would keep), not over the exact span.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+
+/*
+ * elp t x c, trans c x c [to][from], init c, len kp x c.  Long range: k in [kl, kp-1], target blocks of tb positions,
+ * length blocks of kb lengths.  out[0] = blocks in all (state x target block x length block with at least one valid
+ * candidate), out[1] = blocks evaluated, out[2] = lattice cells in all (long range), out[3] = cells evaluated,
+ * out[4] = cells of the whole lattice (all k), out[5] = blocks evaluated if only the FIRST block's minimum is used as
+ * the bound (no update of the bound after later blocks).
+ * Returns 0 / -1 (allocation).
+ */
+int smm_prune_probe(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                    int kl, int tb, int kb, double *out)
+{
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    const int nsb = t / 64 + 2;
+    double *hmax = (double *)malloc(sizeof(double) * (size_t)nsb * c);      /* max of h over aligned 64-source blocks */
+    const int nkb = (kp + kb - 1) / kb + 1;
+    double *lmax = (double *)malloc(sizeof(double) * (size_t)nkb * c);      /* max of len over the length blocks */
+    double *acc = (double *)malloc(sizeof(double) * tb);
+    if (!cum || !h || !gam || !hmax || !lmax || !acc) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        out[4] += (double)kmax * c;
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    for (int sb = 0; sb < nsb; ++sb)
+        for (int j = 0; j < c; ++j) {
+            double m = -INFINITY;
+            for (int s = sb * 64; s < sb * 64 + 64 && s < t; ++s) m = dmax(m, h[(size_t)s * c + j]);
+            hmax[(size_t)sb * c + j] = m;
+        }
+    for (int q = 0; q < nkb; ++q)
+        for (int j = 0; j < c; ++j) {
+            double m = -INFINITY;
+            for (int k = kl + q * kb; k < kl + (q + 1) * kb && k <= kp - 1; ++k) m = dmax(m, len[(size_t)k * c + j]);
+            lmax[(size_t)q * c + j] = m;
+        }
+    for (int j = 0; j < c; ++j) {
+        for (int n0 = 1; n0 <= t; n0 += tb) {
+            const int n1 = (n0 + tb - 1 < t) ? n0 + tb - 1 : t;            /* targets n0 .. n1 */
+            for (int i = 0; i < tb; ++i) acc[i] = -INFINITY;
+            double bound_first = INFINITY;
+            int first_done = 0;
+            for (int q = 0; kl + q * kb <= kp - 1; ++q) {
+                const int k0 = kl + q * kb, k1 = (k0 + kb - 1 < kp - 1) ? k0 + kb - 1 : kp - 1;
+                /* sources n - k, n0 <= n <= n1, k0 <= k <= k1, >= 0 */
+                const int s_hi = n1 - k0, s_lo = (n0 - k1 > 0) ? n0 - k1 : 0;
+                if (s_hi < 0) break;                                          /* no candidate here or in any later block */
+                double cells = 0.0;
+                for (int n = n0; n <= n1; ++n) {
+                    const int ka = k0, kz = (k1 < n) ? k1 : n;
+                    if (kz >= ka) cells += kz - ka + 1;
+                }
+                out[0] += 1.0;
+                out[2] += cells;
+                double hm = -INFINITY;
+                for (int sb = s_lo / 64; sb <= s_hi / 64; ++sb) hm = dmax(hm, hmax[(size_t)sb * c + j]);
+                const double ub = hm + lmax[(size_t)q * c + j];
+                /* lower bound: min over the targets that have a long-range candidate at all (n >= kl) */
+                double lb = INFINITY;
+                for (int n = (n0 > kl ? n0 : kl); n <= n1; ++n) lb = dmin(lb, acc[n - n0]);
+                if (first_done && ub <= bound_first) { /* skipped by the static bound */ } else out[5] += 1.0;
+                if (ub <= lb) continue;                                       /* skipped: cannot change any acc */
+                out[1] += 1.0;
+                out[3] += cells;
+                for (int n = n0; n <= n1; ++n) {
+                    const int kz = (k1 < n) ? k1 : n;
+                    for (int k = k0; k <= kz; ++k)
+                        acc[n - n0] = dmax(acc[n - n0], h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+                }
+                if (!first_done) {
+                    first_done = 1;
+                    bound_first = INFINITY;
+                    for (int n = (n0 > kl ? n0 : kl); n <= n1; ++n) bound_first = dmin(bound_first, acc[n - n0]);
+                }
+            }
+        }
+    }
+    free(cum); free(h); free(gam); free(hmax); free(lmax); free(acc);
+    return 0;
+}
+
+/*
+ * Second design: BANDED PUSH.  The lengths are cut into bands of `bw` (band m = lengths m*bw .. m*bw+bw-1); band m
+ * pushes source s - m*bw when the chain is at s, into the one ring of bw upcoming targets all bands share.  Per state,
+ * per group of 64 sources and band m >= 1 the whole group is skipped when
+ *     max_{s in group} h[s][c] + max_{k in band m} len[k][c]  <=  max_{s in the newest complete group} h[s][c] + min_{1<=k<=gap} len[k][c]
+ * (right side: a real candidate of every target the group can reach, so a lower bound of their A[n][c]; gap = 64 + 63
+ * + bw - 1).  Band 0 is always evaluated.  out[0] = (state, group, band) triples with sources, out[1] = evaluated,
+ * out[2] = band-0 triples (always evaluated), out[3] = cells of the whole lattice, out[4] = cells evaluated.
+ */
+int smm_band_probe(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                   int bw, double *out)
+{
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    const int ng = t / 64 + 2, nb = (kp + bw - 1) / bw;
+    double *hmax = (double *)malloc(sizeof(double) * (size_t)ng * c);
+    double *lmax = (double *)malloc(sizeof(double) * (size_t)(nb + 1) * c);
+    if (!cum || !h || !gam || !hmax || !lmax) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        out[3] += (double)kmax * c;
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    for (int g = 0; g < ng; ++g)
+        for (int j = 0; j < c; ++j) {
+            double m = -INFINITY;
+            for (int s = g * 64; s < g * 64 + 64 && s < t; ++s) m = dmax(m, h[(size_t)s * c + j]);
+            hmax[(size_t)g * c + j] = m;
+        }
+    const int gap = 64 + 63 + bw - 1;
+    for (int j = 0; j < c; ++j) {
+        double lmin = INFINITY;
+        for (int k = 1; k <= gap && k <= kp - 1; ++k) lmin = dmin(lmin, len[(size_t)k * c + j]);
+        if (gap > kp - 1) lmin = -INFINITY;
+        for (int m = 0; m < nb; ++m) {
+            double mm = -INFINITY;
+            for (int k = m * bw; k < (m + 1) * bw && k <= kp - 1; ++k)
+                if (k >= 1) mm = dmax(mm, len[(size_t)k * c + j]);
+            lmax[(size_t)m * c + j] = mm;
+        }
+        for (int g = 0; g * 64 < t; ++g) {
+            const double lb = (g >= 1) ? hmax[(size_t)(g - 1) * c + j] + lmin : -INFINITY;
+            for (int m = 0; m < nb; ++m) {
+                const int gs = g - m * bw / 64;                 /* the source group of band m */
+                if (gs < 0) break;
+                /* cells: sources s in the group, lengths k in the band, target s + k <= t */
+                double cells = 0.0;
+                for (int s = gs * 64; s < gs * 64 + 64 && s < t; ++s) {
+                    int k0 = m * bw < 1 ? 1 : m * bw, k1 = (m + 1) * bw - 1;
+                    if (k1 > kp - 1) k1 = kp - 1;
+                    if (k1 > t - s) k1 = t - s;
+                    if (k1 >= k0) cells += k1 - k0 + 1;
+                }
+                out[0] += 1.0;
+                if (m == 0) out[2] += 1.0;
+                const double ub = hmax[(size_t)gs * c + j] + lmax[(size_t)m * c + j];
+                if (m > 0 && ub <= lb) continue;
+                out[1] += 1.0;
+                out[4] += cells;
+            }
+        }
+    }
+    free(cum); free(h); free(gam); free(hmax); free(lmax);
+    return 0;
+}

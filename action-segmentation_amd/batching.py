@@ -183,6 +183,10 @@ def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn
             pc.batch_index.append(bi)
             off += int(t)
     pc.k_rows = k_rows
+    if not feats:                       # an empty shard (more ranks than single-task batches): a corpus without videos
+        pc.x = torch.zeros((0, 1), dtype=torch.float32, device=device)
+        pc.cons_list = None
+        return pc
     pc.x = torch.cat([f.to(device=device, dtype=torch.float32) for f in feats], dim=0).contiguous()
     if any_cons:
         pc.cons_list = cons_l

@@ -20,8 +20,19 @@ def init(backend=None, timeout_s=180):
     died cannot hang the others forever."""
     import datetime
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world <= 1 or dist.is_initialized():
+    if (world <= 1 and not _single_rank_group()) or dist.is_initialized():
         return int(os.environ.get('RANK', 0)), world
+    if world <= 1:
+        # SMM_DIST_SINGLE_RANK=1 (tests): a ONE-rank group, so that the collectives of the N-rank path -- counters,
+        # parameter broadcast, gradient all-reduce -- run through RCCL on a box with one GPU (tests/test_gpu_rccl.py)
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('LOCAL_RANK', '0')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s.getsockname()[1])
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -35,8 +46,14 @@ def init(backend=None, timeout_s=180):
     return dist.get_rank(), dist.get_world_size()
 
 
+def _single_rank_group():
+    return os.environ.get('SMM_DIST_SINGLE_RANK') == '1'
+
+
 def active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group is up and there is something to reduce over: more than one rank -- or one rank under the explicit
+    test flag SMM_DIST_SINGLE_RANK=1, which sends every collective through the backend anyway."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_group())
 
 
 def reduce_device():
@@ -59,6 +76,19 @@ def all_reduce_tensor(t, op=None):
         return t
     buf = t.to(rd)
     dist.all_reduce(buf, op=op)
+    return buf.to(t.device)
+
+
+def broadcast_tensor(t, src=0):
+    """Rank ``src``'s tensor on every rank (returned on the tensor's own device).  No-op for a single process."""
+    if not active():
+        return t
+    rd = reduce_device()
+    if t.device == rd:
+        dist.broadcast(t, src)
+        return t
+    buf = t.to(rd)
+    dist.broadcast(buf, src)
     return buf.to(t.device)
 
 

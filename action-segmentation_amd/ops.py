@@ -240,7 +240,7 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
         _dev(len_scores, dt, 'len_scores'), _dev(endpen, dt, 'endpen'), _dev(class_map, torch.int64, 'class_map'),
         _dev(spans, torch.int64, 'spans'), _dev(labels, torch.int64, 'labels'), _dev(best, torch.float64, 'best'),
         _dev(n_segs, torch.int32, 'n_segs'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
-    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, _err=_err_view(batch, ws))
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, _err=_err_copy(batch, ws))
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
@@ -262,7 +262,7 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(class_map, torch.int64, 'class_map'), _dev(spans, torch.int64, 'spans'),
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
-    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=_err_view(batch, ws))
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=_err_copy(batch, ws))
 
 
 def _shape_with(batch, extra_flags):
@@ -338,6 +338,14 @@ def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
     return ws[off:off + 12].view(torch.int32)      # [error, gangs timed out, gangs repaired]
+
+
+def _err_copy(batch, ws):
+    """The launch's error words COPIED out of the workspace (12 bytes, stream-ordered behind the kernels, graph-capturable):
+    the per-stream workspace is shared, and the next launch on the stream re-stages it and zeroes these words."""
+    # (an elementwise kernel, not clone(): torch copies device -> device with hipMemcpyAsync, and memset / memcpy nodes are
+    # what replayed wrongly from a captured hipGraph on ROCm 7.2 -- tests/test_gpu_graph.py; kernel nodes replay correctly)
+    return torch.add(_err_view(batch, ws), 0)
 
 
 def error_flag(batch, out=None, ws=None):

@@ -131,7 +131,7 @@ class SemiMarkovModel(object):
             train_nll = num_frames = num_videos = 0
 
             def step(batch_ix):
-                if args.print_every and batch_ix % args.print_every == 0:
+                if args.print_every and batch_ix % args.print_every == 0 and (not dp or rank == 0):
                     print('Epoch: %02d, Batch: %03d/%03d, loss: %.4f, recon: %.4f, Throughput: %.2f vid / sec' % (
                         epoch, batch_ix, len(loader), train_nll / num_videos, train_nll / num_frames,
                         num_videos / (time.time() - start_time)))
@@ -142,6 +142,27 @@ class SemiMarkovModel(object):
                 optimizer.step()
                 self.model.zero_grad()
 
+            def packed_group(group, batch_ix, backprop):
+                """The batches of one optimiser step through ONE launch of each kernel.  ``backprop`` False: the
+                leftover batches of an epoch (fewer than --batch_accumulation): their losses count, no step is taken
+                (reference :273-310 appends every batch's loss and steps only on full groups)."""
+                mine = list(range(rank, len(group), world)) if dp else list(range(len(group)))
+                vals_t = torch.zeros(len(group), dtype=torch.float64, device=self.device)
+                if mine:
+                    pc = pack_batches([group[i] for i in mine], self.device, self.model.max_k, constraints_fn=train_cons,
+                                      additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
+                    with torch.set_grad_enabled(backprop):
+                        loss_b = -self.model.log_likelihood_packed(pc)     # [this rank's batches]
+                    if backprop:
+                        (loss_b.sum() / len(group)).backward()             # == mean over the step's batches once summed over ranks
+                    vals_t[torch.as_tensor(mine, device=self.device)] = loss_b.detach()
+                if dp:
+                    vals_t = distributed.all_reduce_tensor(vals_t)
+                vals = vals_t.cpu().tolist()
+                self._check_finite(vals, batch_ix)
+                return vals, sum(v * len(b['lengths']) for v, b in zip(vals, group))
+
+            batch_ix = -1
             for batch_ix, batch in enumerate(loader):
                 if args.train_limit and batch_ix >= args.train_limit:
                     break
@@ -151,21 +172,9 @@ class SemiMarkovModel(object):
                 if packed:
                     pending.append(batch)
                     if len(pending) >= args.batch_accumulation:
-                        mine = list(range(rank, len(pending), world)) if dp else list(range(len(pending)))
-                        vals_t = torch.zeros(len(pending), dtype=torch.float64, device=self.device)
-                        if mine:
-                            pc = pack_batches([pending[i] for i in mine], self.device, self.model.max_k, constraints_fn=train_cons,
-                                              additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
-                            ll = self.model.log_likelihood_packed(pc)          # [this rank's batches]
-                            loss_b = -ll
-                            (loss_b.sum() / len(pending)).backward()           # == mean over the step's batches once summed over ranks
-                            vals_t[torch.as_tensor(mine, device=self.device)] = loss_b.detach()
-                        if dp:
-                            vals_t = distributed.all_reduce_tensor(vals_t)
-                        vals = vals_t.cpu().tolist()
-                        self._check_finite(vals, batch_ix)
+                        vals, nll = packed_group(pending, batch_ix, True)
                         losses += vals
-                        train_nll += sum(v * len(b['lengths']) for v, b in zip(vals, pending))
+                        train_nll += nll
                         pending = []
                         step(batch_ix)
                     continue
@@ -178,13 +187,24 @@ class SemiMarkovModel(object):
                                                         additional_allowed_ends_per_instance=addl, constraints=cons)
                 loss = -ll - log_det
                 pending.append(loss)
-                losses.append(loss.item())
+                # data parallel without a packed step: every rank runs the batch; the scalars that steer the run (finiteness
+                # check, scheduler, snapshot selection) are rank 0's, so the ranks cannot drift apart on a last-bit difference
+                lv = torch.stack([loss.detach().double(), (-ll).detach().double()])
+                if dp:
+                    lv = distributed.broadcast_tensor(lv, src=0)
+                lv = lv.tolist()
+                losses.append(lv[0])
                 self._check_finite(losses[-1:], batch_ix)
-                train_nll += -ll.item() * len(lengths)
+                train_nll += lv[1] * len(lengths)
                 if len(pending) >= args.batch_accumulation:
                     (sum(pending) / len(pending)).backward()
                     pending = []
                     step(batch_ix)
+            if packed and pending:
+                vals, nll = packed_group(pending, batch_ix, False)
+                losses += vals
+                train_nll += nll
+                pending = []
             train_loss = float(np.mean(losses))
             if scheduler is not None:
                 scheduler.step(train_loss)
@@ -253,7 +273,13 @@ class SemiMarkovModel(object):
         """Everything that happens before the timed decode: collate the reference's batches, move them to the
         device once, stack the per-task factor tables.  ``shard=(rank, world)``: this rank's share of the batches
         (multi-GPU decode: videos are independent, every rank decodes its own; batching.make_data_loader)."""
+        # everything baked into the cached PackedCorpus (constraints scaled by the narration weight, K clipped per batch,
+        # end penalties from the allowed-ends tables) is part of the key
+        order = self.ordered_indices_by_task
         key = (id(test_data), len(test_data), shard, tuple(self.args.sm_constrain_with_narration),
+               float(getattr(self.args, 'sm_constrain_narration_weight', 0.0)), self.model.max_k,
+               None if self.model.allowed_ends is None else tuple(sorted(self.model.allowed_ends)),
+               None if order is None else tuple((t, tuple(v)) for t, v in sorted(order.items())),
                self.args.batch_size, str(self.device))
         cache = self.__dict__.setdefault('_prepared', {})
         hit = cache.get(key)
@@ -263,10 +289,11 @@ class SemiMarkovModel(object):
                                   shard=shard)
         pc = pack_batches(loader, self.device, self.model.max_k, constraints_fn=self._test_constraints(test_data),
                           additional_ends_fn=lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths']))
-        nbytes = pc.x.numel() * 4
+        resident = lambda q: q.x.numel() * 4 + sum(c.numel() * 4 for c in (getattr(q, 'cons_list', None) or []) if c is not None)
+        nbytes = resident(pc)
         if nbytes <= self.cache_prepared_bytes:
             import weakref
-            held = sum(v[1].x.numel() * 4 for v in cache.values())
+            held = sum(resident(v[1]) for v in cache.values())
             if held + nbytes > self.cache_prepared_bytes:
                 cache.clear()
             try:
@@ -274,6 +301,10 @@ class SemiMarkovModel(object):
             except TypeError:                               # (a datasplit type that cannot be weakly referenced)
                 pass
         return self.model.prepare_packed(pc)
+
+    def clear_prepared(self):
+        """Drop every datasplit kept resident by ``prepare`` (frees the HBM they hold)."""
+        self.__dict__.pop('_prepared', None)
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -283,6 +314,8 @@ class SemiMarkovModel(object):
     def predict_packed(self, pc):
         import torch
         from . import ops
+        if pc.n_videos == 0:
+            return {}                                       # this rank's shard is empty
         # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here
         out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
         torch.cuda.current_stream().synchronize()

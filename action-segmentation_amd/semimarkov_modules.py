@@ -634,6 +634,9 @@ class SemiMarkovModule(nn.Module):
         build the per-video end penalties / constraint block / launch metadata."""
         dev = pc.x.device
         d = pc.x.size(1)
+        if pc.n_videos == 0:                # an empty shard: nothing to launch (predict_packed returns {})
+            pc.tables, pc.batch, pc.cons, pc.endpen = {}, None, None, None
+            return pc
         st, n_states, cm, k_rows = self.stacked_tables(pc, differentiable)
         pc.tables, pc.n_states, pc.c_max, pc.k_rows = st, n_states, cm, k_rows
         if getattr(pc, '_static', None) == (cm, k_rows, id(self)):

@@ -55,8 +55,9 @@ def parse(argv=None):
     p.add_argument('--fit-videos', type=int, default=6, help='videos per task the closed-form fit sees (untimed)')
     p.add_argument('--labels-via-copy', action='store_true',
                    help='labels to a device tensor + D->H copy through a pinned buffer instead of kernel stores to pinned host memory')
-    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                   help='which leg is the headline value when N > 1 (the other one is reported beside it)')
+    p.add_argument('--scaling', default=None, choices=['weak', 'strong'],
+                   help='which leg is the headline value when N > 1 (the other one is reported beside it).  Default: strong '
+                        '(BASELINE config 5: ONE corpus sharded by video over the ranks) for N > 1, weak for N = 1')
     p.add_argument('--strong-workload', default='cfg5', choices=['cfg3', 'cfg5', 'cfg4', 'tiny'],
                    help='corpus of the strong-scaling leg (one corpus, seed --seed, sharded by video over the ranks)')
     p.add_argument('--strong-leg', action='store_true', help='run the strong-scaling leg with one rank too')
@@ -79,6 +80,8 @@ def parse(argv=None):
         p.error('--share-gpus needs --backend gloo (RCCL refuses two ranks on one GPU)')
     if a.gpus < 1:
         p.error('--gpus must be >= 1')
+    if a.scaling is None:
+        a.scaling = 'strong' if a.gpus > 1 else 'weak'
     return a
 
 
@@ -92,13 +95,8 @@ def free_port():
 
 def spawn_ranks(a, argv):
     """``python bench.py --gpus N`` without torchrun: start the N ranks as fresh child processes (this parent never
-    initialises the GPU: ``torch.cuda.device_count()`` does not, on this image), wait for them, exit with their status.
-    Rank 0's stdout is the parent's, so its JSON line is the job's line."""
-    if not a.dry_run and not a.share_gpus:
-        n_dev = torch.cuda.device_count()
-        if n_dev < a.gpus:
-            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (a.gpus, n_dev))
-            return 2
+    touches the GPU runtime at all -- a rank without a GPU of its own fails in dist_setup), wait for them, exit with
+    their status.  Rank 0's stdout is the parent's, so its JSON line is the job's line."""
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY='0', LOCAL_WORLD_SIZE=str(a.gpus))
@@ -144,8 +142,10 @@ def dist_setup(a):
         if local >= n_dev:
             raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own (%d visible)" % (rank, local, n_dev))
         torch.cuda.set_device(local)
-    if world == 1:
+    if world == 1 and os.environ.get('SMM_DIST_SINGLE_RANK') != '1':
         return rank, world, local, None
+    # (SMM_DIST_SINGLE_RANK=1: a one-rank group, so that every collective of the N-rank path runs through RCCL on the
+    # one GPU of a test box -- tests/test_gpu_rccl.py)
     D.init(a.backend)
     probe = torch.ones(1, device=D.reduce_device())
     dist.all_reduce(probe)
@@ -204,11 +204,21 @@ def cpu_baseline(data, model, pc):
                       % (t, n_done, c, m.max_k, feats_all.shape[-1], dt)}
 
 
-def cpu_factored(pc, model, budget_s=12.0):
+def spans_to_frame_labels(row, t):
+    """span encoding (label at every span start, -1 = continuation) -> one label per frame (forward fill)."""
+    row = np.asarray(row[:t])
+    idx = np.maximum.accumulate(np.where(row != -1, np.arange(t), 0))
+    return row[idx]
+
+
+def cpu_factored(pc, model, gpu_labels=None, budget_s=12.0):
     """The plain-C factored oracle, OpenMP over the videos of one task at a time (the 'fair' CPU
-    number): emission + Viterbi for whole tasks until ~budget_s of wall time are spent."""
+    number): emission + Viterbi for whole tasks until ~budget_s of wall time are spent.  ``gpu_labels`` (host int64
+    [total_frames], the labels the TIMED decode produced): the twin's spans are turned into frame labels and compared
+    with them for every video the twin covered -- the checker's answer was computed anyway (second return value)."""
     from oracle import factored as F
     t = pc.tables
+    checked = mismatches = vids_checked = 0
     cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     frames, dt, n_vid, n_task = 0, 0.0, 0, 0
     by_group = {}
@@ -227,17 +237,32 @@ def cpu_factored(pc, model, budget_s=12.0):
         for j, x in enumerate(xs):                           # (the emission GEMM runs on numpy's BLAS threads)
             xd = x.astype(np.float64)
             elp[j, :x.shape[0]] = cst + xd @ w - 0.5 * (xd * xd) @ inv_var[:, None]
-        F.viterbi(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
-                  t['len'][g, :kp, :c].cpu().numpy())
+        ep = None if pc.endpen is None else pc.endpen[vids][:, :c].cpu().numpy()
+        if pc.cons is not None:
+            for j, i in enumerate(vids):
+                elp[j, :pc.lengths[i]] += pc.cons[pc.frame_offset[i]:pc.frame_offset[i] + pc.lengths[i], :c].cpu().numpy()
+        spans, _ = F.viterbi(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(),
+                             t['init'][g, :c].cpu().numpy(), t['len'][g, :kp, :c].cpu().numpy(), ep)
         dt += time.perf_counter() - t0
+        if gpu_labels is not None:                               # (outside the CPU timing)
+            cmap = t['class_map'][g].cpu().numpy()
+            for j, i in enumerate(vids):
+                n, o = pc.lengths[i], pc.frame_offset[i]
+                ref = cmap[spans_to_frame_labels(spans[j], n)]
+                mismatches += int((ref != gpu_labels[o:o + n]).sum())
+                checked += n
+                vids_checked += 1
         frames += sum(pc.lengths[i] for i in vids)
         n_vid += len(vids)
         n_task += 1
         if dt > budget_s:
             break
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d videos of %d task(s), oracle/smm_oracle.c factored fp64 DP, OpenMP over the videos of a task "
-                      "(%d host threads), %.1f s" % (n_vid, n_task, cores, dt)}
+    res = {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d videos of %d task(s), oracle/smm_oracle.c factored fp64 DP, OpenMP over the videos of a task "
+                     "(%d host threads), %.1f s" % (n_vid, n_task, cores, dt)}
+    par = None if gpu_labels is None else {"frames_checked": checked, "videos_checked": vids_checked,
+                                            "label_mismatches": mismatches}
+    return res, par
 
 
 # ------------------------------------------------------------------------------------------------ legs
@@ -262,9 +287,9 @@ def timed_decode(a, pc, world, want_events=True):
     """W warm-up + exactly K timed decode steps of this rank's packed corpus, bracketed by barrier + synchronize.
     Returns (wall seconds of the K steps, mean DP kernel ms, last labels (pinned host int64))."""
     from action_segmentation_amd import ops
-    t = pc.tables
-    stream = torch.cuda.current_stream()
     empty = pc is None or pc.n_videos == 0
+    t = None if empty else pc.tables
+    stream = torch.cuda.current_stream()
 
     def step(events=None):
         """emission -> DP -> labels on the host.  (Same two launches as smm_decode_f32; split only so that HIP
@@ -286,7 +311,7 @@ def timed_decode(a, pc, world, want_events=True):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
 
     labels = None
@@ -358,12 +383,20 @@ def strong_leg(a, rank, world, dev, D):
     tmax = D.all_reduce_tensor(torch.tensor([dt, float(pc.n_frames), dp_ms or 0.0], dtype=torch.float64, device=rd),
                                op=torch.distributed.ReduceOp.MAX)
     dt_all = float(tmax[0])
-    return {"scaling": "strong", "workload": "%s seed %d: %d videos, %d frames, sharded by video (whole single-task "
+    roof = None
+    if pc.n_videos and dp_ms:
+        dp_bytes = sum(ln * (32 * pc.n_states[g] + 8) for ln, g in zip(pc.lengths, pc.group))
+        roof = {"bound": "hbm", "achieved": dp_bytes / (dp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dp_bytes / (dp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "smm_viterbi_kernel",
+                "kernel_ms": dp_ms, "algorithmic_bytes_per_launch": dp_bytes,
+                "note": "rank 0's shard of the sharded corpus; the DP is fp64-VALU / latency-bound, not HBM-bound"}
+    return {"scaling": "strong", "roofline_rank0": roof, "workload": "%s seed %d: %d videos, %d frames, sharded by video (whole single-task "
             "batches of %d, greedy LPT on the DP work)" % (a.strong_workload, a.seed, int(tot[1]), int(tot[0]), cfg['batch_size']),
             "value": float(tot[0]) * a.steps / dt_all, "unit": "frames/s", "n_gpus": world, "ms_per_step": dt_all / a.steps * 1e3,
             "frames": int(tot[0]), "videos": int(tot[1]), "max_frames_on_a_rank": int(tmax[1]),
             "dp_kernel_ms_max_over_ranks": float(tmax[2]),
-            "stats_reduced_over": "RCCL all-reduce" if (world > 1 and a.backend == 'nccl') else ("gloo all-reduce" if world > 1 else "1 rank"),
+            "stats_reduced_over": ("%s all-reduce%s" % ("RCCL" if torch.distributed.get_backend() == 'nccl' else "gloo",
+                                                         " (one-rank group)" if world == 1 else "")) if D.active() else "1 rank",
             "stats": {k: round(v, 9) for k, v in summary.items()}}
 
 
@@ -481,9 +514,20 @@ def train_step_rate(args, data, model):
 
 def logz_cpu_baseline(pc, budget_s=10.0):
     """cpu_baseline of the log-partition leg (kind 'port'): oracle/smm_oracle.c forward + exact backward (posteriors),
-    OpenMP over the videos of a task, on whole tasks until ~budget_s are spent."""
+    OpenMP over the videos of a task, on whole tasks until ~budget_s are spent.  The twin's logZ and gradients are
+    compared with smm_logz_f64 / smm_logz_bwd_f64 on the same packed corpus (second return value: max relative error
+    of logZ, max absolute error of the four gradients; tolerances of the path: 1e-6 / 2e-5)."""
     from oracle import factored as F
+    from action_segmentation_amd import ops
     t = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in pc.tables.items()}
+    elp_dev, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
+    ws = torch.empty(pc.batch.workspace_bytes(), dtype=torch.uint8, device=pc.x.device)
+    z_dev = ops.logz(pc.batch, elp_dev, t['trans'], t['init'], t['len'], endpen=pc.endpen, ws=ws, with_backward=True)
+    g_dev = ops.logz_bwd(pc.batch, elp_dev, t['trans'], t['init'], t['len'], z_dev, endpen=pc.endpen, ws=ws, with_backward=True)
+    torch.cuda.synchronize()
+    z_gpu = z_dev.cpu().numpy()
+    g_gpu = {k: v.cpu().numpy() for k, v in g_dev.items()}
+    z_rel, g_abs, n_checked = 0.0, 0.0, 0
     cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     by_group = {}
     for i in range(pc.n_videos):
@@ -505,16 +549,28 @@ def logz_cpu_baseline(pc, budget_s=10.0):
             elp[j, :x.shape[0]] = cst + xd @ w - 0.5 * (xd * xd) @ inv_var[:, None]
             if cons is not None:
                 elp[j, :x.shape[0]] += cons[j]
-        F.logz(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(), t['init'][g, :c].cpu().numpy(),
-               t['len'][g, :kp, :c].cpu().numpy(), ep, grad=True)
+        z_ref, g_ref = F.logz(elp, [pc.lengths[i] for i in vids], t['trans'][g, :c, :c].cpu().numpy(),
+                              t['init'][g, :c].cpu().numpy(), t['len'][g, :kp, :c].cpu().numpy(), ep, grad=True)
         dt += time.perf_counter() - t0
+        # parity (outside the CPU timing): one group = one task here, so the twin's table gradients of this call are the
+        # GPU's rows of group g
+        z_rel = max(z_rel, float(np.max(np.abs(z_gpu[vids] - z_ref) / np.abs(z_ref))))
+        for j, i in enumerate(vids):
+            n, o = pc.lengths[i], pc.frame_offset[i]
+            g_abs = max(g_abs, float(np.max(np.abs(g_gpu['elp'][o:o + n, :c] - g_ref['elp'][j, :n]))))
+        if sum(1 for q in range(pc.n_videos) if pc.group[q] == g) == len(vids):
+            g_abs = max(g_abs, float(np.max(np.abs(g_gpu['trans'][g, :c, :c] - g_ref['trans']))),
+                        float(np.max(np.abs(g_gpu['init'][g, :c] - g_ref['init']))),
+                        float(np.max(np.abs(g_gpu['len'][g, :kp, :c] - g_ref['len']))))
+        n_checked += len(vids)
         frames += sum(pc.lengths[i] for i in vids)
         n_vid += len(vids)
         if dt > budget_s:
             break
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d videos, oracle/smm_oracle.c log-partition forward + exact backward, OpenMP over the videos of a "
-                      "task (%d host threads), %.1f s" % (n_vid, cores, dt)}
+    res = {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d videos, oracle/smm_oracle.c log-partition forward + exact backward, OpenMP over the videos of a "
+                     "task (%d host threads), %.1f s" % (n_vid, cores, dt)}
+    return res, {"logz_videos_checked": n_checked, "logz_max_rel": z_rel, "grad_max_abs": g_abs}
 
 
 def pmc_traffic(workload):
@@ -546,6 +602,7 @@ def dry_run(a, rank, world, D):
     red = D.all_reduce_counters({'frames': [frames, len(mine)], 'ranks': [1, rank]})
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
+                          "scaling": a.scaling,
                           "frames": int(red['frames'][0]), "batches": int(red['frames'][1]), "ranks_seen": int(red['ranks'][0]),
                           "corpus_frames": dry.n_frames, "n_batches": len(batches), "backend": "gloo" if world > 1 else None}),
               flush=True)
@@ -575,6 +632,7 @@ def main():
     frames = pc.n_frames
     stream = torch.cuda.current_stream()
     dt, dp_ms, labels = timed_decode(a, pc, world)
+    labels = labels.clone()          # out of the pinned staging buffer the next decode (predict legs) writes into again
     labels_dev = labels.to(dev)      # the evaluation kernels below (outside the timed region) read device labels
 
     # evaluation, outside the timed region: the reference's per-task statistics from device counters
@@ -606,7 +664,7 @@ def main():
     rd = D.reduce_device()
     counters = D.all_reduce_tensor(torch.tensor([float(correct), float(frames), float(frames)], dtype=torch.float64, device=rd))
     tmax = D.all_reduce_tensor(torch.tensor([dt], dtype=torch.float64, device=rd),
-                               op=torch.distributed.ReduceOp.MAX if world > 1 else None)
+                               op=torch.distributed.ReduceOp.MAX if D.active() else None)
     total_frames = float(counters[2])
     dt = float(tmax[0])
 
@@ -626,17 +684,20 @@ def main():
         par = {None: "1 rank, no collective", "nccl": "RCCL", "gloo": "gloo (rehearsal: NOT a measurement of the RCCL path)"}[backend]
         weak = {"value": total_frames * a.steps / dt, "ms_per_step": dt / a.steps * 1e3}
         head = weak if (a.scaling == 'weak' or strong is None) else strong
+        wl_text = ("%s seed %d: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
+                   "task (mean %.1f; per task: %s), max span length %d, D=%d; closed-form-fitted HSMM parameters"
+                   % (a.workload, a.seed, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
+                      max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg,
+                      ' '.join(str(c) for c in sorted(pc.n_states)), cfg['max_k'] - 1, cfg['d']))
+        if head is not weak:
+            wl_text = head["workload"] + " (BASELINE config 5; the weak leg beside it: " + wl_text + ")"
         res = {
             "metric": METRIC,
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if head is weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic", "backend": backend,
-            "config": {"workload": "%s seed %d: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
-                                   "task (mean %.1f; per task: %s), max span length %d, D=%d; closed-form-fitted HSMM parameters"
-                       % (a.workload, a.seed, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
-                          max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg,
-                          ' '.join(str(c) for c in sorted(pc.n_states)), cfg['max_k'] - 1, cfg['d']),
+            "config": {"workload": wl_text,
                        "parallelism": "videos sharded across %d GPU(s), no data-path collective; step time MAX and frame counters "
                                       "SUM all-reduced over: %s" % (world, par)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -663,11 +724,19 @@ def main():
         }
         if strong is not None:
             res["strong_scaling"] = strong
+            if head is strong and strong.get("roofline_rank0"):
+                res["roofline_weak_leg"] = res["roofline"]
+                res["roofline"] = strong["roofline_rank0"]
+        parity = {"frames_checked": 0, "label_mismatches": None, "logz_max_rel": None, "grad_max_abs": None,
+                  "what": "the C twin (oracle/smm_oracle.c) against the GPU on this workload, checker side only: frame "
+                          "labels of the TIMED decode for every video the cpu_factored leg covered; cfg4: logZ and the "
+                          "four gradients of smm_logz_f64 / smm_logz_bwd_f64 for the videos of the logZ baseline"}
         if a.workload == 'cfg4':
             res["logz_fwd_bwd"] = train_step_rate(args, data, model)
             if not a.no_cpu_baseline:
                 try:
-                    res["logz_fwd_bwd"]["cpu_baseline"] = logz_cpu_baseline(pc)
+                    res["logz_fwd_bwd"]["cpu_baseline"], zp = logz_cpu_baseline(pc)
+                    parity.update(zp)
                 except Exception as e:
                     res["logz_fwd_bwd"]["cpu_baseline"] = {"error": str(e)}
         if world == 1 and not a.no_predict_e2e:
@@ -675,9 +744,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(data, model, pc)
             try:
-                res["cpu_factored"] = cpu_factored(pc, model)
+                res["cpu_factored"], lp = cpu_factored(pc, model, gpu_labels=lab)
+                parity.update(lp)
             except Exception as e:                              # the C oracle needs gcc on the box; report, don't fail
                 res["cpu_factored"] = {"error": str(e)}
+        res["parity"] = parity
         if world == 1 and a.workload == 'cfg3' and a.second_seed >= 0 and a.second_seed != a.seed and a.scale == 1.0:
             # the other draw of states per task (not the headline: same shapes, friendlier state counts)
             data2 = synth.SynthDatasplit(a.workload, seed=a.second_seed, device=dev)
@@ -688,7 +759,7 @@ def main():
                                  "ms_per_step": dt2 / a.steps * 1e3, "dp_kernel_ms": dp2, "frames": pc2.n_frames,
                                  "states_per_task": ' '.join(str(c) for c in sorted(pc2.n_states))}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -39,11 +39,22 @@ def test_world_size_mismatch_fails():
     assert 'WORLD_SIZE=1' in (r.stderr + r.stdout)
 
 
-def test_more_ranks_than_gpus_fails_before_spawning():
+def test_more_ranks_than_gpus_fails():
+    """The spawning parent does not touch the GPU runtime; the rank without a GPU of its own fails and takes the job down."""
     import torch
     n = torch.cuda.device_count()
     r = run(['--gpus', str(max(n, 1) + 1)])
-    assert r.returncode != 0 and 'GPU(s) visible' in r.stderr
+    assert r.returncode != 0 and 'has no GPU of its own' in r.stderr
+
+
+def test_strong_scaling_is_the_headline_for_more_than_one_rank():
+    """BASELINE config 5 (one corpus sharded by video) is what N > 1 headlines; N = 1 stays the weak (cfg3) workload."""
+    r = run(['--gpus', '2', '--dry-run', '--strong-workload', 'tiny'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])['scaling'] == 'strong'
+    r = run(['--gpus', '1', '--dry-run', '--strong-workload', 'tiny'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])['scaling'] == 'weak'
 
 
 def test_share_gpus_needs_gloo():

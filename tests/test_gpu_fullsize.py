@@ -120,3 +120,142 @@ def test_cfg3_gangs_and_singles_agree(monkeypatch):
     b = decode_both(cp)
     np.testing.assert_array_equal(a[0]['spans'].cpu().numpy(), b[0]['spans'].cpu().numpy())
     np.testing.assert_array_equal(a[0]['best'].cpu().numpy(), b[0]['best'].cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------ log-partition, full size
+def _constrained_corpus(seed, lengths, c, k, d=200, rate=(10, 50)):
+    """BASELINE configs[3] shape: a left-to-right chain (transition mask -1e9 BEFORE the softmax, reference
+    semimarkov_modules.py:298-322; only the first state may start, :284-296; only the last may end, :462-471) with
+    narration constraints (-1e4 on a step's column outside its window, 0 on background columns, semimarkov.py:149-157)."""
+    cp = make_corpus(seed, lengths, c, k, d=d, rate=rate)
+    g = np.random.default_rng(seed + 1000)
+    # videos that the chain can explain: ONE pass through the states (runs longer than K - 1 frames are covered by
+    # self-transitions); the odd videos keep make_corpus' cyclic labels, which the chain can only explain badly
+    sigma = np.sqrt(cp['var'])
+    for i, t in enumerate(lengths):
+        if i % 2 == 0 and t >= c:
+            cuts = np.sort(g.choice(np.arange(1, t), size=c - 1, replace=False))
+            lab = np.repeat(np.arange(c), np.diff(np.concatenate([[0], cuts, [t]])))
+            cp['labs'][i] = lab
+            cp['xs'][i] = (cp['mu'][lab] + sigma * g.standard_normal((t, d))).astype(np.float32)
+    logits = g.standard_normal((c, c))
+    allowed = np.eye(c, dtype=bool)
+    for f in range(c - 1):
+        allowed[f + 1, f] = True                                       # [to, from]
+    masked = np.where(allowed, logits, -1e9)
+    mx = masked.max(0, keepdims=True)
+    cp['trans'] = masked - (mx + np.log(np.exp(masked - mx).sum(0, keepdims=True)))
+    il = np.where(np.arange(c) == 0, g.standard_normal(c), -1e9)
+    cp['init'] = il - (il.max() + np.log(np.exp(il - il.max()).sum()))
+    cp['endpen'] = np.full((len(lengths), c), -1e9)
+    cp['endpen'][:, c - 1] = 0.0
+    cons = []
+    for lab in cp['labs']:
+        t = lab.shape[0]
+        cn = np.zeros((t, c), np.float32)
+        for j in range(1, c, 2):                                       # odd states = steps
+            pos = np.flatnonzero(lab == j)
+            lo, hi = (0, t) if len(pos) == 0 else (max(0, pos.min() - int(g.integers(0, 20))), min(t, pos.max() + 1 + int(g.integers(0, 20))))
+            cn[:lo, j] = -1e4
+            cn[hi:, j] = -1e4
+        cons.append(cn)
+    cp['cons'] = cons
+    return cp
+
+
+def _logz_both(cp):
+    """features -> smm_emission_f64 -> smm_logz_f64 + smm_logz_bwd_f64 -> smm_emission_bwd_f64 on the GPU; the C twin's
+    emission + exact forward-backward on the host, and the chain rule through the emission scorer in numpy."""
+    from action_segmentation_amd import ops
+    dev = torch.device('cuda:0')
+    lengths = np.array([x.shape[0] for x in cp['xs']], dtype=np.int64)
+    b, tmax, c, k, d = len(lengths), int(lengths.max()), cp['c'], cp['k'], cp['d']
+    kp = min(k, tmax)
+    off = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    x = torch.from_numpy(np.concatenate(cp['xs'], 0)).to(dev)
+    mu, var = cp['mu'], cp['var']
+    w = (mu / var).T.copy()
+    lognorm = -0.5 * np.log(var).sum() - 0.5 * d * np.log(2 * np.pi)
+    cst = -0.5 * (mu * mu / var).sum(1) + lognorm
+    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    cons = cp.get('cons')
+    cons_dev = None if cons is None else torch.from_numpy(np.concatenate(cons, 0)).to(dev).contiguous()
+    batch = ops.Batch(lengths, [c], k, c_max=c, frame_offset=off, kp=[kp] * b, d=d, t_max=tmax, total_frames=int(lengths.sum()))
+    tabs = (t(cp['trans'][None]), t(cp['init'][None]), t(cp['lens'][None]))
+    ep = t(cp.get('endpen'))
+    elp64, _ = ops.emission(batch, x, t(w[None]), t(cst[None]), t(1.0 / var), cons=cons_dev)
+    ws = torch.empty(batch.workspace_bytes(), dtype=torch.uint8, device=dev)
+    up = np.linspace(0.5, 1.5, b)
+    z = ops.logz(batch, elp64, *tabs, endpen=ep, ws=ws, with_backward=True)
+    gr = ops.logz_bwd(batch, elp64, *tabs, z, grad_logz=t(up), endpen=ep, ws=ws, with_backward=True)
+    g_w, g_cst, g_iv = ops.emission_bwd(batch, x, gr['elp'], ws=ws)
+    torch.cuda.synchronize()
+    # the twin
+    xp = np.zeros((b, tmax, d), np.float32)
+    cn = None if cons is None else np.zeros((b, tmax, c))
+    for i, xi in enumerate(cp['xs']):
+        xp[i, :xi.shape[0]] = xi
+        if cons is not None:
+            cn[i, :xi.shape[0]] = cons[i]
+    elp = F.emission(xp, lengths, mu, 1.0 / var, lognorm, cn)
+    z_ref, g_ref = F.logz(elp, lengths, cp['trans'], cp['init'], cp['lens'], cp.get('endpen'), grad=True, upstream=up)
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref, rtol=1e-6)
+    ge = gr['elp'].cpu().numpy()
+    gw_ref, gc_ref, giv_ref = np.zeros((d, c)), np.zeros(c), np.zeros(d)
+    for i, ti in enumerate(lengths):
+        gi = ge[off[i]:off[i] + ti]
+        np.testing.assert_allclose(gi, g_ref['elp'][i, :ti], rtol=2e-5, atol=2e-5, err_msg='video %d' % i)
+        np.testing.assert_allclose(gi.sum(1), up[i], rtol=1e-4)        # posteriors: exactly one state per frame
+        xd = cp['xs'][i].astype(np.float64)
+        gw_ref += xd.T @ g_ref['elp'][i, :ti]
+        gc_ref += g_ref['elp'][i, :ti].sum(0)
+        giv_ref += -0.5 * ((xd * xd) * g_ref['elp'][i, :ti].sum(1, keepdims=True)).sum(0)
+    np.testing.assert_allclose(gr['trans'].cpu().numpy()[0], g_ref['trans'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gr['init'].cpu().numpy()[0], g_ref['init'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gr['len'].cpu().numpy()[0, :kp], g_ref['len'], rtol=2e-5, atol=2e-5)
+    # chain rule through elp = cst + x.w - 0.5 x^2.inv_var: sums over ~T frames of posteriors x features
+    scale = max(1.0, float(np.abs(gw_ref).max()))
+    np.testing.assert_allclose(g_w.cpu().numpy()[0], gw_ref, rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(g_cst.cpu().numpy()[0], gc_ref, rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(g_iv.cpu().numpy(), giv_ref, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(giv_ref).max())))
+    return z_ref
+
+
+@pytest.mark.parametrize('c', [7, 13])
+def test_cfg4_log_partition_and_gradients_with_constraints(c):
+    """BASELINE configs[3] at its own shape: T <= 2048, K = 64, 7..13 states, D = 200, chain-masked transitions at -1e9,
+    narration penalties -1e4, end penalties: the fp32 integer-exponent ring of smm_logz_kernel at real magnitudes
+    (emission ~ -290 per frame, logZ ~ -6e5)."""
+    z = _logz_both(_constrained_corpus(40 + c, [2048, 900, 1500, 200, 640], c, 64))
+    assert np.all(z < -1e4) and np.all(np.isfinite(z))
+
+
+@pytest.mark.parametrize('c', [21, 23])
+def test_cfg3_shape_log_partition_and_gradients(c):
+    """K = 1024, T = 14 000 (cumE reaches 4e6), 21 and 23 states, next to short videos of the same task."""
+    _logz_both(make_corpus(50 + c, [14000, 600, 3000], c, 1024))
+
+
+def test_cfg3_whole_corpus_one_ragged_launch_equals_the_twin():
+    """BASELINE configs[2] as bench.py decodes it: the cfg3 seed-2 corpus (18 tasks x 20 videos, 11..23 states, T up to
+    14 000, K = 1024) in ONE ragged launch -- gangs, singles and all -- against the C twin, every frame of every video."""
+    import bench
+    from action_segmentation_amd import synth
+    from action_segmentation_amd.semimarkov import SemiMarkovModel
+    dev = torch.device('cuda:0')
+    cfg = synth.CONFIGS['cfg3']
+    data = synth.SynthDatasplit('cfg3', seed=2, device=dev)
+    fitted = SemiMarkovModel.from_args(synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size']), data)
+    fitted.fit(data.subset(6), use_labels=True)
+    model = SemiMarkovModel.from_args(synth.make_args(cfg['max_k'], cuda=True, batch_size=cfg['batch_size']), data)
+    model.model.load_state_dict(fitted.model.state_dict(), strict=False)
+    model.model.to(dev)
+    pc = model.prepare(data)
+    out = model.model.decode_packed(pc, want_spans=False, want_labels=True)
+    torch.cuda.synchronize()
+    from action_segmentation_amd import ops
+    ops.check_decoded(pc.batch, out)
+    labels = out['labels'].cpu().numpy()
+    _, par = bench.cpu_factored(pc, model, gpu_labels=labels, budget_s=1e9)
+    assert par['videos_checked'] == 360 and par['frames_checked'] == pc.n_frames
+    assert par['label_mismatches'] == 0

@@ -169,3 +169,27 @@ def test_fit_with_batch_accumulation_uses_packed_launches():
     log = []
     model.fit(data, use_labels=False, callback_fn=lambda ep, st: log.append(st['train_loss']))
     assert len(log) == 5 and all(np.isfinite(log)) and log[-1] < log[0] - 0.5, log
+
+
+def test_fit_counts_the_leftover_batches_of_an_epoch():
+    """6 batches, --batch_accumulation 4: one optimiser step on four batches, two left over.  Their losses count in
+    train_loss / train_nll (reference semimarkov.py:273-310 appends every batch's loss and steps only on full groups).
+    lr = 0 keeps the parameters in place, so the epoch's statistics must equal the directly computed per-batch values."""
+    data = synth.SynthDatasplit('tiny', seed=9)
+    args = synth.make_args(data.max_k, cuda=True, batch_size=2, epochs=1, lr=0.0, print_every=0, batch_accumulation=4)
+    model = SemiMarkovModel.from_args(args, data)
+    log = []
+    model.fit(data, use_labels=False, callback_fn=lambda ep, st: log.append(st))
+    batches = list(make_data_loader(args, data, shuffle=False, batch_by_task=True, batch_size=2))
+    assert len(batches) == 6
+    m = model.model
+    nll, frames, per_batch = 0.0, 0, []
+    with torch.no_grad():
+        for b in batches:
+            ll, _ = m.log_likelihood(b['features'].to(model.device), b['lengths'], b['task_indices'], spans=None)
+            per_batch.append(-float(ll))
+            nll += -float(ll) * len(b['lengths'])
+            frames += int(b['lengths'].sum())
+    assert len(log) == 1
+    np.testing.assert_allclose(log[0]['train_loss'], np.mean(per_batch), rtol=1e-9)
+    np.testing.assert_allclose(log[0]['train_nll_frame_avg'], nll / frames, rtol=1e-9)

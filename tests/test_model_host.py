@@ -73,3 +73,33 @@ def test_predict_without_gpu_fails_loudly():
     model.fit(data, use_labels=True)
     with pytest.raises(SmmError):
         model.predict(data)
+
+
+def test_a_rank_without_batches_prepares_and_predicts_nothing():
+    """More ranks than single-task batches (a small dev split on a big job): that rank's shard is an EMPTY corpus, its
+    predict() returns {} without a launch (it still takes part in the evaluation's reductions), and the other ranks'
+    shards partition the batches."""
+    data, args, model = tiny_model()
+    n_batches = 6
+    world = n_batches + 2
+    seen = []
+    for rank in range(world):
+        pc = model.prepare(data, shard=(rank, world))
+        seen += list(pc.video_names)
+        if pc.n_videos == 0:
+            assert pc.x.shape[0] == 0 and pc.n_frames == 0
+            assert model.predict(data, shard=(rank, world)) == {}
+    assert sorted(seen) == sorted(n for names in data._videos_by_task.values() for n in names)
+    assert pack_batches([], torch.device('cpu'), 12).n_videos == 0
+
+
+def test_prepared_cache_key_covers_the_constraints():
+    """The resident PackedCorpus bakes in the narration weight and the allowed ends: changing either is a cache miss."""
+    data, args, model = tiny_model(constrain=True, narration=('test',))
+    a = model.prepare(data)
+    assert model.prepare(data) is a
+    args.sm_constrain_narration_weight = -123.0
+    b = model.prepare(data)
+    assert b is not a and float(b.cons.min()) == -123.0
+    model.clear_prepared()
+    assert model.prepare(data) is not b

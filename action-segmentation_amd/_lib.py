@@ -89,3 +89,29 @@ def check(status):
         if status == -4:
             msg += " (hipError %d)" % lib.smm_last_hip_error()
         raise SmmError("libsmmdp: %s" % msg)
+
+
+def host_cores():
+    """CPU cores this process is entitled to: the cgroup's CFS quota when there is one, else the affinity mask
+    (SMM_HOST_CORES overrides).  A container that SEES 256 logical CPUs but owns 16 is throttled for the rest of every
+    100 ms scheduling period once default-sized thread pools have spun the quota away: ~90 ms stalls in the host glue
+    of a 1 ms decode.  The CLI sizes torch's intra-op pool with this."""
+    import os
+    env = os.environ.get('SMM_HOST_CORES')
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for quota_file, period_file in (('/sys/fs/cgroup/cpu.max', None),
+                                    ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us')):
+        try:
+            if period_file is None:
+                q, p = open(quota_file).read().split()[:2]
+                if q == 'max':
+                    continue
+            else:
+                q, p = open(quota_file).read(), open(period_file).read()
+            if float(q) > 0:
+                return max(1, min(n, int(float(q) / float(p) + 0.5)))
+        except (OSError, ValueError):
+            continue
+    return n

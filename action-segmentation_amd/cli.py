@@ -171,6 +171,10 @@ def main(argv=None):
     if not args.cuda:
         raise SystemExit("--cuda is required: the semi-Markov path has no CPU back-end in this build")
     from . import distributed
+    from ._lib import host_cores
+    # the host side of this path is glue around kernels (tiny tensors): a pool of one thread per VISIBLE CPU only adds
+    # wake-up latency, and in a container with a CPU quota it gets the process throttled
+    torch.set_num_threads(max(1, min(8, host_cores())))
     # torchrun: one rank per GPU over RCCL, decode sharded by video, training data-parallel (SMM_DIST_BACKEND=gloo: a
     # rehearsal with several ranks on one GPU)
     distributed.init(backend=os.environ.get('SMM_DIST_BACKEND') or None)

@@ -113,6 +113,7 @@ struct SmmPlan {
     size_t hist_doubles;   // sum over videos of 8*c_max*(T+1): forward cumE/h/gamma, backward cumE/h/gamma, 2 transposes
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
+    size_t band_doubles;   // Viterbi BAND mode: state-major length table + skip-test bounds per (group, state)
     size_t total;
 };
 
@@ -135,7 +136,8 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.hist_doubles = h;
     p.elp_doubles = (size_t)s->total_frames * s->c_max;
     p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
-    p.total = p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles) + 1024;
+    p.band_doubles = (size_t)s->n_groups * s->c_max * ((size_t)SMM_BAND_ROW + SMM_BAND_TAB);
+    p.total = p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles + p.band_doubles) + 1024;
     return p;
 }
 
@@ -162,6 +164,8 @@ struct Staged {
     double *hist;
     double *elp;
     double *tabs;
+    double *band;          // [g][c_max][k_rows] len_t | [g][c_max][16] band bounds
+    bool band_mode;        // Viterbi: BAND mode (one workgroup per video, exact band skipping) instead of 1024-slot rings / gangs
     int32_t *pair_flags;
     int32_t *em_cum;       // emission: workgroups before each video of `order` ([b + 1])
     int em_tpw, em_blocks;
@@ -303,6 +307,8 @@ static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, i
     return (int)gangs.size();
 }
 
+static bool band_mode(int kp_max, int c_need);
+
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
 // want_gangs: plan gangs for the Viterbi kernel (a list-schedule simulation, ~0.3 ms of host time at 360 videos: only
 // the entry points that launch that kernel ask for it)
@@ -356,7 +362,8 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
     out->n_pairs = 0;
     out->pairs_cover_big = false;
-    if (want_gangs) out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
+    out->band_mode = want_gangs && band_mode(kp_max, c_need);
+    if (want_gangs && !out->band_mode) out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
     {
         // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
         int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
@@ -386,9 +393,20 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     out->hist = reinterpret_cast<double *>(base + p.meta_bytes);
     out->elp = out->hist + p.hist_doubles;
     out->tabs = out->elp + p.elp_doubles;
+    out->band = out->tabs + p.tab_doubles;
     out->kp_max = kp_max;
     out->c_need = c_need;
     return SMM_OK;
+}
+
+// Viterbi at K > 512: BAND mode (smm_viterbi.hip) for up to 28 states; SMM_BAND=0 brings the 1024-slot rings and the gangs
+// back (A/B measurements, and the shapes above 28 states)
+static bool band_mode(int kp_max, int c_need)
+{
+    if (kp_max <= 512 || c_need > 28 || std::getenv("SMM_NW")) return false;
+    if (std::getenv("SMM_PAIRS") || std::getenv("SMM_TRIPLES")) return false;     // an explicit gang configuration is asked for
+    const char *e = std::getenv("SMM_BAND");
+    return !(e && std::atoi(e) == 0);
 }
 
 static int ring_regs(int kp_max)
@@ -430,6 +448,13 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     a.n_pairs = st.n_pairs;
     a.pair_flags = st.pair_flags;
     if (st.pairs_cover_big) a.flags |= 4;
+    if (st.band_mode) {
+        double *len_t = st.band, *band_tab = st.band + (size_t)s->n_groups * s->c_max * SMM_BAND_ROW;
+        smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, s->n_groups, s->c_max, s->k_rows, stream);
+        a.len_t = len_t;
+        a.band_tab = band_tab;
+        a.flags |= 128;
+    }
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant

@@ -6,6 +6,12 @@
 #define SMM_BIG_NEG (-1e9)   // reference BIG_NEG, semimarkov_modules.py:20
 #define SMM_NEG_INF (-__builtin_huge_val())
 #define SMM_MAX_STATES_DEV 32
+// Viterbi BAND mode (smm_viterbi.hip)
+#define SMM_BAND_DELAY 112
+#define SMM_BAND_LO 16
+#define SMM_BAND_N 8          // delayed bands
+#define SMM_BAND_ROW 1026      // doubles per state of the shifted state-major length table (row[k + 1] = len[k], k <= 1024)
+#define SMM_BAND_TAB 16       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 17..158, [m] max len over band m
 
 // One entry per video, built on the host by smm_plan() and staged into the workspace.
 struct SmmVideo {
@@ -32,7 +38,8 @@ struct SmmDpArgs {
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
-    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] gangs that timed out, [2] gangs repaired
+    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] gangs that timed out, [2] gangs repaired;
+                               // [3] Viterbi BAND mode, diagnostic: delayed band-blocks (4 sources x one band of one state) evaluated
     int32_t c_max, k_rows, t_max, b;
     int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
                                // backward; bit 2: every video with more than 21 states is in the paired prefix;
@@ -43,6 +50,8 @@ struct SmmDpArgs {
     const double *trans_t;     // logZ, both directions in one launch (flags bit 6): transposed tables [g][c_max][c_max]
     double *logz_b;            // ... and where the reversed runs put their closing value [b]
     int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
+    const double *len_t;       // Viterbi BAND mode (flags bit 7, 128): [g][c_max][k_rows] state-major length table ...
+    const double *band_tab;    // ... and [g][c_max][16] bounds of the band skip test (smm_viterbi.hip: smm_band_tables_kernel)
 };
 
 // One-CU videos on 8 waves: the rank (0..6) that trades places with the chain wave's partner (rank 6, the lightest) so

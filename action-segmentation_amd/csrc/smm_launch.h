@@ -48,6 +48,9 @@ int smm_emission_bwd_chunk();
 void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
+// Viterbi BAND mode: the state-major length table and the skip-test bounds of every (group, state) (smm_viterbi.hip)
+void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, int n_groups, int cm,
+                            int k_rows, hipStream_t stream);
 // follow-up of a launch with gangs: decodes, on one CU each, the videos whose gang gave up (no-op kernels otherwise)
 void smm_launch_viterbi_recovery(const SmmDpArgs &a, int c_need, hipStream_t stream);
 // LogSemiring forward: logz[b]; same arguments as the Viterbi launch

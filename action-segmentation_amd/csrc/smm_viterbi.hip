@@ -396,6 +396,45 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// BAND mode (PAIR = 2): one workgroup per video at K > 512, the lattice cut along the segment length into BANDS that share
+// ONE ring of 128 upcoming targets per state, and whole bands skipped -- exactly -- while they cannot matter.
+//   band 0     lengths K0 < k <= 127, sources undelayed: always evaluated (what a gang leader's short rings do);
+//   band m>=1  lengths 16+112m .. 127+112m (m = 1..8 covers 128..1023), fed with the source of 112m positions ago:
+//              slot p of the shared ring, waiting for target n at ring distance kr = n - s, receives
+//              h[s - 112m] + len[kr + 112m]; ring distances below 16 carry -inf in these bands (around the hand-over a
+//              slot changes targets at kr = 6..9, block-wise; a band's own lengths never come that close).
+// The accumulators A are shared by the bands of a state (all of them aim at the same 128 targets): 2 registers per
+// state for A and 2 per band for its length ring, 36 per state instead of the 64 of a 1024-slot ring.
+//
+// Skipping.  Per state and group of 16 sources (4 hand-over blocks) the owner wave keeps hm[g] = max h over the group
+// (LDS ring of 64 groups).  Before the sources of group G are pushed, band m is switched off for the group when
+//     hm[G - 7m] + max_{k in band m} len[k]   <=   hm[G - 1] + min_{17 <= k <= 158} len[k].
+// Left: an upper bound of every candidate the band would push (its 16 sources are group G - 7m).  Right: for every
+// target n the band can reach, n in [16G + 16, 16G + 142], the best source s* of group G - 1 is a real candidate of
+// A[n] with 17 <= n - s* <= 158, so the right side is a lower bound of the final A[n] (all of it needs kp - 1 >= 158;
+// otherwise the bound is -inf and nothing is skipped).  max is exact and rounding is monotone, so a skipped candidate
+// can never be the only one that attains a maximum: not a bit of the result changes, whatever the inputs are.  What
+// changes is the work: on CrossTask-shaped data 99 % of the delayed band-groups are skipped (14 % of the lattice cells
+// are evaluated, profiles/round3_prune_survival.txt), so the frame time is the chain wave's for any state count.
+// A band that comes back re-reads its length ring from the state-major length table (len_t); the h rows of the delayed
+// sources come from the history the mover wave writes anyway (lane = (state, band), 4 positions each, fetched one block
+// ahead with sc1 loads and handed to the pushes with v_readlane).
+// (SMM_BAND_DELAY = 112, SMM_BAND_LO = 16, SMM_BAND_N = 8 bands, SMM_BAND_TAB: smm_device.h)
+
+// Length ring of band m at push step t (a multiple of 4): slot p = 2 lane + r is at ring distance kr = (p + off) & 127,
+// off = B + D - t (odd).  The state-major table is stored shifted by one (row[k + 1] = len[k]) so that a lane's two
+// lengths are one aligned 16-byte load; a delayed band keeps NO ring between blocks -- it is read again from the table
+// (8 KB per state, L1-resident while the state is active) at the phase of every block it is switched on for.
+__device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double *lent_row, int off, int m, int kp, int lane)
+{
+    const int kr0 = (lane * 2 + off) & 127;                       // odd; kr0 = 127: the second slot wraps to 0 (masked)
+    const int k0 = kr0 + SMM_BAND_DELAY * m;
+    const double2 v = *reinterpret_cast<const double2 *>(lent_row + k0 + 1);
+    L[0] = (kr0 >= SMM_BAND_LO && k0 <= kp - 1) ? v.x : SMM_NEG_INF;
+    L[1] = (kr0 != 127 && kr0 + 1 >= SMM_BAND_LO && k0 + 1 <= kp - 1) ? v.y : SMM_NEG_INF;
+}
+
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per lane group of the chain wave: 8, 12 or 16
 //     (two groups of 32 lanes) or 4 (launches of at most 16 states without gangs: FOUR groups of 16 lanes, merged by a
@@ -408,11 +447,13 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 //     lengths 1..2B+D-1 itself
 // PAIR 1: the first 3*a.n_pairs workgroups are gangs of leader / follower 0 / follower 1 (R = 16, 8 waves only; see
 //         PAIR mode above; follower 1 returns at once when the video needs one follower)
+//      2: BAND mode (above): one workgroup per video, 128-slot rings, SPW = states per pusher wave (3 or 4)
 template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    static_assert(!PAIR || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair mode: 1024-slot rings, 8 waves");
+    static_assert(!PAIR || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair / band mode: K <= 1024, 8 waves");
+    constexpr bool GANG = PAIR == 1, BAND = PAIR == 2;
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
@@ -420,12 +461,12 @@ smm_viterbi_kernel(SmmDpArgs a)
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
     // role: 0 one workgroup per video, 1 leader, 2 follower of pair blockIdx.x / 2
     int role = 0, vsel = blockIdx.x;
-    if (PAIR) {
+    if (GANG) {
         if ((int)blockIdx.x < 3 * a.n_pairs) { role = 1 + blockIdx.x % 3; vsel = blockIdx.x / 3; }   // gang: leader, follower 0, 1
         else vsel = blockIdx.x - 2 * a.n_pairs;
     }
     const int pair = blockIdx.x / 3;
-    const bool recover = !PAIR && (a.flags & 16);
+    const bool recover = PAIR == 0 && (a.flags & 16);
     if (recover) {
         // RECOVERY launch (follows a gang launch on the stream; grid = number of gangs): workgroup p decodes the video of
         // gang p again on ONE CU if that gang gave up waiting for a partner, and only if this configuration holds the
@@ -446,12 +487,12 @@ smm_viterbi_kernel(SmmDpArgs a)
         if (NW == 8 && threadIdx.x == 0) atomicAdd(a.err + 1, 1);          // gangs that timed out
         if (!mine) return;
     }
-    if (PAIR && role >= 2) {
+    if (GANG && role >= 2) {
         if ((a.flags & 32) && pair == 0) return;                           // (test hook: gang 0's followers never show up)
         if (T > 0) smm_follower(a, mv, C, pair, role - 2);
         return;
     }
-    const bool lead = PAIR && role == 1;
+    const bool lead = GANG && role == 1;
     const int cl = lead ? smm_pair_cl(C, mv.nfol) : 0;        // leader: long-range states it keeps
     const int cm = a.c_max;
     const int kp = mv.kp;
@@ -479,7 +520,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
-    __shared__ __attribute__((aligned(16))) double sh_along[PAIR ? 2 : 1][PAIR ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
+    __shared__ __attribute__((aligned(16))) double sh_along[GANG ? 2 : 1][GANG ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
+    __shared__ double sh_hm[BAND ? SMM_MAX_STATES_DEV : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
@@ -500,7 +542,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
-            if (PAIR) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[PAIR ? 1 : 0][i][c] = SMM_NEG_INF; }
+            if (GANG) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[GANG ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
         sh_gam[c] = SMM_NEG_INF;
         sh_gfin[c] = SMM_NEG_INF;
@@ -570,7 +612,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     ap[i] = sh_apart[jj & 1][i][to];
-                    if (PAIR) ap[i] = smm_fmax(ap[i], sh_along[PAIR ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
+                    if (GANG) ap[i] = smm_fmax(ap[i], sh_along[GANG ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
                     ev[i] = sh_e[jj & 1][i][to];
                 }
                 // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
@@ -645,7 +687,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
         }
         SMM_PROF_OUT();
-    } else if (PAIR && lead) {
+    } else if (GANG && lead) {
         // ============================================================================ pusher waves of a pair's leader
         // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21, rank+28 and long range
         // (128 <= k <= kp-1, 1024-slot rings) of states rank, rank+7 below cl.  The follower's long-range A' rows come
@@ -785,6 +827,196 @@ smm_viterbi_kernel(SmmDpArgs a)
             store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
         }
         if (stpar >= 0) __builtin_amdgcn_s_waitcnt(0x0F70);                 // (published after the barrier below)
+    } else if (BAND) {
+      if constexpr (BAND) {
+        // ============================================================================ pusher waves, BAND mode (see above)
+        constexpr int SPS = SPW, RS = 2, NBD = SMM_BAND_N;
+        static_assert(!BAND || SPS * NBD <= 64, "one lane per (state, band) of a pusher wave");
+        const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);   // states rank, rank + 7, ... (wave 4, the mover, owns the fewest)
+        const double *lent = a.len_t + (size_t)g * cm * SMM_BAND_ROW;       // [c][k + 1]: a state's lengths are contiguous
+        const double *btab = a.band_tab + (size_t)g * cm * SMM_BAND_TAB;
+        const bool bound_ok = kp - 1 >= 16 + 15 + 127;                       // the lower bound's witness needs lengths up to 158
+        double As[SPS][RS], L0[SPS][RS], hds[SPS];
+        double hmx[SPS];                                                     // max h over the sources of the current group
+        double lmx[SPS];                                                     // lane m: max len over band m  (lane 0: unused)
+        double lbm[SPS];                                                     // min len over 17..158 (uniform)
+        uint32_t act[SPS];                                                   // bit m: band m is switched on for the current group
+        uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
+#pragma unroll
+        for (int js = 0; js < SPS; ++js) {
+            const int c = js * NP + rank;
+            const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
+            smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
+            hds[js] = SMM_NEG_INF;
+            hmx[js] = SMM_NEG_INF;
+            act[js] = 0;
+            const bool mine = c < C && lane >= 1 && lane <= NBD && SMM_BAND_LO + SMM_BAND_DELAY * lane <= kp - 1;
+            lmx[js] = mine ? btab[(size_t)c * SMM_BAND_TAB + lane] : SMM_NEG_INF;
+            lbm[js] = (c < C && bound_ok) ? btab[(size_t)c * SMM_BAND_TAB] : SMM_NEG_INF;
+        }
+        // lane q = 8 js + (m - 1) fetches the delayed sources of (state js, band m), one block ahead
+        const int qjs = lane >> 3, qm = (lane & 7) + 1;
+        const int qc = qjs * NP + rank;
+        const double *qcol = hh + (size_t)((qjs < SPS && qc < C) ? qc : 0) * (T + 1);
+        double hq[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) hq[i] = SMM_NEG_INF;
+        // mover role (wave MW), as in the plain configuration below
+        int lo[NE], row[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            row[q] = e / cm;
+            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
+        }
+        int slo[NE], srw[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            srw[q] = e / C;
+            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
+        }
+        const int64_t e_last = (int64_t)T * cm - 1;
+        double pre[NE];
+        if (w == MW) {
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
+                pre[q] = elp[e < e_last ? e : e_last];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): tables and rings have arrived
+        auto store_block = [&](const double *src, double *dst, int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x;
+                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
+            }
+        };
+        auto store_h_block = [&](const double *src, int q) {
+#pragma unroll
+            for (int x = 0; x < NE; ++x) {
+                const int e = lane + 64 * x, c = e / B, i = e % B;
+                if (c < C && q * B + 1 + i <= T) hh[(size_t)c * (T + 1) + q * B + 1 + i] = src[i * SMM_MAX_STATES_DEV + c];
+            }
+        };
+        SMM_PROF_DECL;
+        for (int j0 = 0; j0 < J; j0 += UB) {
+#pragma unroll
+            for (int jj = 0; jj < UB; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;
+                if (w == MW) {
+                    double *dst = &sh_e[(jj + 1) & 1][0][0];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q)
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                        pre[q] = elp[e < e_last ? e : e_last];
+                    }
+                    if (j >= 1) {
+                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
+                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
+                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
+                    }
+                }
+                // this block pushes sources (j-1)B .. jB-1 (push steps jB ..): band 0 from LDS, the bands that are switched
+                // on from the rows fetched during the previous block
+#pragma unroll
+                for (int js = 0; js < SPS; ++js) {
+                    const int c = js * NP + rank;
+                    if (c >= C) break;
+                    const double *h_blk = &sh_h[(jj + 1) & 1][0][c];
+                    double hv[B];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
+                    smm_push<RS>(As[js], L0[js], hds[js], (jj * B) % RS);
+                    double gm = hds[js];
+#pragma unroll
+                    for (int i = 1; i < B; ++i) {
+                        smm_push<RS>(As[js], L0[js], hv[i - 1], (jj * B + i) % RS);
+                        gm = smm_fmax(gm, hv[i - 1]);
+                    }
+                    hds[js] = hv[B - 1];
+                    hmx[js] = smm_fmax(hmx[js], gm);
+                    if (act[js]) {
+                        // the bands that are switched on (rarely any): their rings at this block's phase come from the table
+                        const double *lrow = lent + (size_t)c * SMM_BAND_ROW;
+                        const int off = (B + D - j * B) & 127;
+                        uint32_t mm = act[js];
+                        nact += __builtin_popcount(mm);
+                        int m = __builtin_ctz(mm);
+                        double Lm[RS];
+                        smm_band_ring_load(Lm, lrow, off, m, kp, lane);
+                        while (true) {
+                            mm &= mm - 1;
+                            const int mn = mm ? __builtin_ctz(mm) : 0;
+                            double Ln[RS];
+                            if (mn) smm_band_ring_load(Ln, lrow, off, mn, kp, lane);      // in flight while band m is pushed
+                            const int q = js * 8 + m - 1;
+#pragma unroll
+                            for (int i = 0; i < B; ++i)
+                                smm_push<RS>(As[js], Lm, smm_readlane(hq[i], q), (jj * B + i) % RS);
+                            if (!mn) break;
+                            Lm[0] = Ln[0]; Lm[1] = Ln[1];
+                            m = mn;
+                        }
+                    }
+                    // hand A' of block j+1 to the chain wave and clear those slots (the B slots are all registers of B/RS lanes)
+                    const int d = lane - (((j + 1) * B) & 127) / RS;
+                    if (d >= 0 && d < B / RS) {
+                        double *a_blk = &sh_apart[(jj + 1) & 1][0][c];
+#pragma unroll
+                        for (int r = 0; r < RS; ++r) {
+                            a_blk[(d * RS + r) * SMM_MAX_STATES_DEV] = As[js][r];
+                            As[js][r] = ninf;
+                        }
+                    }
+                }
+                if (jj == 0) {
+                    // the sources of group G - 1 = j/4 - 1 are through: decide the bands of group G
+                    const int G = j / 4;
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) {
+                        const int c = js * NP + rank;
+                        if (c >= C) break;
+                        const double hprev = hmx[js];
+                        if (G >= 1 && lane == 0) sh_hm[BAND ? c : 0][BAND ? ((G - 1) & 63) : 0] = hprev;
+                        hmx[js] = SMM_NEG_INF;
+                        const int gi = G - 7 * lane;                         // lane m: the band's sources are group G - 7m
+                        const double hsrc = sh_hm[BAND ? c : 0][BAND ? (gi & 63) : 0];
+                        const double ub = hsrc + lmx[js];
+                        const double lb = hprev + lbm[js];
+                        const bool on = lane >= 1 && lane <= NBD && gi >= 0 && ub > lb;
+                        act[js] = (uint32_t)__ballot(on);
+                    }
+                }
+                // fetch the delayed sources of block j+1: positions jB - 112m .. + B-1 of (state, band) = lane
+                {
+                    unsigned long long lanes = 0;
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)((act[js] >> 1) & 0xffu) << (8 * js);
+                    if (lanes) {                                  // (nearly always nothing is switched on: no loads at all)
+                        const bool mine = (lanes >> lane) & 1ull;
+                        const int s0 = j * B - SMM_BAND_DELAY * qm;
+                        const double *src = qcol + ((mine && s0 >= 0) ? s0 : 0);
+#pragma unroll
+                        for (int i = 0; i < B; ++i) hq[i] = smm_ld_agent(src + i);
+                    }
+                }
+                SMM_BLOCK_BARRIER();                             // end of block j
+            }
+        }
+        SMM_PROF_OUT();
+        if (w == MW) {
+            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
+            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
+            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
+        }
+        if (lane == 0 && nact) atomicAdd(a.err + 3, (int)nact);             // error block word 3: see ops.error_words
+      }
     } else {
         // ============================================================================ pusher waves
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
@@ -895,7 +1127,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     // -------------------------------------------------------------------------------- last position
     // sh_gfin holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
-    if (PAIR && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
+    if (GANG && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
         smm_publish(a.pair_flags + 4 * pair, T);
     const bool no_eos = (a.flags & 8) != 0;    // add_eos=False: T counts the frames before the last one (see smmdp.h)
     if (w == 0) {
@@ -924,7 +1156,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 
     // -------------------------------------------------------------------------------- back-trace
     if (a.flags & 1) return;
-    if (PAIR && lead) {
+    if (GANG && lead) {
         // a gang that gave up (this workgroup or a follower) has garbage in its lattice: leave the outputs to the recovery
         // launch.  (A follower only ever gives up when this leader was not making progress, i.e. before this point.)
         if (__hip_atomic_load(a.pair_flags + 4 * pair + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -1045,6 +1277,38 @@ smm_viterbi_kernel(SmmDpArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ band tables
+// Per (parameter group, state): the state-major copy of the length table (a band that is switched back on reads its ring
+// from it, 128 consecutive lengths per wave instruction) and the bounds of the skip test: [0] min len over 17..158,
+// [m] max len over band m = 16+112m .. 127+112m (clipped to the table; a video's own kp only makes the bound looser).
+__global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len, const int32_t *n_states, double *len_t,
+                                                              double *band_tab, int cm, int k_rows)
+{
+    const int g = blockIdx.x / cm, c = blockIdx.x % cm;
+    const double *src = len + (size_t)g * k_rows * cm + c;
+    double *dst = len_t + ((size_t)g * cm + c) * SMM_BAND_ROW;     // row[k + 1] = len[k]; -inf beyond the table
+    const bool live = c < n_states[g];
+    for (int k = threadIdx.x; k < SMM_BAND_ROW; k += blockDim.x)
+        dst[k] = (live && k >= 1 && k - 1 < k_rows) ? src[(size_t)(k - 1) * cm] : SMM_NEG_INF;
+    if (threadIdx.x <= SMM_BAND_N) {
+        const int m = threadIdx.x;
+        const int k0 = m ? SMM_BAND_LO + SMM_BAND_DELAY * m : 17, k1 = m ? 127 + SMM_BAND_DELAY * m : 158;
+        double v = m ? SMM_NEG_INF : __builtin_huge_val();
+        for (int k = k0; k <= k1 && k < k_rows; ++k) {
+            const double x = src[(size_t)k * cm];
+            v = m ? fmax(v, x) : fmin(v, x);
+        }
+        if (!live) v = SMM_NEG_INF;
+        band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + m] = v;
+    }
+}
+
+void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, int n_groups, int cm,
+                            int k_rows, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smm_band_tables_kernel, dim3(n_groups * cm), dim3(256), 0, stream, len, n_states, len_t, band_tab, cm, k_rows);
+}
+
 // ------------------------------------------------------------------------------------------------ dispatch
 #include <cstdlib>
 #include "../../include/smmdp.h"
@@ -1076,6 +1340,24 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
     return 1;
 }
 
+// BAND mode (the host asks for it with flags bit 7): 8 waves, up to 21 states with 3 per pusher wave, up to 28 with 4
+static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
+{
+    const dim3 grid(a.b), block(512);
+#ifdef SMM_DEV_BAND_ONE   // development builds: one instantiation
+    (void)c_need;
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    return SMM_OK;
+#else
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 16, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else return SMM_ERR_UNSUPPORTED;
+    return SMM_OK;
+#endif
+}
+
 template <int R>
 static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
@@ -1087,6 +1369,9 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     int nw = 8;
     if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
     if (nw != 4 && nw != 8 && nw != 16) nw = 8;
+    if constexpr (R == 16) {
+        if (a.flags & 128) return launch_band(a, c_need, stream);
+    }
     if constexpr (R == 16) {
         // 22..32 states, every such video in a gang (a.flags bit 2; 24..32: a triple): the 8-wave kernel, whose gang leaders
         // hold 35 short-range states and whose single workgroups only ever see <= 21
@@ -1132,6 +1417,9 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 // unless its gang's failure word is set.  1024-slot rings only (gangs exist for nothing else).
 void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t stream)
 {
+#ifdef SMM_DEV_BAND_ONLY
+    (void)a0; (void)c_need; (void)stream;
+#else
     SmmDpArgs a = a0;
     a.flags = (a0.flags & ~4) | 16;
     const dim3 grid(a0.n_pairs);
@@ -1143,10 +1431,15 @@ void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t st
     if (c_need > 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
     if (c_need > 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
     else if (c_need > 23) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 12, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
+#endif
 }
 
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)
 {
+#ifdef SMM_DEV_BAND_ONLY   // development builds: instantiate the BAND kernels only (quick compile-measure cycles)
+    (void)r;
+    return launch_band(a, c_need, stream);
+#else
     // SMM_DEV_R (development builds only): instantiate one ring size, for quick compile-measure cycles
 #ifndef SMM_DEV_R
 #define SMM_DEV_R 0
@@ -1162,4 +1455,5 @@ int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream
     }
 #undef SMM_CASE_R
     return SMM_ERR_UNSUPPORTED;
+#endif
 }

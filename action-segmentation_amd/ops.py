@@ -337,7 +337,7 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 12].view(torch.int32)      # [error, gangs timed out, gangs repaired]
+    return ws[off:off + 16].view(torch.int32)      # [error, gangs timed out, gangs repaired, band-blocks evaluated]
 
 
 def _err_copy(batch, ws):
@@ -360,7 +360,8 @@ gang_timeouts_repaired = 0     # how often a decode had gangs repaired by the re
 
 
 def error_words(batch, out=None, ws=None):
-    """[error word, gangs that timed out, gangs repaired by the recovery launch] of a decode (synchronises)."""
+    """[error word, gangs that timed out, gangs repaired by the recovery launch, delayed band-blocks evaluated (a
+    diagnostic of the Viterbi kernel's BAND mode: smm_viterbi.hip)] of a decode (synchronises)."""
     if out is not None and out.get('_err') is not None:
         return [int(v) for v in out['_err'].tolist()]
     if ws is None:
@@ -374,7 +375,7 @@ def check_decoded(batch, out=None):
     up waiting for its partner workgroup -- the outputs are invalid (the library relaunches such a batch without
     gangs by itself, so this only surfaces when that was switched off)."""
     global gang_timeouts_repaired
-    flag, timed_out, repaired = error_words(batch, out)
+    flag, timed_out, repaired = error_words(batch, out)[:3]
     gang_timeouts_repaired += repaired
     if timed_out > repaired:
         raise _lib.SmmError("libsmmdp: %d gang(s) of workgroups timed out waiting for a partner and %d were repaired by "

@@ -219,7 +219,7 @@ def cpu_factored(pc, model, gpu_labels=None, budget_s=12.0):
     from oracle import factored as F
     t = pc.tables
     checked = mismatches = vids_checked = 0
-    cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    cores = F.set_threads(F.host_cores())
     frames, dt, n_vid, n_task = 0, 0.0, 0, 0
     by_group = {}
     for i in range(pc.n_videos):
@@ -527,8 +527,13 @@ def logz_cpu_baseline(pc, budget_s=10.0):
     torch.cuda.synchronize()
     z_gpu = z_dev.cpu().numpy()
     g_gpu = {k: v.cpu().numpy() for k, v in g_dev.items()}
-    z_rel, g_abs, n_checked = 0.0, 0.0, 0
-    cores = F.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    z_rel, g_abs, g_tol, n_checked = 0.0, 0.0, 0.0, 0
+
+    def cmp(got, ref):
+        """max |got - ref| and max of |got - ref| / (2e-5 + 2e-5 |ref|) (<= 1: inside the tests' rtol = atol = 2e-5)"""
+        err = np.abs(got - ref)
+        return float(err.max()), float((err / (2e-5 + 2e-5 * np.abs(ref))).max())
+    cores = F.set_threads(F.host_cores())
     by_group = {}
     for i in range(pc.n_videos):
         by_group.setdefault(pc.group[i], []).append(i)
@@ -555,13 +560,14 @@ def logz_cpu_baseline(pc, budget_s=10.0):
         # parity (outside the CPU timing): one group = one task here, so the twin's table gradients of this call are the
         # GPU's rows of group g
         z_rel = max(z_rel, float(np.max(np.abs(z_gpu[vids] - z_ref) / np.abs(z_ref))))
-        for j, i in enumerate(vids):
-            n, o = pc.lengths[i], pc.frame_offset[i]
-            g_abs = max(g_abs, float(np.max(np.abs(g_gpu['elp'][o:o + n, :c] - g_ref['elp'][j, :n]))))
+        pairs = [(g_gpu['elp'][pc.frame_offset[i]:pc.frame_offset[i] + pc.lengths[i], :c], g_ref['elp'][j, :pc.lengths[i]])
+                 for j, i in enumerate(vids)]
         if sum(1 for q in range(pc.n_videos) if pc.group[q] == g) == len(vids):
-            g_abs = max(g_abs, float(np.max(np.abs(g_gpu['trans'][g, :c, :c] - g_ref['trans']))),
-                        float(np.max(np.abs(g_gpu['init'][g, :c] - g_ref['init']))),
-                        float(np.max(np.abs(g_gpu['len'][g, :kp, :c] - g_ref['len']))))
+            pairs += [(g_gpu['trans'][g, :c, :c], g_ref['trans']), (g_gpu['init'][g, :c], g_ref['init']),
+                      (g_gpu['len'][g, :kp, :c], g_ref['len'])]
+        for got, ref in pairs:
+            ea, et = cmp(got, ref)
+            g_abs, g_tol = max(g_abs, ea), max(g_tol, et)
         n_checked += len(vids)
         frames += sum(pc.lengths[i] for i in vids)
         n_vid += len(vids)
@@ -570,7 +576,9 @@ def logz_cpu_baseline(pc, budget_s=10.0):
     res = {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d videos, oracle/smm_oracle.c log-partition forward + exact backward, OpenMP over the videos of a "
                      "task (%d host threads), %.1f s" % (n_vid, cores, dt)}
-    return res, {"logz_videos_checked": n_checked, "logz_max_rel": z_rel, "grad_max_abs": g_abs}
+    return res, {"logz_videos_checked": n_checked, "logz_max_rel": z_rel, "grad_max_abs": g_abs,
+                 "grad_max_err_over_tol": g_tol,
+                 "grad_tolerance": "|got - ref| <= 2e-5 + 2e-5 |ref| (the tests' rtol = atol; expected transition counts reach 1e2..1e3)"}
 
 
 def pmc_traffic(workload):
@@ -614,6 +622,7 @@ def main():
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(a, argv))                      # before any GPU call in this process
     torch.set_num_threads(min(8, os.cpu_count() or 1))   # host-side torch ops are tiny: a 256-thread pool only adds latency
+    os.environ.setdefault('OMP_NUM_THREADS', '16')          # (any OpenMP runtime loaded later: not one spinning thread per visible CPU)
     rank, world, local, backend = dist_setup(a)
     from action_segmentation_amd import distributed as D
     if a.dry_run:
@@ -727,6 +736,11 @@ def main():
             if head is strong and strong.get("roofline_rank0"):
                 res["roofline_weak_leg"] = res["roofline"]
                 res["roofline"] = strong["roofline_rank0"]
+        # (before any CPU-baseline leg: the oracle's OpenMP pool -- one spinning thread per host core -- and torch's own
+        # intra-op pool would fight over the cores, and predict()'s host work would be timed under that contention:
+        # round 2 reported 4 s for a 25 ms call this way)
+        if world == 1 and not a.no_predict_e2e:
+            res["predict_end_to_end"] = predict_end_to_end(model, data)
         parity = {"frames_checked": 0, "label_mismatches": None, "logz_max_rel": None, "grad_max_abs": None,
                   "what": "the C twin (oracle/smm_oracle.c) against the GPU on this workload, checker side only: frame "
                           "labels of the TIMED decode for every video the cpu_factored leg covered; cfg4: logZ and the "
@@ -739,8 +753,6 @@ def main():
                     parity.update(zp)
                 except Exception as e:
                     res["logz_fwd_bwd"]["cpu_baseline"] = {"error": str(e)}
-        if world == 1 and not a.no_predict_e2e:
-            res["predict_end_to_end"] = predict_end_to_end(model, data)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(data, model, pc)
             try:

@@ -22,11 +22,40 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_SO)
+        _lib.smm_oracle_set_threads(host_cores())      # (not OpenMP's default of one spinning thread per visible CPU)
     return _lib
 
 
+def host_cores():
+    """CPU cores this process may really use: the cgroup's CFS quota when there is one (a container that sees 256
+    logical CPUs but is entitled to 16 gets THROTTLED for the rest of every 100 ms period once spinning OpenMP threads
+    have burnt the quota -- stalls of ~90 ms in whatever runs next), else the affinity mask.  SMM_HOST_CORES overrides."""
+    env = os.environ.get('SMM_HOST_CORES')
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]             # cgroup v2: "max 100000" or "1600000 100000"
+        if q != 'max':
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())    # cgroup v1
+            p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return n
+
+
 def set_threads(n=0):
-    """OpenMP threads of the batch loops (n <= 0: leave as is).  Returns the number in use."""
+    """OpenMP threads of the batch loops (n <= 0: as many as host_cores()).  Returns the number in use."""
+    if n <= 0:
+        n = host_cores()
     return int(lib().smm_oracle_set_threads(int(n)))
 
 

@@ -193,3 +193,73 @@ int smm_band_probe(const double *elp, int t, int c, const double *trans, const d
     free(cum); free(h); free(gam); free(hmax); free(lmax);
     return 0;
 }
+
+/*
+ * Third probe: the banded push AS BUILT (smm_viterbi.hip, BAND mode).  Band 0 = lengths 9..127, always evaluated.
+ * Band m = 1..8 covers lengths 16+112m .. 127+112m with sources delayed by 112m; tests per group of `grp` sources:
+ *   skip (state c, band m, undelayed group g)  iff  hmax[g - 112m/grp] + lenmax[m]  <=  hmax[g-1] + min_{17<=k<=grp+142} len[k]
+ * out[0] = band-groups with sources (m >= 1), out[1] = evaluated, out[2] = activation edges (inactive -> active),
+ * out[3] = cells of the lattice, out[4] = cells evaluated (bands) + band 0 + chain lengths.
+ */
+int smm_band_probe2(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                    int grp, double *out)
+{
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    const int ng = t / grp + 2;
+    double *hmax = (double *)malloc(sizeof(double) * (size_t)ng * c);
+    if (!cum || !h || !gam || !hmax) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        out[3] += (double)kmax * c;
+        out[4] += (double)(kmax < 127 ? kmax : 127) * c;
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    for (int g = 0; g < ng; ++g)
+        for (int j = 0; j < c; ++j) {
+            double m = -INFINITY;
+            for (int s = g * grp; s < g * grp + grp && s < t; ++s) m = dmax(m, h[(size_t)s * c + j]);
+            hmax[(size_t)g * c + j] = m;
+        }
+    const int reach = grp + grp - 1 + 127;        /* n - witness <= grp + (grp - 1) + 127 */
+    for (int j = 0; j < c; ++j) {
+        double lmin = INFINITY;
+        for (int k = 17; k <= reach && k <= kp - 1; ++k) lmin = dmin(lmin, len[(size_t)k * c + j]);
+        if (reach > kp - 1) lmin = -INFINITY;
+        for (int m = 1; m <= 8; ++m) {
+            double lm = -INFINITY;
+            for (int k = 16 + 112 * m; k <= 127 + 112 * m && k <= kp - 1; ++k) lm = dmax(lm, len[(size_t)k * c + j]);
+            int was = 0;
+            for (int g = 0; g * grp < t; ++g) {
+                const int s0 = g * grp - 112 * m;         /* first source of the band's group (may straddle two aligned groups) */
+                if (s0 + grp - 1 < 0) continue;
+                const int ga = (s0 < 0 ? 0 : s0) / grp, gb = (s0 + grp - 1) / grp;
+                double hm = dmax(hmax[(size_t)ga * c + j], hmax[(size_t)gb * c + j]);
+                const double lb = (g >= 1) ? hmax[(size_t)(g - 1) * c + j] + lmin : -INFINITY;
+                out[0] += 1.0;
+                const int act = hm + lm > lb;
+                if (act) {
+                    out[1] += 1.0;
+                    out[4] += 112.0 * grp;
+                    if (!was) out[2] += 1.0;
+                }
+                was = act;
+            }
+        }
+    }
+    free(cum); free(h); free(gam); free(hmax);
+    return 0;
+}

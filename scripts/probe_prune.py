@@ -50,6 +50,17 @@ def band_probe(elp, trans, init, len_scores, bw):
     return out
 
 
+def band_probe2(elp, trans, init, len_scores, grp):
+    t, c = elp.shape
+    kp = min(len_scores.shape[0], t)
+    out = np.zeros(8)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (elp, trans, init, len_scores[:kp])]
+    rc = lib.smm_band_probe2(arrs[0].ctypes.data_as(P), t, c, arrs[1].ctypes.data_as(P), arrs[2].ctypes.data_as(P),
+                             arrs[3].ctypes.data_as(P), kp, grp, out.ctypes.data_as(P))
+    assert rc == 0
+    return out
+
+
 def main():
     per_task = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg3'
@@ -65,6 +76,9 @@ def main():
     tot = {d: np.zeros(8) for d in designs}
     bands = [64, 128, 256]
     btot = {b: np.zeros(8) for b in bands}
+    grps = [16, 64]
+    b2tot = {g: np.zeros(8) for g in grps}
+    frames = 0
     t0 = time.time()
     for task, names in sorted(data._videos_by_task.items()):
         vc = torch.tensor(data.corpus._indices_by_task[task])
@@ -77,6 +91,9 @@ def main():
                 tot[d] += probe(elp, tab['trans'].numpy(), tab['init'].numpy(), tab['len'].numpy(), *d)
             for bw in bands:
                 btot[bw] += band_probe(elp, tab['trans'].numpy(), tab['init'].numpy(), tab['len'].numpy(), bw)
+            for gp in grps:
+                b2tot[gp] += band_probe2(elp, tab['trans'].numpy(), tab['init'].numpy(), tab['len'].numpy(), gp)
+            frames += elp.shape[0]
             print('# %s %s T=%d C=%d  (%.0f s)' % (task, name, elp.shape[0], elp.shape[1], time.time() - t0), flush=True)
     print("workload %s seed 2 (CPU draw), %d videos per task, K = %d" % (wl, per_task, cfg['max_k']))
     print("%-28s %10s %10s %10s %12s %12s" % ("long range from / target block / length block", "blocks", "survive",
@@ -92,6 +109,12 @@ def main():
     for bw in bands:
         o = btot[bw]
         print("bw=%-9d %12d %9.1f%% %11.1f%% %13.1f%%" % (bw, o[0], 100 * o[1] / o[0], 100 * o[2] / o[0], 100 * o[4] / o[3]))
+    print()
+    print("banded push as built: band 0 = lengths 9..127 (always), bands 1..8 = 16+112m..127+112m, sources delayed by 112m")
+    print("%-12s %14s %10s %18s %14s" % ("test group", "band-groups>=1", "evaluated", "activations/kframe", "lattice cells"))
+    for gp in grps:
+        o = b2tot[gp]
+        print("grp=%-8d %14d %9.2f%% %18.2f %13.1f%%" % (gp, o[0], 100 * o[1] / o[0], 1e3 * o[2] / frames, 100 * o[4] / o[3]))
 
 
 if __name__ == '__main__':

@@ -562,6 +562,105 @@ def test_viterbi_24_to_32_states_ride_in_triples(c, monkeypatch):
         np.testing.assert_array_equal(got[key], slow[key].cpu().numpy())
 
 
+# ---------------------------------------------------------------------------------------------------- BAND mode
+def structured_problem(seed, lengths, c, k, margin=18.0, rate=(20, 400)):
+    """A lattice with CrossTask-like structure: HSMM-sampled segments, the true state's emission beats the others by
+    `margin` per frame on average, Poisson length tables -- the regime in which the Viterbi kernel's BAND mode switches
+    nearly every delayed band off."""
+    from scipy.special import gammaln
+    g = np.random.default_rng(seed)
+    b, tmax = len(lengths), int(max(lengths))
+    rates = g.uniform(rate[0], rate[1], size=c)
+    elp = np.zeros((b, tmax, c))
+    for i, t in enumerate(lengths):
+        lab, cur, tot = [], int(g.integers(0, c)), 0
+        while tot < t:
+            ln = int(np.clip(g.poisson(rates[cur]), 1, k - 1))
+            lab.append(np.full(ln, cur)); tot += ln; cur = (cur + 1) % c
+        lab = np.concatenate(lab)[:t]
+        e = -290.0 - margin + 6.0 * g.standard_normal((t, c))
+        e[np.arange(t), lab] += margin
+        elp[i, :t] = e
+    kk = np.arange(k)[:, None]
+    lens = kk * np.log(rates) - rates - gammaln(kk + 1)
+    trans = np.log(g.dirichlet(np.ones(c) * 0.5, size=c).T + 1e-3)
+    trans -= np.log(np.exp(trans).sum(0, keepdims=True))
+    init = np.log(g.dirichlet(np.ones(c)))
+    return dict(elp=elp, lengths=np.asarray(lengths), trans=trans, init=init, lens=lens, endpen=None, c=c, c_max=c, k=k)
+
+
+BAND_SHAPES = [
+    # lengths, states, K: 3 states per pusher wave (<= 21), 4 (22..28); K = 1024 and the clipped tables in between;
+    # lengths that end inside a block / a group of 16 sources / just past a band boundary
+    ([1500, 700], 5, 1024), ([2300, 1029], 16, 1024), ([3000], 21, 1024), ([2100, 2099, 130], 23, 1024),
+    ([1800, 600], 28, 900), ([1200, 1100, 515], 13, 600), ([4100], 11, 1024), ([1153, 1041], 22, 1024),
+]
+
+
+@pytest.mark.parametrize('shape', BAND_SHAPES)
+@pytest.mark.parametrize('kind', ['random', 'structured', 'integer', 'flat'])
+def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
+    """K > 512, up to 28 states: the BAND kernel (128-slot rings shared by nine length bands, delayed bands skipped by an
+    exact bound test) against the C twin AND against the 1024-slot ring kernels (SMM_BAND=0), bit for bit -- on random
+    lattices, on CrossTask-like lattices (nearly every delayed band is skipped), on integer lattices full of exact ties
+    (a skipped candidate may TIE with the maximum, never beat it) and on FLAT lattices (every state emits the same, so no
+    state ever falls behind and hardly a band can be skipped: the worst case of the test's cost, not of its result)."""
+    lengths, c, k = shape
+    ops = _ops()
+    monkeypatch.delenv('SMM_PAIRS', raising=False)
+    monkeypatch.delenv('SMM_BAND', raising=False)
+    if kind == 'structured':
+        p = structured_problem(hash((tuple(lengths), c)) % 1000, lengths, c, k)
+    else:
+        p = make_problem(hash((tuple(lengths), c)) % 1000 + 5, len(lengths), max(lengths), c, k, integer=(kind == 'integer'))
+        p['lengths'] = np.asarray(lengths)
+        if kind == 'flat':
+            g = np.random.default_rng(17)
+            p['elp'] = p['elp'][:, :, :1] + 1e-3 * g.standard_normal(p['elp'].shape)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    assert out['_err'][0] == 0
+    # the diagnostic counter: delayed band-blocks evaluated, of (frames / 4) x states x (bands with a valid length)
+    kp = min(k, max(lengths))
+    bands = sum(1 for m in range(1, 9) if 16 + 112 * m <= kp - 1)
+    possible = sum(-(-int(t) // 4) for t in lengths) * c * bands
+    frac = out['_err'][3] / possible
+    if kind == 'structured':
+        assert frac < 0.12, frac                       # (long videos: ~1-3 %; the first 1000 frames of a video cost the most)
+    elif kind == 'flat':
+        assert frac > 0.5, frac
+    monkeypatch.setenv('SMM_BAND', '0')
+    ring = run_gpu(p)
+    assert ring['_err'][3] == 0
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], ring[key])
+
+
+def test_viterbi_band_mode_no_eos_and_end_penalties(monkeypatch):
+    """The two closing variants on the BAND kernel: add_eos=False, and per-video allowed ends."""
+    ops = _ops()
+    monkeypatch.delenv('SMM_PAIRS', raising=False)
+    p = structured_problem(7, [2200, 1300], 19, 1024)
+    dev = torch.device('cuda:0')
+    b, tmax, c = p['elp'].shape
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    batch = ops.Batch(p['lengths'], [c], 1024, c_max=c, t_max=tmax, total_frames=b * tmax, no_eos=True)
+    out = ops.viterbi(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
+    torch.cuda.synchronize()
+    ops.check_decoded(batch, out)
+    spans, v = F.viterbi(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], None, no_eos=True)
+    np.testing.assert_array_equal(out['best'].cpu().numpy(), v)
+    np.testing.assert_array_equal(out['spans'].cpu().numpy(), spans)
+    g = np.random.default_rng(3)
+    p['endpen'] = np.full((b, c), -1e9)
+    for i in range(b):
+        p['endpen'][i, g.integers(0, c, size=2)] = 0.0
+    got = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, got, spans, v)
+
+
 # ---------------------------------------------------------------------------------------------------- gang recovery
 @pytest.mark.parametrize('c', [13, 23, 26, 31])
 def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):

@@ -11,7 +11,7 @@
 #define SMM_BAND_LO 16
 #define SMM_BAND_N 8          // delayed bands
 #define SMM_BAND_ROW 1026      // doubles per state of the shifted state-major length table (row[k + 1] = len[k], k <= 1024)
-#define SMM_BAND_TAB 16       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 17..158, [m] max len over band m
+#define SMM_BAND_TAB 16       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 33..174, [m] max len over band m
 
 // One entry per video, built on the host by smm_plan() and staged into the workspace.
 struct SmmVideo {

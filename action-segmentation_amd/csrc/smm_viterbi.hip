@@ -407,19 +407,23 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 // The accumulators A are shared by the bands of a state (all of them aim at the same 128 targets): 2 registers per
 // state for A and 2 per band for its length ring, 36 per state instead of the 64 of a 1024-slot ring.
 //
-// Skipping.  Per state and group of 16 sources (4 hand-over blocks) the owner wave keeps hm[g] = max h over the group
-// (LDS ring of 64 groups).  Before the sources of group G are pushed, band m is switched off for the group when
-//     hm[G - 7m] + max_{k in band m} len[k]   <=   hm[G - 1] + min_{17 <= k <= 158} len[k].
+// Skipping.  Per state and group of 16 sources (4 hand-over blocks) the mover wave keeps hm[g] = max h over the group
+// (LDS ring of 64 groups, lane = state).  A block before the sources of group G are pushed, band m is switched off for
+// the group when
+//     hm[G - 7m] + max_{k in band m} len[k]   <=   hm[G - 2] + min_{33 <= k <= 174} len[k].
 // Left: an upper bound of every candidate the band would push (its 16 sources are group G - 7m).  Right: for every
-// target n the band can reach, n in [16G + 16, 16G + 142], the best source s* of group G - 1 is a real candidate of
-// A[n] with 17 <= n - s* <= 158, so the right side is a lower bound of the final A[n] (all of it needs kp - 1 >= 158;
-// otherwise the bound is -inf and nothing is skipped).  max is exact and rounding is monotone, so a skipped candidate
-// can never be the only one that attains a maximum: not a bit of the result changes, whatever the inputs are.  What
-// changes is the work: on CrossTask-shaped data 99 % of the delayed band-groups are skipped (14 % of the lattice cells
-// are evaluated, profiles/round3_prune_survival.txt), so the frame time is the chain wave's for any state count.
-// A band that comes back re-reads its length ring from the state-major length table (len_t); the h rows of the delayed
-// sources come from the history the mover wave writes anyway (lane = (state, band), 4 positions each, fetched one block
-// ahead with sc1 loads and handed to the pushes with v_readlane).
+// target n the band can reach, n in [16G + 16, 16G + 142], the best source s* of group G - 2 (the newest group that is
+// complete when the decision is due) is a real candidate of A[n] with 33 <= n - s* <= 174, so the right side is a lower
+// bound of the final A[n] (all of it needs kp - 1 >= 174; otherwise the bound is -inf and nothing is skipped).  max is
+// exact and rounding is monotone; a skipped candidate may tie with a maximum, but then its witness attains it too and
+// is either evaluated (lengths <= 127 always are) or has a newer witness of its own: not a bit of the result changes,
+// whatever the inputs are.  What changes is the work: on CrossTask-shaped data ~99 % of the delayed band-groups are
+// skipped (14 % of the lattice cells are evaluated, profiles/round3_prune_survival.txt), so the frame time no longer
+// grows with K and hardly with the state count.
+// A band that is switched on reads its length ring from the state-major length table (len_t) at the phase of every
+// block -- no registers are kept for the delayed bands --; the h rows of the delayed sources come from the history the
+// mover wave writes anyway (lane = (state, band), 4 positions each, fetched one block ahead with sc1 loads and handed
+// to the pushes with v_readlane).
 // (SMM_BAND_DELAY = 112, SMM_BAND_LO = 16, SMM_BAND_N = 8 bands, SMM_BAND_TAB: smm_device.h)
 
 // Length ring of band m at push step t (a multiple of 4): slot p = 2 lane + r is at ring distance kr = (p + off) & 127,
@@ -447,7 +451,7 @@ __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double 
 //     lengths 1..2B+D-1 itself
 // PAIR 1: the first 3*a.n_pairs workgroups are gangs of leader / follower 0 / follower 1 (R = 16, 8 waves only; see
 //         PAIR mode above; follower 1 returns at once when the video needs one follower)
-//      2: BAND mode (above): one workgroup per video, 128-slot rings, SPW = states per pusher wave (3 or 4)
+//      2: BAND mode (above): one workgroup per video, 128-slot rings, SPW = states per state-owning pusher wave (3..5)
 template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
@@ -522,6 +526,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ __attribute__((aligned(16))) double sh_along[GANG ? 2 : 1][GANG ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ double sh_hm[BAND ? SMM_MAX_STATES_DEV : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
+    __shared__ uint32_t sh_act[2][BAND ? SMM_MAX_STATES_DEV : 1];             // band mode: bit m-1 = band m of the state is switched on
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
@@ -544,6 +549,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
             if (GANG) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[GANG ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
+        if (BAND) { sh_act[0][BAND ? c : 0] = 0; sh_act[1][BAND ? c : 0] = 0; }
         sh_gam[c] = SMM_NEG_INF;
         sh_gfin[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
@@ -832,31 +838,45 @@ smm_viterbi_kernel(SmmDpArgs a)
         // ============================================================================ pusher waves, BAND mode (see above)
         constexpr int SPS = SPW, RS = 2, NBD = SMM_BAND_N;
         static_assert(!BAND || SPS * NBD <= 64, "one lane per (state, band) of a pusher wave");
-        const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);   // states rank, rank + 7, ... (wave 4, the mover, owns the fewest)
+        // Wave 4 shares its SIMD with the chain wave: it only moves data (elp in, history out) and owns NO states -- every
+        // instruction it issues can cost the chain wave an issue slot, and the chain wave's time is the frame time.  The
+        // other six pushers own states rank, rank + 6, ...; waves (1,5), (2,6), (3,7) share a SIMD.
+        constexpr int NPS = NP - 1;
+        const int rank = (w == MW) ? (1 << 20) : ((w < MW) ? w - 1 : w - 2);  // (the mover: no state passes the c < C tests below)
         const double *lent = a.len_t + (size_t)g * cm * SMM_BAND_ROW;       // [c][k + 1]: a state's lengths are contiguous
         const double *btab = a.band_tab + (size_t)g * cm * SMM_BAND_TAB;
-        const bool bound_ok = kp - 1 >= 16 + 15 + 127;                       // the lower bound's witness needs lengths up to 158
+        const bool bound_ok = kp - 1 >= 32 + 15 + 127;                       // the lower bound's witness needs lengths up to 174
         double As[SPS][RS], L0[SPS][RS], hds[SPS];
-        double hmx[SPS];                                                     // max h over the sources of the current group
-        double lmx[SPS];                                                     // lane m: max len over band m  (lane 0: unused)
-        double lbm[SPS];                                                     // min len over 17..158 (uniform)
-        uint32_t act[SPS];                                                   // bit m: band m is switched on for the current group
+        uint32_t act[SPS];                                                   // bit m-1: band m is switched on for the current group
         uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
 #pragma unroll
         for (int js = 0; js < SPS; ++js) {
-            const int c = js * NP + rank;
+            const int c = js * NPS + rank;
             const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
             smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
             hds[js] = SMM_NEG_INF;
-            hmx[js] = SMM_NEG_INF;
             act[js] = 0;
-            const bool mine = c < C && lane >= 1 && lane <= NBD && SMM_BAND_LO + SMM_BAND_DELAY * lane <= kp - 1;
-            lmx[js] = mine ? btab[(size_t)c * SMM_BAND_TAB + lane] : SMM_NEG_INF;
-            lbm[js] = (c < C && bound_ok) ? btab[(size_t)c * SMM_BAND_TAB] : SMM_NEG_INF;
+        }
+        // The mover wave also keeps the books of the skip test, one lane per state: max h over every group of 16 sources
+        // (ring sh_hm), and -- a block before a group starts -- which bands are switched on for it (sh_act): lane
+        // 8 s + (m - 1) of pass p tests band m of state 8 p + s.  The witness of the lower bound is the group before the
+        // last one (G - 2: the last one is still being pushed when the decision is due), so the test reads
+        //     hm[G - 7m] + max_{band m} len  >  hm[G - 2] + min_{33 <= k <= 174} len      <=>  band m on for group G.
+        constexpr int NPASS = SMM_MAX_STATES_DEV / 8;
+        double hmx = SMM_NEG_INF, hdm = SMM_NEG_INF;                         // lane = state: running max, last row of the previous block
+        double lmx[NPASS], lbm[NPASS];
+        if (w == MW) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int c = 8 * p + (lane >> 3), m = (lane & 7) + 1;
+                const bool mine = c < C && SMM_BAND_LO + SMM_BAND_DELAY * m <= kp - 1;
+                lmx[p] = mine ? btab[(size_t)c * SMM_BAND_TAB + m] : SMM_NEG_INF;
+                lbm[p] = (c < C && bound_ok) ? btab[(size_t)c * SMM_BAND_TAB] : SMM_NEG_INF;
+            }
         }
         // lane q = 8 js + (m - 1) fetches the delayed sources of (state js, band m), one block ahead
         const int qjs = lane >> 3, qm = (lane & 7) + 1;
-        const int qc = qjs * NP + rank;
+        const int qc = qjs * NPS + rank;
         const double *qcol = hh + (size_t)((qjs < SPS && qc < C) ? qc : 0) * (T + 1);
         double hq[B];
 #pragma unroll
@@ -921,38 +941,62 @@ smm_viterbi_kernel(SmmDpArgs a)
                         store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
                         store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
                     }
+                    // the sources the pushers push in this block: positions (j-1)B .. jB-1, lane = state
+                    {
+                        const double *h_blk = &sh_h[(jj + 1) & 1][0][lane & (SMM_MAX_STATES_DEV - 1)];
+                        double gm = hdm;
+#pragma unroll
+                        for (int i = 0; i < B - 1; ++i) gm = smm_fmax(gm, h_blk[i * SMM_MAX_STATES_DEV]);
+                        hdm = h_blk[(B - 1) * SMM_MAX_STATES_DEV];
+                        hmx = smm_fmax(hmx, gm);
+                        if (jj == 0) {                                         // group j/4 - 1 is complete
+                            if (j >= 4 && lane < SMM_MAX_STATES_DEV) sh_hm[BAND ? lane : 0][BAND ? ((j / 4 - 1) & 63) : 0] = hmx;
+                            hmx = SMM_NEG_INF;
+                        }
+                        if (jj == UB - 1) {                                    // the next block ends with the switch to group G
+                            const int G = (j + 1) / 4;
+#pragma unroll
+                            for (int p = 0; p < NPASS; ++p) {
+                                if (8 * p >= C) break;
+                                const int c = 8 * p + (lane >> 3), m = (lane & 7) + 1;
+                                const int gi = G - 7 * m;
+                                const double hsrc = sh_hm[BAND ? c : 0][BAND ? (gi & 63) : 0];
+                                const double hwit = sh_hm[BAND ? c : 0][BAND ? ((G - 2) & 63) : 0];
+                                const bool on = c < C && gi >= 0 && (G < 2 || hsrc + lmx[p] > hwit + lbm[p]);
+                                const unsigned long long mask = __ballot(on);
+                                if (lane < 8) sh_act[G & 1][BAND ? 8 * p + lane : 0] = (uint32_t)(mask >> (8 * lane)) & 0xffu;
+                            }
+                        }
+                    }
                 }
                 // this block pushes sources (j-1)B .. jB-1 (push steps jB ..): band 0 from LDS, the bands that are switched
-                // on from the rows fetched during the previous block
+                // on from the rows fetched during the previous block.  (Reading the rows of all states first and
+                // interleaving the states' pushes step by step measured 3 % SLOWER: the wave is not bound by the latency
+                // of one state's chain.)
 #pragma unroll
                 for (int js = 0; js < SPS; ++js) {
-                    const int c = js * NP + rank;
+                    const int c = js * NPS + rank;
                     if (c >= C) break;
                     const double *h_blk = &sh_h[(jj + 1) & 1][0][c];
                     double hv[B];
 #pragma unroll
                     for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
                     smm_push<RS>(As[js], L0[js], hds[js], (jj * B) % RS);
-                    double gm = hds[js];
 #pragma unroll
-                    for (int i = 1; i < B; ++i) {
-                        smm_push<RS>(As[js], L0[js], hv[i - 1], (jj * B + i) % RS);
-                        gm = smm_fmax(gm, hv[i - 1]);
-                    }
+                    for (int i = 1; i < B; ++i) smm_push<RS>(As[js], L0[js], hv[i - 1], (jj * B + i) % RS);
                     hds[js] = hv[B - 1];
-                    hmx[js] = smm_fmax(hmx[js], gm);
                     if (act[js]) {
                         // the bands that are switched on (rarely any): their rings at this block's phase come from the table
                         const double *lrow = lent + (size_t)c * SMM_BAND_ROW;
                         const int off = (B + D - j * B) & 127;
                         uint32_t mm = act[js];
                         nact += __builtin_popcount(mm);
-                        int m = __builtin_ctz(mm);
+                        int m = __builtin_ctz(mm) + 1;
                         double Lm[RS];
                         smm_band_ring_load(Lm, lrow, off, m, kp, lane);
                         while (true) {
                             mm &= mm - 1;
-                            const int mn = mm ? __builtin_ctz(mm) : 0;
+                            const int mn = mm ? __builtin_ctz(mm) + 1 : 0;
                             double Ln[RS];
                             if (mn) smm_band_ring_load(Ln, lrow, off, mn, kp, lane);      // in flight while band m is pushed
                             const int q = js * 8 + m - 1;
@@ -976,28 +1020,19 @@ smm_viterbi_kernel(SmmDpArgs a)
                     }
                 }
                 if (jj == 0) {
-                    // the sources of group G - 1 = j/4 - 1 are through: decide the bands of group G
-                    const int G = j / 4;
+                    // the next block starts group G = j/4: the mover wave decided its bands a block ago
 #pragma unroll
                     for (int js = 0; js < SPS; ++js) {
-                        const int c = js * NP + rank;
+                        const int c = js * NPS + rank;
                         if (c >= C) break;
-                        const double hprev = hmx[js];
-                        if (G >= 1 && lane == 0) sh_hm[BAND ? c : 0][BAND ? ((G - 1) & 63) : 0] = hprev;
-                        hmx[js] = SMM_NEG_INF;
-                        const int gi = G - 7 * lane;                         // lane m: the band's sources are group G - 7m
-                        const double hsrc = sh_hm[BAND ? c : 0][BAND ? (gi & 63) : 0];
-                        const double ub = hsrc + lmx[js];
-                        const double lb = hprev + lbm[js];
-                        const bool on = lane >= 1 && lane <= NBD && gi >= 0 && ub > lb;
-                        act[js] = (uint32_t)__ballot(on);
+                        act[js] = sh_act[(j / 4) & 1][BAND ? c : 0];
                     }
                 }
                 // fetch the delayed sources of block j+1: positions jB - 112m .. + B-1 of (state, band) = lane
                 {
                     unsigned long long lanes = 0;
 #pragma unroll
-                    for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)((act[js] >> 1) & 0xffu) << (8 * js);
+                    for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)act[js] << (8 * js);
                     if (lanes) {                                  // (nearly always nothing is switched on: no loads at all)
                         const bool mine = (lanes >> lane) & 1ull;
                         const int s0 = j * B - SMM_BAND_DELAY * qm;
@@ -1279,7 +1314,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 
 // ------------------------------------------------------------------------------------------------ band tables
 // Per (parameter group, state): the state-major copy of the length table (a band that is switched back on reads its ring
-// from it, 128 consecutive lengths per wave instruction) and the bounds of the skip test: [0] min len over 17..158,
+// from it, 128 consecutive lengths per wave instruction) and the bounds of the skip test: [0] min len over 33..174,
 // [m] max len over band m = 16+112m .. 127+112m (clipped to the table; a video's own kp only makes the bound looser).
 __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len, const int32_t *n_states, double *len_t,
                                                               double *band_tab, int cm, int k_rows)
@@ -1292,7 +1327,7 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
         dst[k] = (live && k >= 1 && k - 1 < k_rows) ? src[(size_t)(k - 1) * cm] : SMM_NEG_INF;
     if (threadIdx.x <= SMM_BAND_N) {
         const int m = threadIdx.x;
-        const int k0 = m ? SMM_BAND_LO + SMM_BAND_DELAY * m : 17, k1 = m ? 127 + SMM_BAND_DELAY * m : 158;
+        const int k0 = m ? SMM_BAND_LO + SMM_BAND_DELAY * m : 33, k1 = m ? 127 + SMM_BAND_DELAY * m : 174;
         double v = m ? SMM_NEG_INF : __builtin_huge_val();
         for (int k = k0; k <= k1 && k < k_rows; ++k) {
             const double x = src[(size_t)k * cm];
@@ -1343,16 +1378,18 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
 // BAND mode (the host asks for it with flags bit 7): 8 waves, up to 21 states with 3 per pusher wave, up to 28 with 4
 static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
+    // six state-owning pusher waves: up to 18 states with 3 each, 24 with 4, 28 (30) with 5; HF = source states per lane
+    // group of the chain wave (4: four groups of 16 lanes)
     const dim3 grid(a.b), block(512);
 #ifdef SMM_DEV_BAND_ONE   // development builds: one instantiation
     (void)c_need;
-    hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
     return SMM_OK;
 #else
     if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 4, 1, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
     else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 16, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 4, 1, 2>), grid, block, 0, stream, a);
     else return SMM_ERR_UNSUPPORTED;
     return SMM_OK;
 #endif

@@ -27,9 +27,8 @@ def run(b, T, C, K):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.viterbi(batch, elp, trans, init, lens); e1.record(); torch.cuda.synchronize()
     ws = list(ops._ws_cache.values())[0]
-    # error block offset: mirrors make_plan() in smm_api.hip
-    al = lambda x: (x + 255) // 256 * 256
-    o_err = al(32 * b) + al(4 * b) + al(4)
+    import ctypes
+    o_err = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
     pp = ws[o_err: o_err + 512].cpu().numpy().view(np.uint64).astype(np.float64)
     nblk = pp[7]
     print(f"b={b} T={T} C={C} K={K}: {e0.elapsed_time(e1):.3f} ms, {nblk:.0f} blocks; cycles per block (busy / in barrier) by wave:")

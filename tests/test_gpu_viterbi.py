@@ -615,8 +615,14 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         p = make_problem(hash((tuple(lengths), c)) % 1000 + 5, len(lengths), max(lengths), c, k, integer=(kind == 'integer'))
         p['lengths'] = np.asarray(lengths)
         if kind == 'flat':
+            # every state emits the same and every table is a proper log-probability (<= 0): no path ever gains on another,
+            # h = beta - cumE only sinks with time, so an OLD source is never worse than a new one
             g = np.random.default_rng(17)
             p['elp'] = p['elp'][:, :, :1] + 1e-3 * g.standard_normal(p['elp'].shape)
+            p['lens'] = -np.log(k) - 0.05 * g.random(p['lens'].shape)
+            tr = g.standard_normal(p['trans'].shape)
+            p['trans'] = tr - np.log(np.exp(tr).sum(0, keepdims=True))
+            p['init'] = np.full_like(p['init'], -np.log(c))
     out = run_gpu(p)
     spans, v = run_oracle(p)
     check(p, out, spans, v)

@@ -47,11 +47,35 @@ class LabelSpace:
         return cls(by_task, corpus._background_indices, getattr(corpus, 'n_classes', None))
 
     def local_table(self, device):
-        tab = torch.full((len(self.tasks), self.n_labels), -1, dtype=torch.int32)
-        for g, t in enumerate(self.tasks):
-            for l, i in enumerate(self.ids[t]):
-                tab[g, i] = l
-        return tab.to(device)
+        """global id -> local id per task (int32 [tasks, n_labels], -1 = not of the task), built once per device"""
+        cache = self.__dict__.setdefault('_local_tables', {})
+        tab = cache.get(str(device))
+        if tab is None:
+            host = np.full((len(self.tasks), self.n_labels), -1, dtype=np.int32)
+            for g, t in enumerate(self.tasks):
+                host[g, self.ids[t]] = np.arange(len(self.ids[t]), dtype=np.int32)
+            tab = cache[str(device)] = torch.from_numpy(host).to(device)
+        return tab
+
+    def device_background(self, device):
+        cache = self.__dict__.setdefault('_gbg_dev', {})
+        t = cache.get(str(device))
+        if t is None:
+            t = cache[str(device)] = torch.from_numpy(self.static_tables()[1]).to(device)
+        return t
+
+    def static_tables(self):
+        """host tables that do not depend on the predictions: per task the number of labels and which local ids are
+        background (uint8 [tasks, c_max + 1])"""
+        st = self.__dict__.get('_static')
+        if st is None:
+            w = self.c_max + 1
+            n = np.array([len(self.ids[t]) for t in self.tasks], dtype=np.int64)
+            gbg = np.zeros((len(self.tasks), w), dtype=np.uint8)
+            for g, t in enumerate(self.tasks):
+                gbg[g, :n[g]] = [i in self.background for i in self.ids[t]]
+            st = self.__dict__['_static'] = (n, gbg)
+        return st
 
 
 def _pad_labels(present, size):
@@ -111,6 +135,58 @@ def _kernel_tables(space, g2c_by_task, device):
                 cluster[g, l] = invented[c]
     to = lambda a: torch.from_numpy(a).to(device)
     return to(cluster), to(gbg), to(pbg)
+
+
+def _finalise_identity(conf, ids, gbg, S, lev_sum, normed_sum, maxseg_sum, n_videos, want_extras):
+    """``_finalise`` for the identity assignment (every ground-truth label that occurs is its own cluster), vectorised:
+    the supervised evaluation of a whole corpus is 18 of these per call."""
+    row, col, hit = conf.sum(1), conf.sum(0), np.diagonal(conf).astype(np.float64)
+    occ = row > 0
+    nb = occ & (gbg == 0)
+    f = lambda key: float(S[CN[key]])
+    frames = f('frames')
+    stat = {}
+    stat['mof'] = [float(hit[occ].sum()), frames]
+    stat['mof_bg'] = [float(hit[occ].sum()), float(row[occ].sum())]
+    stat['mof_non_bg'] = [float(hit[nb].sum()), float(row[nb].sum())]
+    stat['precision'] = [f('tp'), frames]
+    stat['recall'] = [f('tp'), f('gt_labels')]
+    ratio = lambda p: p[0] / p[1] if p[1] else 0.0
+    p_, r_ = ratio(stat['precision']), ratio(stat['recall'])
+    stat['f1'] = [2 * p_ * r_ / (p_ + r_) if p_ + r_ > 0 else 0.0, 1.0]
+    stat['precision_non_bg'] = [f('tp_non_bg'), f('frames_non_bg')]
+    stat['recall_non_bg'] = [f('tp_non_bg'), f('gt_labels_non_bg')]
+    pn, rn = ratio(stat['precision_non_bg']), ratio(stat['recall_non_bg'])
+    stat['f1_non_bg'] = [2 * pn * rn / (pn + rn) if pn + rn > 0 else 0.0, 1.0]
+    stat['true_background'] = [f('true_bg'), frames]
+    stat['pred_background'] = [f('pred_bg'), frames]
+    stat['iou_multi_non_bg'] = [f('iou_num'), f('iou_den')]
+    stat['multiple_gt_labels'] = [f('multi'), frames]
+    union = (row + col - np.diagonal(conf))[occ]
+    per_class = float(sum(h / u for h, u in zip(hit[occ].tolist(), union.tolist())))    # (the reference's summation order)
+    n_occ = int(occ.sum())
+    stat['iou'] = [per_class, n_occ]
+    stat['iou_bg'] = [per_class, n_occ]
+    nv = float(n_videos)
+    stat['mean_levenshtein'] = [lev_sum / nv, 1.0]
+    stat['mean_max_segments'] = [maxseg_sum / nv, 1.0]
+    stat['total_levenshtein'] = [float(lev_sum), 1.0]
+    stat['num_videos'] = [nv, 1.0]
+    stat['mean_normed_levenshtein'] = [normed_sum / nv, 1.0]
+    stat['predicted_segments_per_video'] = [f('segs_pred'), nv]
+    stat['predicted_segments_non_bg_per_video'] = [f('segs_pred_non_bg'), nv]
+    stat['single_step_recall'] = [f('draw_hit'), f('steps')]
+    stat['step_recall_non_bg'] = [f('draw_hit_non_bg'), f('steps_non_bg')]
+    stat['center_step_recall'] = [f('mid_hit'), f('steps')]
+    stat['center_step_recall_non_bg'] = [f('mid_hit_non_bg'), f('steps_non_bg')]
+    stat['predicted_label_types_per_video'] = [f('types'), nv]
+    stat['predicted_label_types_non_bg_per_video'] = [f('types_non_bg'), nv]
+    if not want_extras:
+        return stat, None
+    idx = np.flatnonzero(occ)
+    return stat, dict(classes_mof={ids[l]: [float(hit[l]), int(row[l])] for l in idx},
+                      classes_iou={ids[l]: [float(hit[l]), int(row[l] + col[l] - conf[l, l])] for l in idx},
+                      gt2cluster={ids[l]: [ids[l]] for l in idx})
 
 
 def _finalise(conf, ids, g2c, background, S, lev_sum, normed_sum, maxseg_sum, n_videos):
@@ -199,60 +275,113 @@ def evaluate_labels(pred, gt, lengths, frame_offset, tasks, space, optimal_assig
         conf_d = ops.eval_confusion(eb, pred, gt2, local_of)
     if reduce is not None:
         conf_d = reduce(conf_d)
+    ng = len(space.tasks)
+    n_ids, gbg_h = space.static_tables()
+    per_video_d = None
+    if not optimal_assignment and not empty:
+        # identity assignment: every ground-truth label that occurs is its own cluster.  The cluster tables come from
+        # the confusion table ON THE DEVICE, so the second kernel follows the first without a trip to the host.
+        w = space.c_max + 1
+        occ_d = conf_d[:, :w, :w].sum(2) > 0
+        occ_d[:, -1] = False
+        gbg_d = space.device_background(pred.device)
+        cluster_d = torch.where(occ_d, torch.arange(w, dtype=torch.int32, device=pred.device).unsqueeze(0),
+                                torch.full((), -1, dtype=torch.int32, device=pred.device)).contiguous()
+        pbg_d = torch.zeros((ng, 2 * w), dtype=torch.uint8, device=pred.device)
+        pbg_d[:, :w] = gbg_d * occ_d.to(torch.uint8)
+        per_video_d = ops.eval_videos(eb, pred, gt2, local_of, cluster_d, gbg_d, pbg_d, seed=seed)
     conf = conf_d.cpu().numpy()
     if conf[:, :, -1].sum() or conf[:, -1, :].sum():
         raise ValueError("labels outside their task's class set: %d predicted, %d ground-truth frames"
                          % (conf[:, :, -1].sum(), conf[:, -1, :].sum()))
-    g2c = {}
-    for g, t in enumerate(space.tasks):
-        n = len(space.ids[t])
-        g2c[t] = assign_from_confusion(conf[g, :n, :n], space.ids[t], optimal_assignment)
-        n_pred = int((conf[g, :n, :n].sum(0) > 0).sum())
-        assert n_pred <= n, "more predicted labels than the task has classes (accuracy.py:349-352)"
-    cluster, gbg, pbg = _kernel_tables(space, g2c, pred.device)
+    if optimal_assignment:
+        g2c = {}
+        for g, t in enumerate(space.tasks):
+            n = len(space.ids[t])
+            g2c[t] = assign_from_confusion(conf[g, :n, :n], space.ids[t], optimal_assignment)
+            n_pred = int((conf[g, :n, :n].sum(0) > 0).sum())
+            assert n_pred <= n, "more predicted labels than the task has classes (accuracy.py:349-352)"
+        cluster, gbg, pbg = _kernel_tables(space, g2c, pred.device)
     if empty:
         per_video = np.zeros((0, _lib.EVAL_COUNTERS), dtype=np.int64)
+    elif per_video_d is not None:
+        per_video = per_video_d.cpu().numpy()
     else:
         per_video = ops.eval_videos(eb, pred, gt2, local_of, cluster, gbg, pbg, seed=seed).cpu().numpy()
 
-    # additive per-task sums: integer counters, then the three per-video quantities of levenshtein()
-    ng = len(space.tasks)
+    # additive per-task sums (one small matrix product): integer counters, then the three per-video quantities of levenshtein()
     sums = np.zeros((ng, _lib.EVAL_COUNTERS + 4), dtype=np.float64)
     grp = np.asarray(group, dtype=np.int64)
-    for g in range(ng):
-        rows = per_video[grp == g]
-        if rows.shape[0] == 0:
-            continue
-        sums[g, :_lib.EVAL_COUNTERS] = rows.sum(0)
-        lev = rows[:, CN['levenshtein']].astype(np.float64)
-        longest = np.maximum(rows[:, CN['segs_gt']], rows[:, CN['segs_pred']]).astype(np.float64)
-        sums[g, _lib.EVAL_COUNTERS:] = [lev.sum(), (lev / longest).sum(), longest.sum(), rows.shape[0]]
+    if per_video.shape[0]:
+        member = np.zeros((ng, per_video.shape[0]), dtype=np.float64)
+        member[grp, np.arange(per_video.shape[0])] = 1.0
+        lev = per_video[:, CN['levenshtein']].astype(np.float64)
+        longest = np.maximum(per_video[:, CN['segs_gt']], per_video[:, CN['segs_pred']]).astype(np.float64)
+        sums[:, :_lib.EVAL_COUNTERS] = member @ per_video.astype(np.float64)          # (counts < 2^53: exact)
+        sums[:, _lib.EVAL_COUNTERS:] = member @ np.stack([lev, lev / longest, longest, np.ones_like(lev)], axis=1)
     if reduce is not None:
         sums = reduce(torch.from_numpy(sums).to(pred.device)).cpu().numpy()
     out, extras = {}, {}
     for g, t in enumerate(space.tasks):
         if sums[g, -1] == 0:
             continue
-        n = len(space.ids[t])
+        n = int(n_ids[g])
         lev_sum, normed_sum, maxseg_sum, nv = sums[g, _lib.EVAL_COUNTERS:]
-        out[t], extras[t] = _finalise(conf[g, :n, :n], space.ids[t], g2c[t], space.background,
-                                      sums[g, :_lib.EVAL_COUNTERS], lev_sum, normed_sum, maxseg_sum, nv)
-        extras[t]['per_video'] = per_video[grp == g]
+        if optimal_assignment:
+            out[t], extras[t] = _finalise(conf[g, :n, :n], space.ids[t], g2c[t], space.background,
+                                          sums[g, :_lib.EVAL_COUNTERS], lev_sum, normed_sum, maxseg_sum, nv)
+        else:
+            out[t], extras[t] = _finalise_identity(conf[g, :n, :n], space.ids[t], gbg_h[g, :n], sums[g, :_lib.EVAL_COUNTERS],
+                                                   lev_sum, normed_sum, maxseg_sum, nv, return_extras)
+        if return_extras:
+            extras[t]['per_video'] = per_video[grp == g]
     return (out, extras) if return_extras else out
 
 
-def accuracy_corpus(data, predictions, optimal_assignment, seed=0, reduce=None, device=None):
-    """``Datasplit.accuracy_corpus`` (corpus.py:405-600) for single-label ground truth: ``{task: stat dict}``.
+def _ground_truth(sample):
+    """Full-rate ground truth of one video as int64 [T, W], -1 padded: ``gt`` (per frame a list of labels, the
+    reference's ``Video.gt()``; or a [T, W] tensor) when the sample has it, else the single-label sequence."""
+    gt = sample.get('gt')
+    if gt is not None:
+        if torch.is_tensor(gt):
+            return gt.to(torch.int64).view(gt.size(0), -1)
+        width = max(len(f) for f in gt)
+        arr = np.full((len(gt), width), -1, dtype=np.int64)
+        for i, f in enumerate(gt):
+            arr[i, :len(f)] = f
+        return torch.from_numpy(arr)
+    single = sample.get('gt_single_unsampled')
+    if single is None:
+        single = sample['gt_single']
+    return torch.as_tensor(single).to(torch.int64).view(-1, 1)
 
-    ``data``: a datasplit with ``_videos_by_task`` / ``corpus``; ``predictions``: ``{video_name: int64[T]}`` as
-    ``SemiMarkovModel.predict`` returns (numpy or tensors), uploaded once and counted on the device.
+
+def accuracy_corpus(data, predictions, optimal_assignment, seed=0, reduce=None, device=None):
+    """``Datasplit.accuracy_corpus`` (corpus.py:405-604): ``{task: stat dict}``.
+
+    ``data``: a datasplit with ``_videos_by_task`` / ``_videos`` / ``corpus``; ``predictions``: ``{video_name:
+    int64[T]}`` as ``SemiMarkovModel.predict`` returns (numpy or tensors), uploaded once and counted on the device.
+    What the reference does on top of ``Accuracy`` is done here too, on the device:
+      * multi-label ground truth (``video.gt()``: the sample's ``gt`` entry; the first label is "the" label);
+      * ``data.subsample != 1`` (--frame_subsample): predictions made on every subsample-th frame are repeated back to
+        the frame rate, ``np.array(pred + [pred[-1]]).repeat(subsample)[:len(gt)]`` (:466-472);
+      * ``corpus.annotate_background_with_previous``: every background id of the corpus, in ground truth and predictions,
+        becomes the corpus' first background id (:474-480, ``canonicalize_background`` :399-403).
     With ``reduce`` (multi-process: ``distributed.all_reduce_tensor``) ``predictions`` may hold only this rank's videos;
     the counters are summed over ranks before anything is finalised, so every rank returns the corpus statistics
     (``main.py:486-532`` sums the same pairs over tasks).
     """
     device = device or torch.device('cuda', torch.cuda.current_device())
     tasks = list(data._videos_by_task)
-    space = LabelSpace.from_corpus(data.corpus, tasks)
+    corpus = data.corpus
+    subsample = int(getattr(data, 'subsample', 1) or 1)
+    canonical = bool(getattr(corpus, 'annotate_background_with_previous', False)) and len(corpus._background_indices) > 0
+    by_task = {t: (corpus.indices_by_task(t) if hasattr(corpus, 'indices_by_task') else corpus._indices_by_task[t])
+               for t in tasks}
+    if canonical:
+        bkg0 = int(corpus._background_indices[0])
+        by_task = {t: sorted(set(int(i) for i in ids) | {bkg0}) for t, ids in by_task.items()}
+    space = LabelSpace(by_task, corpus._background_indices, getattr(corpus, 'n_classes', None))
     lengths, offsets, task_of, preds, gts, keys = [], [], [], [], [], []
     off = 0
     for task in tasks:
@@ -260,20 +389,30 @@ def accuracy_corpus(data, predictions, optimal_assignment, seed=0, reduce=None, 
             if reduce is not None and name not in predictions:
                 continue                                   # another rank's video
             keys.append(key)                               # index inside the task: seeds the step-recall draw
-            gt = torch.as_tensor(data._videos[(task, name)]['gt_single']).to(torch.int64)
-            pr = torch.as_tensor(predictions[name]).to(torch.int64)
-            assert gt.numel() == pr.numel(), "%s: %d ground-truth vs %d predicted frames" % (name, gt.numel(), pr.numel())
-            lengths.append(int(gt.numel()))
+            gt = _ground_truth(data._videos[(task, name)])
+            pr = torch.as_tensor(predictions[name]).to(torch.int64).view(-1).to(device, non_blocking=True)
+            if subsample != 1:
+                pr = torch.cat([pr, pr[-1:]]).repeat_interleave(subsample)[:gt.size(0)]
+            assert gt.size(0) == pr.numel(), "%s: %d ground-truth vs %d predicted frames" % (name, gt.size(0), pr.numel())
+            lengths.append(int(gt.size(0)))
             offsets.append(off)
             task_of.append(task)
-            preds.append(pr.to(device, non_blocking=True))
+            preds.append(pr)
             gts.append(gt.to(device, non_blocking=True))
             off += lengths[-1]
     if not preds:                                          # a rank without videos still takes part in the reductions
-        preds, gts = [torch.zeros(1, dtype=torch.int64, device=device)], [torch.zeros(1, dtype=torch.int64, device=device)]
+        preds, gts = [torch.zeros(1, dtype=torch.int64, device=device)], [torch.zeros((1, 1), dtype=torch.int64, device=device)]
         lengths, offsets, task_of, keys = [], [], [], []
-    return evaluate_labels(torch.cat(preds), torch.cat(gts), lengths, offsets, task_of, space, optimal_assignment,
-                           seed=seed, video_key=keys, reduce=reduce)
+    width = max(g.size(1) for g in gts)
+    gts = [g if g.size(1) == width else torch.nn.functional.pad(g, (0, width - g.size(1)), value=-1) for g in gts]
+    pred, gt = torch.cat(preds), torch.cat(gts)
+    if canonical:
+        table = torch.arange(max(space.n_labels, int(pred.max()) + 1 if pred.numel() else 1), dtype=torch.int64, device=device)
+        table[torch.as_tensor([int(b) for b in corpus._background_indices], device=device)] = bkg0
+        pred = table[pred]
+        gt = torch.where(gt >= 0, table[gt.clamp(min=0)], gt)
+    return evaluate_labels(pred, gt, lengths, offsets, task_of, space, optimal_assignment, seed=seed, video_key=keys,
+                           reduce=reduce)
 
 
 def summarise(stats_by_task, keys, prefix=''):

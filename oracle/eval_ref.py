@@ -221,3 +221,30 @@ def task_counters(gt, pred, background, possible=None, optimal=False, seed=0):
     extras = dict(gt2cluster=g2c, classes_mof=cls_mof, classes_iou=cls_iou, frames=n_frames,
                   levenshtein=lev, max_segments=longest)
     return stat, extras
+
+
+def datasplit_counters(tasks, background, videos, subsample=1, annotate_background_with_previous=False, optimal=False,
+                       seed=0):
+    """``Datasplit.accuracy_corpus`` (src/data/corpus.py:405-604) on top of ``task_counters``: per task,
+    multi-label ground truth, predictions made on every ``subsample``-th frame repeated back to the frame rate
+    (``np.array(pred + [pred[-1]]).repeat(subsample)[:len(gt)]``, :466-472) and, under
+    ``annotate_background_with_previous``, EVERY background id of the corpus -- in ground truth and predictions --
+    replaced by the corpus' first background id (:474-480, ``canonicalize_background`` :399-403).
+
+    tasks: {task: class ids}; videos: {task: {name: dict(gt=per-frame label lists, pred=labels)}} in the datasplit's
+    order.  Returns {task: stat dict}."""
+    background = [int(b) for b in background]
+    canon = (lambda x: background[0] if int(x) in background else int(x)) if annotate_background_with_previous else int
+    out = {}
+    for task, vids in videos.items():
+        gts, preds = [], []
+        for name, v in vids.items():
+            gt = [[canon(x) for x in f] for f in v['gt']]
+            pred = [int(x) for x in v['pred']]
+            if subsample != 1:
+                pred = list(np.array(pred + [pred[-1]]).repeat(subsample)[:len(gt)])
+                assert len(pred) == len(gt), (name, len(pred), len(gt))
+            gts.append(gt)
+            preds.append([canon(x) for x in pred])
+        out[task], _ = task_counters(gts, preds, background, tasks[task], optimal, seed=seed)
+    return out

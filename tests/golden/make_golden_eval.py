@@ -60,6 +60,9 @@ class _NoCluster:
     def __iter__(self):
         return iter(())
 
+    def __getitem__(self, i):                  # (corpus.py:553 reads val[0] inside try / except IndexError)
+        raise IndexError(i)
+
     def __eq__(self, other):
         return False
 
@@ -165,11 +168,101 @@ def run(case):
                 classes_mof=classes_mof, classes_iou=classes_iou)
 
 
+# ------------------------------------------------------------------------------------------------ Datasplit level
+# ``Datasplit.accuracy_corpus`` itself (src/data/corpus.py:405-604) on a stand-in datasplit: what it does ON TOP of
+# ``Accuracy`` is (a) multi-label ground truth from ``video.gt()``, (b) the re-expansion of predictions made on every
+# ``subsample``-th frame (:466-472), (c) the canonicalisation of background labels under
+# ``--annotate_background_with_previous`` (:474-480: EVERY background id of the corpus becomes the corpus' first one).
+def make_datasplit_cases():
+    rng = np.random.default_rng(23)
+    tasks = {'t0': list(range(0, 7)), 't1': list(range(7, 16))}           # chains BKG, step, BKG, ...: even positions = background
+    bkg = [ids[i] for ids in tasks.values() for i in range(0, len(ids), 2)]
+    lengths = {'t0': (95, 61, 130), 't1': (88, 143)}
+    base = {}
+    for task, ids in tasks.items():
+        vids = {}
+        for vi, t in enumerate(lengths[task]):
+            gt = []
+            cur = 0
+            while len(gt) < t:
+                gt += [ids[cur % len(ids)]] * int(max(1, rng.poisson(7)))
+                cur += 1
+            gt = gt[:t]
+            steps = [i for i in ids if i not in bkg]
+            gtm = [[x, int(rng.choice([y for y in steps if y != x]))] if (x not in bkg and rng.random() < 0.12) else [x]
+                   for x in gt]
+            vids['%s_v%d' % (task, vi)] = dict(gt=gtm, pred_full=noisy(rng, gt, ids, 0.3, 4))
+        base[task] = vids
+    cases = {}
+    for name, sub, canon, optimal in (('ds_multi_label', 1, False, False), ('ds_subsample3', 3, False, False),
+                                      ('ds_canonical_background', 1, True, False), ('ds_subsample2_canonical_optimal', 2, True, True)):
+        videos = {}
+        for task, vids in base.items():
+            videos[task] = {n: dict(gt=v['gt'], pred=v['pred_full'][:(len(v['pred_full']) // sub) * sub:sub] if sub > 1 else v['pred_full'])
+                            for n, v in vids.items()}
+        cases[name] = dict(tasks=tasks, background=bkg, subsample=sub, annotate_background_with_previous=canon,
+                           optimal=optimal, videos=videos)
+    return cases
+
+
+def run_datasplit(case):
+    import data.corpus as DC
+
+    class _F1:                                # (F1Score samples with np.random.random_integers, gone from numpy 2; its keys
+        def __init__(self, **kw): pass        #  are not among the statistics this build reproduces)
+        def set_gt(self, *a): pass
+        def set_pr(self, *a): pass
+        def set_gt2pr(self, *a): pass
+        def f1(self): pass
+        def stat(self): return {}
+    DC.F1Score = _F1
+
+    class _Video:
+        def __init__(self, gt, pred):
+            self._gt, self._pred, self.segmentation, self.iter = gt, pred, {}, 0
+
+        def gt(self):
+            return [list(x) for x in self._gt]
+
+    class _Corpus(Corpus):
+        def __init__(self, background, tasks, canon):
+            Corpus.__init__(self, background, 64)
+            self._tasks, self.annotate_background_with_previous = tasks, canon
+
+        def indices_by_task(self, task):
+            return list(self._tasks[task])
+
+    ds = object.__new__(DC.Datasplit)
+    ds._corpus = _Corpus(case['background'], case['tasks'], case['annotate_background_with_previous'])
+    ds._videos_by_task = {t: {n: _Video(v['gt'], v['pred']) for n, v in vids.items()} for t, vids in case['videos'].items()}
+    ds._K_by_task = {t: len(ids) for t, ids in case['tasks'].items()}
+    ds.subsample = case['subsample']
+    ds._gt2label, ds._label2gt = None, {}
+    # (same stand-in for the empty cluster lists as in run(): Accuracy is constructed inside accuracy_corpus)
+    from collections import defaultdict
+    orig_init = Accuracy.__init__
+
+    def patched(self, *a, **kw):
+        orig_init(self, *a, **kw)
+        self._gt2cluster = defaultdict(_NoCluster)
+    DC.Accuracy.__init__ = patched
+    try:
+        np.random.seed(0)
+        stats = ds.accuracy_corpus(case['optimal'], lambda video: video._pred, verbose=False)
+    finally:
+        DC.Accuracy.__init__ = orig_init
+    return {t: {k: [float(v[0]), float(v[1])] for k, v in st.items()} for t, st in stats.items()}
+
+
 def main():
     out = {'random_keys': list(RANDOM_KEYS), 'cases': {}}
     for name, case in make_cases().items():
         out['cases'][name] = dict(inputs=case, expected=run(case))
         print(name, {k: v for k, v in out['cases'][name]['expected']['stat'].items() if k in ('mof', 'f1', 'mean_normed_levenshtein')})
+    out['datasplit_cases'] = {}
+    for name, case in make_datasplit_cases().items():
+        out['datasplit_cases'][name] = dict(inputs=case, expected=run_datasplit(case))
+        print(name, {t: st['mof'] for t, st in out['datasplit_cases'][name]['expected'].items()})
     with open(os.path.join(HERE, 'eval_vectors.json'), 'w') as f:
         json.dump(out, f)
 

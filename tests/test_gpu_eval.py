@@ -234,3 +234,41 @@ def test_sharded_evaluation_reduces_to_the_single_process_answer():
         want, _ = eval_ref.task_counters(data[t][0], data[t][1], bkg, by_task[t], True, seed=4)
         assert_stats(results[0][t], want)
         assert_stats(results[1][t], want)
+
+
+class _DsCorpus:
+    def __init__(self, inp):
+        self._background_indices = list(inp['background'])
+        self._tasks = {t: list(v) for t, v in inp['tasks'].items()}
+        self.annotate_background_with_previous = inp['annotate_background_with_previous']
+        self.n_classes = max(max(v) for v in self._tasks.values()) + 1
+
+    def indices_by_task(self, task):
+        return self._tasks[task]
+
+
+class _Ds:
+    def __init__(self, inp):
+        self.corpus = _DsCorpus(inp)
+        self.subsample = inp['subsample']
+        self._videos_by_task = {t: list(v) for t, v in inp['videos'].items()}
+        self._videos = {(t, n): dict(gt=v['gt']) for t, vids in inp['videos'].items() for n, v in vids.items()}
+
+
+@pytest.mark.parametrize('name', sorted(GOLD['datasplit_cases']))
+def test_accuracy_corpus_datasplit_semantics_match_the_reference(name):
+    """``evaluation.accuracy_corpus`` against the reference's own ``Datasplit.accuracy_corpus`` (goldens made by running
+    it on a stand-in datasplit): multi-label ground truth, --frame_subsample re-expansion, background canonicalisation
+    under --annotate_background_with_previous, identity and Hungarian assignment -- and against the CPU restatement with
+    the same seeded draw (every key, exactly)."""
+    from action_segmentation_amd.evaluation import accuracy_corpus
+    inp, exp = GOLD['datasplit_cases'][name]['inputs'], GOLD['datasplit_cases'][name]['expected']
+    preds = {n: np.asarray(v['pred'], dtype=np.int64) for vids in inp['videos'].values() for n, v in vids.items()}
+    got = accuracy_corpus(_Ds(inp), preds, inp['optimal'], seed=5)
+    assert set(got) == set(exp)
+    for task in exp:
+        assert_stats(got[task], exp[task], skip=GOLD['random_keys'])
+    want = eval_ref.datasplit_counters(inp['tasks'], inp['background'], inp['videos'], inp['subsample'],
+                                       inp['annotate_background_with_previous'], inp['optimal'], seed=5)
+    for task in want:
+        assert_stats(got[task], want[task])

@@ -51,3 +51,16 @@ def test_draw_is_roughly_uniform():
     for v in range(4000):
         counts[min(range(8), key=lambda t: (eval_ref.frame_hash(3, v, t), t))] += 1
     assert counts.min() > 400 and counts.max() < 600
+
+
+@pytest.mark.parametrize('name', sorted(GOLD['datasplit_cases']))
+def test_datasplit_level_counters_match_reference(name):
+    """The restated ``Datasplit.accuracy_corpus`` (multi-label ground truth, --frame_subsample re-expansion, background
+    canonicalisation) against the reference's own method run on a stand-in datasplit (make_golden_eval.py)."""
+    case = GOLD['datasplit_cases'][name]
+    inp, exp = case['inputs'], case['expected']
+    got = eval_ref.datasplit_counters(inp['tasks'], inp['background'], inp['videos'], inp['subsample'],
+                                      inp['annotate_background_with_previous'], inp['optimal'])
+    assert set(got) == set(exp)
+    for task in exp:
+        check_stat(got[task], exp[task], GOLD['random_keys'], False)

@@ -130,6 +130,7 @@ class PackedCorpus:
         self.batch_index = []      # per video: index of the source batch it came from
         self.k_rows = None
         self.tables = None         # stacked per-group fp64 tables on the device (filled by the module)
+        self.device = None         # set when x stays on the host (pack_batches(keep_on_host=True)): the GPU to decode on
 
     @property
     def n_videos(self):
@@ -140,8 +141,10 @@ class PackedCorpus:
         return int(np.sum(self.lengths))
 
 
-def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn=None):
+def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn=None, keep_on_host=False):
     """Fold reference-style batches (dicts from ``padding_colate``) into one PackedCorpus on ``device``.
+    ``keep_on_host``: the packed features stay on the host in PINNED memory (``pc.x``; ``pc.device`` names the GPU the
+    tables and the metadata are built for): the form ``SemiMarkovModel.predict_host`` streams to the device slab by slab.
 
     Each source batch contributes its videos with kp = min(max_k-rows, Tmax of that batch).
     ``constraints_fn(batch) -> b x Tmax x C tensor or None``; ``additional_ends_fn(batch) -> list or None``.
@@ -187,7 +190,12 @@ def pack_batches(batches, device, max_k, constraints_fn=None, additional_ends_fn
         pc.x = torch.zeros((0, 1), dtype=torch.float32, device=device)
         pc.cons_list = None
         return pc
-    pc.x = torch.cat([f.to(device=device, dtype=torch.float32) for f in feats], dim=0).contiguous()
+    if keep_on_host:
+        pc.x = torch.empty((off, int(feats[0].shape[1])), dtype=torch.float32, pin_memory=True)
+        torch.cat([f.to(device='cpu', dtype=torch.float32) for f in feats], dim=0, out=pc.x)
+        pc.device = torch.device(device)
+    else:
+        pc.x = torch.cat([f.to(device=device, dtype=torch.float32) for f in feats], dim=0).contiguous()
     if any_cons:
         pc.cons_list = cons_l
     else:

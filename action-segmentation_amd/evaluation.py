@@ -140,15 +140,17 @@ def _kernel_tables(space, g2c_by_task, device):
 def _finalise_identity(conf, ids, gbg, S, lev_sum, normed_sum, maxseg_sum, n_videos, want_extras):
     """``_finalise`` for the identity assignment (every ground-truth label that occurs is its own cluster), vectorised:
     the supervised evaluation of a whole corpus is 18 of these per call."""
-    row, col, hit = conf.sum(1), conf.sum(0), np.diagonal(conf).astype(np.float64)
-    occ = row > 0
-    nb = occ & (gbg == 0)
-    f = lambda key: float(S[CN[key]])
+    row_l, col_l, hit_l = conf.sum(1).tolist(), conf.sum(0).tolist(), np.diagonal(conf).tolist()
+    bg_l = gbg.tolist()
+    idx = [l for l, r in enumerate(row_l) if r > 0]                     # ground-truth labels that occur
+    Sl = S.tolist()
+    f = lambda key: float(Sl[CN[key]])
     frames = f('frames')
     stat = {}
-    stat['mof'] = [float(hit[occ].sum()), frames]
-    stat['mof_bg'] = [float(hit[occ].sum()), float(row[occ].sum())]
-    stat['mof_non_bg'] = [float(hit[nb].sum()), float(row[nb].sum())]
+    hit_sum = float(sum(hit_l[l] for l in idx))
+    stat['mof'] = [hit_sum, frames]
+    stat['mof_bg'] = [hit_sum, float(sum(row_l[l] for l in idx))]
+    stat['mof_non_bg'] = [float(sum(hit_l[l] for l in idx if not bg_l[l])), float(sum(row_l[l] for l in idx if not bg_l[l]))]
     stat['precision'] = [f('tp'), frames]
     stat['recall'] = [f('tp'), f('gt_labels')]
     ratio = lambda p: p[0] / p[1] if p[1] else 0.0
@@ -162,11 +164,9 @@ def _finalise_identity(conf, ids, gbg, S, lev_sum, normed_sum, maxseg_sum, n_vid
     stat['pred_background'] = [f('pred_bg'), frames]
     stat['iou_multi_non_bg'] = [f('iou_num'), f('iou_den')]
     stat['multiple_gt_labels'] = [f('multi'), frames]
-    union = (row + col - np.diagonal(conf))[occ]
-    per_class = float(sum(h / u for h, u in zip(hit[occ].tolist(), union.tolist())))    # (the reference's summation order)
-    n_occ = int(occ.sum())
-    stat['iou'] = [per_class, n_occ]
-    stat['iou_bg'] = [per_class, n_occ]
+    per_class = float(sum(hit_l[l] / (row_l[l] + col_l[l] - hit_l[l]) for l in idx))    # (the reference's summation order)
+    stat['iou'] = [per_class, len(idx)]
+    stat['iou_bg'] = [per_class, len(idx)]
     nv = float(n_videos)
     stat['mean_levenshtein'] = [lev_sum / nv, 1.0]
     stat['mean_max_segments'] = [maxseg_sum / nv, 1.0]
@@ -183,9 +183,8 @@ def _finalise_identity(conf, ids, gbg, S, lev_sum, normed_sum, maxseg_sum, n_vid
     stat['predicted_label_types_non_bg_per_video'] = [f('types_non_bg'), nv]
     if not want_extras:
         return stat, None
-    idx = np.flatnonzero(occ)
-    return stat, dict(classes_mof={ids[l]: [float(hit[l]), int(row[l])] for l in idx},
-                      classes_iou={ids[l]: [float(hit[l]), int(row[l] + col[l] - conf[l, l])] for l in idx},
+    return stat, dict(classes_mof={ids[l]: [float(hit_l[l]), int(row_l[l])] for l in idx},
+                      classes_iou={ids[l]: [float(hit_l[l]), int(row_l[l] + col_l[l] - hit_l[l])] for l in idx},
                       gt2cluster={ids[l]: [ids[l]] for l in idx})
 
 

@@ -244,12 +244,12 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
-           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False):
+           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False, labels_out=None):
     """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream.
-    ``labels_on_host``: see ``viterbi``."""
+    ``labels_on_host`` / ``labels_out``: see ``viterbi``."""
     lib = _lib.load()
     dev = x.device
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out)
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want_elp else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()

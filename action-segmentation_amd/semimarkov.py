@@ -309,6 +309,8 @@ class SemiMarkovModel(object):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop('_prepared', None)                        # device-resident copies of datasets are not model state
+        state.pop('_prepared_host', None)
+        state.pop('_host_stream_state', None)
         return state
 
     def predict_packed(self, pc):
@@ -327,6 +329,97 @@ class SemiMarkovModel(object):
         assert lab_t.numel() == 0 or int(lab_t.max()) < self.model.n_classes, "predictions should not contain EOS"
         labels = lab_t.numpy()
         return {name: labels[off:off + t] for name, off, t in zip(pc.video_names, pc.frame_offset, pc.lengths)}
+
+    # ------------------------------------------------------------------ host-resident features
+    # The reference loads every video's features from disk into host memory (crosstask.py:95-112) and moves each batch
+    # of five to the device synchronously (semimarkov.py:349-354).  Here a datasplit whose features stay on the host is
+    # packed into a few SLABS of pinned memory once; a decode pass then streams them over PCIe on a copy stream into two
+    # device buffers while the previous slab is being decoded (emission + DP read the features once), and the labels
+    # leave through the DP kernel's stores into pinned memory: the pass costs about the upload, 4 D bytes per frame.
+    def prepare_host(self, test_data, n_slabs=6, shard=None):
+        """Collate the reference's batches and pack them into ``n_slabs`` PackedCorpora whose features live in pinned
+        host memory (whole single-task batches per slab, balanced by frames).  Done once per datasplit."""
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
+                                  shard=shard)
+        batches = list(loader)
+        frames = [int(b['lengths'].sum()) for b in batches]
+        # equal shares, except that the last two slabs split one share 3 : 1 -- the pass ends with the decode of the last
+        # slab, which nothing overlaps: keep it short
+        shares = [1.0] * n_slabs if n_slabs < 3 else [1.0] * (n_slabs - 2) + [0.75, 0.25]
+        bounds = np.cumsum(shares) / np.sum(shares)
+        total, slabs, cur, acc = sum(frames), [], [], 0
+        for b, f in zip(batches, frames):
+            cur.append(b)
+            acc += f
+            if len(slabs) < n_slabs - 1 and acc >= total * bounds[len(slabs)]:
+                slabs.append(cur)
+                cur = []
+        if cur:
+            slabs.append(cur)
+        cons_fn = self._test_constraints(test_data)
+        ends_fn = lambda b: self.make_additional_allowed_ends(b['task_name'], b['lengths'])
+        packed = [self.model.prepare_packed(pack_batches(grp, self.device, self.model.max_k, constraints_fn=cons_fn,
+                                                         additional_ends_fn=ends_fn, keep_on_host=True)) for grp in slabs]
+        return packed
+
+    def decode_host(self, slabs, labels_out=None):
+        """One decode pass over slabs from ``prepare_host``: upload (copy stream, two device buffers) overlapped with the
+        decode of the previous slab.  Returns (labels int64 [frames of all slabs] in pinned host memory, the launches'
+        result dicts); synchronises the device before it returns."""
+        import torch
+        from . import ops
+        dev = self.device
+        n_max = max(pc.x.size(0) for pc in slabs)
+        d = slabs[0].x.size(1)
+        st = self.__dict__.setdefault('_host_stream_state', {})
+        if st.get('shape') != (n_max, d, str(dev)):
+            st.update(shape=(n_max, d, str(dev)), bufs=[torch.empty((n_max, d), dtype=torch.float32, device=dev) for _ in range(2)],
+                      copy=torch.cuda.Stream(device=dev))
+        total = sum(pc.x.size(0) for pc in slabs)
+        if labels_out is None:
+            if st.get('labels') is None or st['labels'].numel() < total:
+                st['labels'] = torch.empty(total, dtype=torch.int64, pin_memory=True)
+            labels_out = st['labels'][:total]
+        main = torch.cuda.current_stream(dev)
+        copied = [torch.cuda.Event() for _ in slabs]
+        freed = [None, None]                                   # per device buffer: the decode that last read it is done
+        outs, off = [], 0
+        for k, pc in enumerate(slabs):
+            n = pc.x.size(0)
+            buf = st['bufs'][k & 1][:n]
+            with torch.cuda.stream(st['copy']):
+                if freed[k & 1] is not None:
+                    st['copy'].wait_event(freed[k & 1])
+                buf.copy_(pc.x, non_blocking=True)
+                copied[k].record(st['copy'])
+            main.wait_event(copied[k])
+            outs.append(self.model.decode_packed(pc, want_spans=False, want_labels=True, x=buf, labels_out=labels_out[off:off + n]))
+            freed[k & 1] = torch.cuda.Event()
+            freed[k & 1].record(main)
+            off += n
+        main.synchronize()
+        for pc, out in zip(slabs, outs):
+            ops.check_decoded(pc.batch, out)
+        return labels_out, outs
+
+    def predict_host(self, test_data, n_slabs=6, shard=None):
+        """``predict`` for a datasplit whose features stay in host memory: ``{video: int64[T]}``."""
+        cache = self.__dict__.setdefault('_prepared_host', {})
+        key = (id(test_data), len(test_data), n_slabs, shard, tuple(self.args.sm_constrain_with_narration), self.args.batch_size)
+        slabs = cache.get(key)
+        if slabs is None:
+            cache.clear()
+            slabs = cache[key] = self.prepare_host(test_data, n_slabs, shard)
+        else:
+            slabs = [self.model.prepare_packed(pc) for pc in slabs]      # (tables follow the current parameters)
+        labels, _ = self.decode_host(slabs)
+        lab = labels.clone().numpy()
+        out, off = {}, 0
+        for pc in slabs:
+            for name, o, t in zip(pc.video_names, pc.frame_offset, pc.lengths):
+                out[name] = lab[off + o:off + o + t]
+            off += pc.x.size(0)
+        return out
 
     def predict(self, test_data, fused=True, shard=None):
         """``{video: int64[T]}``.  ``shard=(rank, world)`` (default: the torch.distributed group when one is up) limits the

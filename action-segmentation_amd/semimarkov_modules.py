@@ -527,7 +527,7 @@ class SemiMarkovModule(nn.Module):
         """fp64 factor tables of every group of a PackedCorpus stacked to [groups, ...] and zero-padded to c_max columns.
         ``differentiable``: built from the parameters with autograd history (training); otherwise the cached decode
         tables."""
-        dev = pc.x.device
+        dev = pc.device or pc.x.device
         if differentiable and self.max_k > 1:
             return self._stacked_tables_batched(pc, dev)
         if differentiable:
@@ -632,7 +632,7 @@ class SemiMarkovModule(nn.Module):
     def prepare_packed(self, pc, differentiable=False):
         """Stack the fp64 factor tables of every group of a PackedCorpus (batching.py), padded to c_max columns, and
         build the per-video end penalties / constraint block / launch metadata."""
-        dev = pc.x.device
+        dev = pc.device or pc.x.device
         d = pc.x.size(1)
         if pc.n_videos == 0:                # an empty shard: nothing to launch (predict_packed returns {})
             pc.tables, pc.batch, pc.cons, pc.endpen = {}, None, None, None
@@ -664,16 +664,20 @@ class SemiMarkovModule(nn.Module):
         pc._static = (cm, k_rows, id(self))
         return pc
 
-    def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False, labels_on_host=False):
+    def decode_packed(self, pc, want_spans=False, want_labels=True, want_elp=False, labels_on_host=False, x=None,
+                      labels_out=None):
         """One emission launch + one DP launch for a whole PackedCorpus.  Returns the dict of ops.decode
-        (``labels``: int64 [total_frames] global class ids; ``spans``: [n_videos, t_max+1])."""
-        self._require_device(pc.x, 'decode_packed')
+        (``labels``: int64 [total_frames] global class ids; ``spans``: [n_videos, t_max+1]).
+        ``x``: the corpus' features on the device when ``pc.x`` itself lives on the host (predict_host uploads them slab by
+        slab); ``labels_out``: where the frame labels go (a device tensor, or pinned host memory)."""
+        x = pc.x if x is None else x
+        self._require_device(x, 'decode_packed')
         if pc.tables is None:
             self.prepare_packed(pc)
         t = pc.tables
-        return ops.decode(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
+        return ops.decode(pc.batch, x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
                           cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'], want_spans=want_spans,
-                          want_labels=want_labels, want_elp=want_elp, labels_on_host=labels_on_host)
+                          want_labels=want_labels, want_elp=want_elp, labels_on_host=labels_on_host, labels_out=labels_out)
 
     # ------------------------------------------------------------------ likelihoods (reference :597-658)
     def gold_score(self, features, lengths, valid_classes, spans, additional_allowed_ends_per_instance=None,

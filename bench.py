@@ -433,6 +433,32 @@ def predict_end_to_end(model, data):
     return out
 
 
+def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=8):
+    """The same decode with the features in HOST memory (the reference's flow: features loaded from disk
+    into host memory, crosstask.py:95-112, every batch moved to the device, semimarkov.py:349-354): the corpus packed
+    into pinned slabs once (untimed, the loader's job), then K timed passes of SemiMarkovModel.decode_host -- upload on a
+    copy stream into two device buffers, overlapped with the decode of the previous slab, labels back through the DP
+    kernel's stores into pinned memory.  PCIe-inclusive: never the headline value."""
+    host = data.subset(10 ** 9)                              # (the same videos, features on the host)
+    t0 = time.perf_counter()
+    slabs = model.prepare_host(host, n_slabs)
+    prep = time.perf_counter() - t0
+    frames = sum(pc.n_frames for pc in slabs)
+    nbytes = sum(pc.x.numel() * 4 for pc in slabs)
+    labels, _ = model.decode_host(slabs)                     # warm-up (buffers, workspaces)
+    same = bool(np.array_equal(labels.numpy(), labels_ref))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.decode_host(slabs)
+    dt = (time.perf_counter() - t0) / a.steps
+    return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "slabs": len(slabs),
+            "h2d_GBps": nbytes / dt / 1e9, "pcie_bound_frames_per_s": 63e9 / (4.0 * cfg['d']),
+            "labels_equal_resident_decode": same, "prepare_host_s": prep,
+            "what": "features in pinned host memory, streamed over PCIe every pass (%d slabs, two device buffers, copy "
+                    "stream) while the previous slab decodes; PCIe Gen5 x16 bounds it at 63 GB/s / (4 D B/frame)" % len(slabs)}
+
+
 def train_step_rate(args, data, model):
     """Secondary figures for config 4: frames/s of the unsupervised objective's forward + backward (emission, log Z
     forward kernel, time-reversed backward kernel, marginal kernels, chain rule into the parameters):
@@ -741,6 +767,10 @@ def main():
         # round 2 reported 4 s for a 25 ms call this way)
         if world == 1 and not a.no_predict_e2e:
             res["predict_end_to_end"] = predict_end_to_end(model, data)
+            try:
+                res["host_features"] = host_features_leg(a, cfg, model, data, lab)
+            except Exception as e:
+                res["host_features"] = {"error": repr(e)}
         parity = {"frames_checked": 0, "label_mismatches": None, "logz_max_rel": None, "grad_max_abs": None,
                   "what": "the C twin (oracle/smm_oracle.c) against the GPU on this workload, checker side only: frame "
                           "labels of the TIMED decode for every video the cpu_factored leg covered; cfg4: logZ and the "

@@ -193,3 +193,21 @@ def test_fit_counts_the_leftover_batches_of_an_epoch():
     assert len(log) == 1
     np.testing.assert_allclose(log[0]['train_loss'], np.mean(per_batch), rtol=1e-9)
     np.testing.assert_allclose(log[0]['train_nll_frame_avg'], nll / frames, rtol=1e-9)
+
+
+@pytest.mark.parametrize('constrain', [False, True])
+def test_predict_host_streams_slabs_and_equals_predict(constrain):
+    """Features that stay in host memory (pinned slabs, double-buffered upload on a copy stream overlapped with the decode of
+    the previous slab) decode to exactly what the device-resident corpus decodes to -- with and without constraints."""
+    data, args, model = build(constrain, ('test',) if constrain else ())
+    want = model.predict(data)
+    host = data.subset(10 ** 9)
+    assert all(not smp['features'].is_cuda for smp in host._videos.values())
+    for n_slabs in (1, 3, 6):
+        got = model.predict_host(host, n_slabs=n_slabs)
+        assert set(got) == set(want)
+        for name in want:
+            np.testing.assert_array_equal(got[name], want[name], err_msg='%s (%d slabs)' % (name, n_slabs))
+    slabs = model.prepare_host(host, 3)
+    assert len(slabs) == 3 and all(pc.x.is_pinned() and not pc.x.is_cuda for pc in slabs)
+    assert sum(pc.n_videos for pc in slabs) == len(want)

@@ -455,6 +455,14 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         a.band_tab = band_tab;
         a.flags |= 128;
     }
+    if (ring_regs(st.kp_max) == 1 && !std::getenv("SMM_NO_BT_WINDOW")) {
+        // short segments: window back-trace (smm_viterbi.hip); W >= 2 kp keeps a window good for many segments
+        // about 48 KB of window (three workgroups per CU stay possible), at least 2 kp positions, at most 512
+        int w = (int)(48 * 1024 / (24 * (size_t)st.c_need)) & ~7;
+        w = std::min(512, std::max(w, (2 * st.kp_max + 7) & ~7));
+        const size_t bytes = sizeof(double) * ((size_t)3 * w + st.c_need + st.kp_max) * st.c_need;
+        if (bytes <= 126 * 1024) { a.bt_window = w; a.bt_dyn_bytes = (int32_t)bytes; }
+    }
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant

@@ -52,6 +52,8 @@ struct SmmDpArgs {
     int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
     const double *len_t;       // Viterbi BAND mode (flags bit 7, 128): [g][c_max][k_rows] state-major length table ...
     const double *band_tab;    // ... and [g][c_max][16] bounds of the band skip test (smm_viterbi.hip: smm_band_tables_kernel)
+    int32_t bt_window;         // Viterbi, kp <= 64: positions per LDS window of the back-trace (0: the general back-trace) ...
+    int32_t bt_dyn_bytes;      // ... and the dynamic LDS it needs: (3 W + c + kp) c doubles for the launch's largest c, kp
 };
 
 // One-CU videos on 8 waves: the rank (0..6) that trades places with the chain wave's partner (rank 6, the lightest) so

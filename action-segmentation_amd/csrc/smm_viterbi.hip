@@ -1202,6 +1202,92 @@ smm_viterbi_kernel(SmmDpArgs a)
     // one lane per state) finds the maximum and the usually single state that attains it from 8*C bytes of the
     // gamma history; phase B scans only that state's row for the first k (16 B per candidate), all waves abreast.
     int n = T, to = sh_c, nseg = 0, round = 0;
+    if constexpr (R == 1) {
+        // -------- short segments (kp <= 64: the reference's default --sm_max_span_length 20, cfg4's 64): WINDOW back-trace.
+        // The general path below makes one or two round trips to the history per SEGMENT (1.6 us each) with the whole
+        // workgroup; with short segments a video is hundreds of them.  Here a window of the history (W positions: the
+        // gamma and cumE rows, the h rows, 24 C bytes per position) is staged in LDS in bulk by all waves, then wave 0
+        // walks every segment that ends inside it from LDS alone -- lane = state for the maximum, lane = length for the
+        // first length that attains it: no barrier, no memory round trip per segment.  Same expressions, same
+        // first-(k, state) order as the general path.  a.bt_window = W (0: the general path; the host sizes the dynamic LDS).
+        const int W = a.bt_window;
+        if (W > 0) {
+            extern __shared__ __attribute__((aligned(16))) double smm_dyn[];
+            double *win_g = smm_dyn, *win_c = win_g + (size_t)W * C, *win_h = win_c + (size_t)W * C;
+            double *tab_t = win_h + (size_t)W * C, *tab_l = tab_t + (size_t)C * C;     // trans [to][from], len [k][c]
+            for (int e = threadIdx.x; e < C * C; e += blockDim.x) tab_t[e] = trans[(size_t)(e / C) * cm + e % C];
+            for (int e = threadIdx.x; e < kp * C; e += blockDim.x) tab_l[e] = len[(size_t)(e / C) * cm + e % C];
+            // lane c: the global id of local label c (a load per segment from the class map would be a trip to L2 each)
+            const int64_t gid_l = (lane <= C) ? (cmap ? cmap[lane] : (int64_t)lane) : 0;
+            const int gid_lo = (int)(gid_l & 0xffffffff), gid_hi = (int)(gid_l >> 32);
+            // ... and lane c: the end penalty of state c.  (No global LOAD inside the walk: a wave that waits for a load
+            // waits for its older stores too -- vmcnt counts both, in order -- and every segment stores its labels.)
+            const double ep_l = (endpen && lane < C) ? endpen[lane] : 0.0;
+            bool bad = false;
+            while (n > 0) {
+                // window = positions n0 .. n  (W of them, or all that are left)
+                const int n0 = (n - W + 1 > 0) ? n - W + 1 : 0, rows = n - n0 + 1;
+                __syncthreads();                                   // the previous window has been walked
+                for (int e = threadIdx.x; e < rows * C; e += blockDim.x) {
+                    win_g[e] = hgam[(size_t)n0 * C + e];
+                    win_c[e] = hcum[(size_t)n0 * C + e];
+                }
+                for (int e = threadIdx.x; e < rows * C; e += blockDim.x) {
+                    const int c2 = e / rows, i = e % rows;         // (h is state-major in HBM: consecutive threads, consecutive positions)
+                    win_h[(size_t)i * C + c2] = hh[(size_t)c2 * (T + 1) + n0 + i];
+                }
+                __syncthreads();
+                if (w == 0) {
+                    // every segment whose candidates all lie inside the window
+                    while (n > 0 && (n0 == 0 || n - (kp - 1) >= n0)) {
+                        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+                        const int row = n - n0;
+                        double wgt = 0.0, gmv = SMM_NEG_INF, cnl = 0.0;
+                        if (lane < C) {
+                            cnl = win_c[(size_t)row * C + lane];
+                            wgt = (to == C) ? ep_l : tab_t[(size_t)to * C + lane];
+                            gmv = win_g[(size_t)row * C + lane] + wgt;
+                        }
+                        const double rmax = smm_row_max16(gmv);
+                        const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
+                        unsigned long long fmask = __ballot(lane < C && gmv == best);
+                        int k = 0x7fffffff, c = 0x7fffffff;
+                        while (fmask) {
+                            const int f = __builtin_amdgcn_readfirstlane(__ffsll(fmask) - 1);
+                            fmask &= fmask - 1;
+                            const double cn = smm_readlane(cnl, f), wf = smm_readlane(wgt, f);
+                            const int lim = (kmax < k - 1) ? kmax : k - 1;      // an equal k with a larger state loses
+                            const int kk = lane + 1;
+                            bool hit = false;
+                            if (kk <= lim) hit = ((cn + (win_h[(size_t)(row - kk) * C + f] + tab_l[(size_t)kk * C + f])) + wf) == best;
+                            const unsigned long long m = __ballot(hit);
+                            if (m) { k = __ffsll(m); c = f; }
+                        }
+                        if (k < 1 || k > kmax || c < 0 || c >= C) { bad = true; break; }   // NaN / inf - inf in the inputs
+                        const int s0 = n - k;
+                        const int64_t gid = ((int64_t)__builtin_amdgcn_readlane(gid_hi, c) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane(gid_lo, c);
+                        if (labels && lane < k) labels[s0 + lane] = gid;
+                        if (spans && lane == 0) spans[s0] = gid;
+                        ++nseg;
+                        n = s0;
+                        to = c;
+                    }
+                    if (lane == 0) { sh_kmin[0] = (unsigned)n; sh_kmin[1] = (unsigned)to; sh_kmin[2] = bad ? 1u : 0u; }
+                }
+                __syncthreads();
+                n = (int)sh_kmin[0];
+                to = (int)sh_kmin[1];
+                if (sh_kmin[2]) {
+                    if (threadIdx.x == 0) atomicExch(a.err, 1);
+                    break;
+                }
+            }
+            if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg + (no_eos ? 1 : 0);
+            if (recover && threadIdx.x == 0) atomicAdd(a.err + 2, 1);
+            return;
+        }
+    }
 #ifdef SMM_PROFILE
     unsigned long long bt_a = 0, bt_b = 0, bt_c = 0, bt_t = __builtin_readcyclecounter();   // phase A / B / labels, workgroup 0
 #define SMM_BT_STAMP(acc) do { const unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - bt_t; bt_t = t_; } while (0)
@@ -1368,10 +1454,23 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
         }
     }
     if (a.n_pairs > 0) return 0;                                 // (the host only pairs for the configuration above)
+    // R = 1 (kp <= 64): the window back-trace stages history and tables in dynamic LDS (a.bt_dyn_bytes, up to ~125 KB:
+    // the 64 KB default limit of dynamic LDS is lifted once per kernel)
+    const size_t dyn = (R == 1 && a.bt_window > 0) ? (size_t)a.bt_dyn_bytes : 0;
+    auto go = [&](auto kernel) {
+        if constexpr (R == 1) {
+            static bool raised = false;
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL(kernel, dim3(a.b), dim3(NW * 64), dyn, stream, a);
+    };
     // HF: source states per half of the chain wave (2 HF >= states)
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 4, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
-    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
-    else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B>), dim3(a.b), dim3(NW * 64), 0, stream, a);
+    if (c_need <= 16) go(smm_viterbi_kernel<R, SPW, NW, 4, 0, B>);
+    else if (c_need <= 24) go(smm_viterbi_kernel<R, SPW, NW, 12, 0, B>);
+    else go(smm_viterbi_kernel<R, SPW, NW, 16, 0, B>);
     return 1;
 }
 

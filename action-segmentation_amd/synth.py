@@ -38,6 +38,10 @@ CONFIGS = {
     # configs[3]: ordering constraints + narration constraints, small shapes
     'cfg4': dict(n_tasks=6, videos_per_task=10, steps=(3, 7), t_lognormal=(900, 0.4, 200, 2048), max_k=64, d=200,
                  chain=True, rate=(10, 50), batch_size=5, narration=True),
+    # the reference's DEFAULT shapes: --sm_max_span_length 20 (modules:55), --batch_size 5 (main.py:70), one
+    # feature vector per second of CrossTask video (T of a few hundred), PCA-200 features
+    'refdef': dict(n_tasks=18, videos_per_task=5, steps=(5, 11), t_lognormal=(300, 0.3, 100, 600), max_k=20, d=200,
+                   chain=True, rate=(4, 16), batch_size=5),
     # tiny CPU-test corpus
     'tiny': dict(n_tasks=3, videos_per_task=4, steps=(2, 4), t_lognormal=(60, 0.3, 20, 120), max_k=12, d=8,
                  chain=True, rate=(3, 9), batch_size=2, narration=True),

@@ -48,7 +48,7 @@ def parse(argv=None):
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=2)
-    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3c', 'cfg4', 'cfg5', 'tiny'])
+    p.add_argument('--workload', default='cfg3', choices=['cfg1', 'cfg2', 'cfg3', 'cfg3c', 'cfg4', 'cfg5', 'refdef', 'tiny'])
     p.add_argument('--scale', type=float, default=1.0, help='videos per task multiplier')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--seed', type=int, default=2, help='corpus seed of rank 0 (weak scaling: rank r uses seed + r)')
@@ -459,6 +459,58 @@ def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=8):
                     "stream) while the previous slab decodes; PCIe Gen5 x16 bounds it at 63 GB/s / (4 D B/frame)" % len(slabs)}
 
 
+def reference_default_leg(a, dev, D, with_cpu):
+    """The reference's own default shapes (synth 'refdef': --sm_max_span_length 20, batches of 5 videos of one task,
+    T ~ 300, 11..23 states, D = 200): SemiMarkovModel.predict in the reference's call pattern (one viterbi() per batch:
+    wall time per call, everything included) and as one fused launch; with its own cpu_baseline (the dense port, which
+    IS runnable at these sizes: 14 MB of potentials per video)."""
+    from action_segmentation_amd import synth
+    cfg = synth.CONFIGS['refdef']
+    data = synth.SynthDatasplit('refdef', seed=a.seed, device=dev)
+    aa = argparse.Namespace(**vars(a))
+    aa.fit_videos = 5
+    args, model = fit_model(aa, cfg, data, dev, D, 1)
+    frames = data.n_frames
+    n_batches = cfg['n_tasks']
+    out = {"workload": "refdef seed %d: %d tasks x %d videos, %d frames, max span length %d, D=%d"
+                       % (a.seed, cfg['n_tasks'], cfg['videos_per_task'], frames, cfg['max_k'] - 1, cfg['d'])}
+    for name, fused in (('per_batch', False), ('fused', True)):
+        model.predict(data, fused=fused)
+        model.predict(data, fused=fused)
+        best = None
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.predict(data, fused=fused)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[name] = {"ms": best * 1e3, "frames_per_s": frames / best}
+    out["viterbi_call_ms"] = out['per_batch']['ms'] / n_batches
+    if with_cpu:
+        from oracle import dense_ref as O
+        m = model.model
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        p = O.RefParams(m.n_classes, sd['poisson_log_rates'], sd['gaussian_means'], torch.diagonal(sd['gaussian_cov']).clone(),
+                        sd['transition_logits'], sd['init_logits'], m.max_k, True)
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        done, dt = 0, 0.0
+        for (tk, nm) in sorted(data._videos):
+            smp = data._videos[(tk, nm)]
+            x = smp['features'].cpu().float()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.viterbi(p, x.unsqueeze(0), torch.tensor([x.shape[0]]), smp['task_indices'])
+            dt += time.perf_counter() - t0
+            done += x.shape[0]
+            if dt > 8.0:
+                break
+        out["cpu_baseline"] = {"value": done / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "%d frames (whole videos, one at a time): dense potentials + sequential max-DP with "
+                                         "back-pointers (oracle/dense_ref.py), %.1f s" % (done, dt)}
+    return out
+
+
 def train_step_rate(args, data, model):
     """Secondary figures for config 4: frames/s of the unsupervised objective's forward + backward (emission, log Z
     forward kernel, time-reversed backward kernel, marginal kernels, chain rule into the parameters):
@@ -771,6 +823,11 @@ def main():
                 res["host_features"] = host_features_leg(a, cfg, model, data, lab)
             except Exception as e:
                 res["host_features"] = {"error": repr(e)}
+            if a.workload == 'cfg3':
+                try:
+                    res["reference_default"] = reference_default_leg(a, dev, D, not a.no_cpu_baseline)
+                except Exception as e:
+                    res["reference_default"] = {"error": repr(e)}
         parity = {"frames_checked": 0, "label_mismatches": None, "logz_max_rel": None, "grad_max_abs": None,
                   "what": "the C twin (oracle/smm_oracle.c) against the GPU on this workload, checker side only: frame "
                           "labels of the TIMED decode for every video the cpu_factored leg covered; cfg4: logZ and the "

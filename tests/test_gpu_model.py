@@ -209,5 +209,5 @@ def test_predict_host_streams_slabs_and_equals_predict(constrain):
         for name in want:
             np.testing.assert_array_equal(got[name], want[name], err_msg='%s (%d slabs)' % (name, n_slabs))
     slabs = model.prepare_host(host, 3)
-    assert len(slabs) == 3 and all(pc.x.is_pinned() and not pc.x.is_cuda for pc in slabs)
+    assert 2 <= len(slabs) <= 3 and all(pc.x.is_pinned() and not pc.x.is_cuda for pc in slabs)
     assert sum(pc.n_videos for pc in slabs) == len(want)

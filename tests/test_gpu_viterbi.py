@@ -562,6 +562,26 @@ def test_viterbi_24_to_32_states_ride_in_triples(c, monkeypatch):
         np.testing.assert_array_equal(got[key], slow[key].cpu().numpy())
 
 
+# ---------------------------------------------------------------------------------------------------- window back-trace
+@pytest.mark.parametrize('shape', [(5, 300, 20, 20), (5, 320, 23, 20), (3, 700, 12, 64), (2, 1500, 32, 33), (6, 64, 4, 20),
+                                   (2, 129, 7, 64), (1, 5000, 9, 40), (4, 257, 16, 65)])
+@pytest.mark.parametrize('integer', [False, True])
+def test_window_backtrace_equals_general_backtrace_and_the_twin(shape, integer, monkeypatch):
+    """kp <= 64 (the reference's default --sm_max_span_length 20): the back-trace walks windows of the history staged in
+    LDS (one wave, no memory round trip per segment) -- same spans, labels and segment counts as the general back-trace
+    (SMM_NO_BT_WINDOW=1) and as the C twin, incl. integer lattices where many (k, state) candidates tie."""
+    b, tmax, c, k = shape
+    p = make_problem(hash(shape) % 1000 + 3, b, tmax, c, k, integer=integer, ends=(c > 2))
+    monkeypatch.delenv('SMM_NO_BT_WINDOW', raising=False)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    monkeypatch.setenv('SMM_NO_BT_WINDOW', '1')
+    gen = run_gpu(p)
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], gen[key])
+
+
 # ---------------------------------------------------------------------------------------------------- BAND mode
 def structured_problem(seed, lengths, c, k, margin=18.0, rate=(20, 400)):
     """A lattice with CrossTask-like structure: HSMM-sampled segments, the true state's emission beats the others by

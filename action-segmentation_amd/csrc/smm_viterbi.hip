@@ -53,6 +53,13 @@
         const unsigned long long t2 = __builtin_readcyclecounter();               \
         p_busy += t1 - p_t0; p_wait += t2 - t1; p_t0 = t2;                        \
     } while (0)
+#define SMM_LDS_BARRIER()                                                          \
+    do {                                                                          \
+        const unsigned long long t1 = __builtin_readcyclecounter();               \
+        smm_lds_barrier();                                                        \
+        const unsigned long long t2 = __builtin_readcyclecounter();               \
+        p_busy += t1 - p_t0; p_wait += t2 - t1; p_t0 = t2;                        \
+    } while (0)
 #define SMM_PROF_OUT()                                                            \
     if (blockIdx.x == 0 && lane == 0) {                                           \
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err);   \
@@ -61,8 +68,21 @@
 #else
 #define SMM_PROF_DECL do { } while (0)
 #define SMM_BLOCK_BARRIER() __syncthreads()
+#define SMM_LDS_BARRIER() smm_lds_barrier()
 #define SMM_PROF_OUT() do { } while (0)
 #endif
+
+// Block barrier of the BAND mode: what the waves hand each other per block lives in LDS only, so the barrier waits for
+// the wave's LDS operations (lgkmcnt) and NOT for its vector-memory operations.  __syncthreads() is a workgroup-scope
+// release + barrier + acquire, i.e. s_waitcnt vmcnt(0) in front of every s_barrier: the mover wave then stalls once per
+// block until the elp rows it has just asked for (two blocks ahead, on purpose) have arrived from HBM, and seven waves
+// wait for it.  Global data that does change hands inside the workgroup is ordered otherwise: the history rows the
+// delayed bands read were stored >= 27 blocks earlier by a wave that has since waited for YOUNGER loads (vmcnt counts in
+// issue order), and the back-trace starts behind real __syncthreads().
+__device__ __forceinline__ void smm_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 #ifndef SMM_B
 #define SMM_B 4   // positions per hand-over block (development builds override it)
@@ -574,7 +594,8 @@ smm_viterbi_kernel(SmmDpArgs a)
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
         constexpr bool GAMROW = (B > 4) || (R < 4);       // a separate gamma broadcast row (see the position loop)
-        constexpr bool TAILFREE = R < 16;                  // no bounds tests inside a block (see the position loop)
+        constexpr bool TAILFREE = R < 16 || BAND;          // no bounds tests inside a block (see the position loop; BAND:
+                                                           // the chain wave alone bounds the frame, whatever the state count)
         constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
         const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
         const bool live = to < C;
@@ -689,7 +710,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if constexpr (CP) {
                     if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
                 }
-                SMM_BLOCK_BARRIER();                                       // end of block j
+                if constexpr (BAND) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j
             }
         }
         SMM_PROF_OUT();
@@ -1041,7 +1062,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                         for (int i = 0; i < B; ++i) hq[i] = smm_ld_agent(src + i);
                     }
                 }
-                SMM_BLOCK_BARRIER();                             // end of block j
+                SMM_LDS_BARRIER();                               // end of block j
             }
         }
         SMM_PROF_OUT();

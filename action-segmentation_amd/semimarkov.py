@@ -232,12 +232,20 @@ class SemiMarkovModel(object):
         return res
 
     def expand_constraints(self, datasplit, task, task_indices, constraints):
+        """b x T x S step constraints -> b x T x C in the task's class order, zeros on the background columns (reference
+        :149-157).  Stays on the device of ``constraints``: one scatter instead of a column loop."""
         task_indices = [int(v) for v in task_indices]
         step_indices = datasplit.get_ordered_indices_no_background()[task]
         assert constraints.size(2) == len(step_indices)
-        out = torch.zeros((constraints.size(0), constraints.size(1), len(task_indices)))
-        for index, label in enumerate(step_indices):
-            out[:, :, task_indices.index(label)] = constraints[:, :, index]
+        cache = self.__dict__.setdefault('_step_columns', {})
+        key = (task, tuple(task_indices), str(constraints.device))
+        cols = cache.get(key)
+        if cols is None:
+            cols = cache[key] = torch.tensor([task_indices.index(label) for label in step_indices], dtype=torch.long,
+                                             device=constraints.device)
+        out = torch.zeros((constraints.size(0), constraints.size(1), len(task_indices)), dtype=constraints.dtype,
+                          device=constraints.device)
+        out[:, :, cols] = constraints
         return out
 
     def _train_constraints(self, train_data):
@@ -247,7 +255,8 @@ class SemiMarkovModel(object):
         def fn(batch):
             tasks = batch['task_name']
             assert all_equal(tasks)
-            ce = self.expand_constraints(train_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
+            cons = batch['constraints'].to(self.device, non_blocking=True)     # (S columns: expanded on the device)
+            ce = self.expand_constraints(train_data, tasks[0], batch['task_indices'][0], 1 - cons)
             return ce * self.args.sm_constrain_narration_weight
         return fn
 
@@ -258,7 +267,8 @@ class SemiMarkovModel(object):
         def fn(batch):
             tasks = batch['task_name']
             assert all_equal(tasks)
-            ce = self.expand_constraints(test_data, tasks[0], batch['task_indices'][0], 1 - batch['constraints'])
+            cons = batch['constraints'].to(self.device, non_blocking=True)
+            ce = self.expand_constraints(test_data, tasks[0], batch['task_indices'][0], 1 - cons)
             return ce * self.args.sm_constrain_narration_weight
         return fn
 
@@ -311,6 +321,7 @@ class SemiMarkovModel(object):
         state.pop('_prepared', None)                        # device-resident copies of datasets are not model state
         state.pop('_prepared_host', None)
         state.pop('_host_stream_state', None)
+        state.pop('_step_columns', None)
         return state
 
     def predict_packed(self, pc):

@@ -423,6 +423,7 @@ class SemiMarkovModule(nn.Module):
         state = dict(self.__dict__)
         state.pop('_table_cache', None)          # device tensors derived from the parameters: rebuilt on demand
         state.pop('_index_cache', None)
+        state.pop('_endpen_cache', None)
         state.pop('_single_group', None)         # (index tensors + the ctypes shape of the table kernels)
         return state
 
@@ -453,13 +454,26 @@ class SemiMarkovModule(nn.Module):
                 id(getattr(self, 'merge_classes', None)), bool(getattr(self, 'allow_self_transitions', True)))
 
     def _endpen(self, valid_classes, additional_allowed_ends_per_instance, b, c, device):
-        ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
-        if ends is None:
+        """fp64 [b, c] end penalties on the device (0 for an allowed end state, -1e9 otherwise; reference :462-471).
+        Cached per (class set, additional ends of the batch): the reference's call pattern asks for the same few
+        tables batch after batch, and building one is a python loop plus a host-to-device copy."""
+        if self.allowed_ends is None:
             return None
+        add = additional_allowed_ends_per_instance
+        key = (None if valid_classes is None else tuple(int(v) for v in valid_classes), b, c, str(device),
+               tuple(sorted(self.allowed_ends)), None if add is None else tuple(tuple(int(x) for x in a) for a in add))
+        cache = self.__dict__.setdefault('_endpen_cache', {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        ends = self._allowed_ends_per_instance(valid_classes, additional_allowed_ends_per_instance, b)
         ep = torch.full((b, c), BIG_NEG, dtype=torch.float64)
         for i, e in enumerate(ends):
             ep[i, e] = 0.0
-        return ep.to(device)
+        if len(cache) > 256:
+            cache.clear()
+        cache[key] = ep = ep.to(device)
+        return ep
 
     @staticmethod
     def _require_device(t, what):

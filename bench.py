@@ -433,7 +433,7 @@ def predict_end_to_end(model, data):
     return out
 
 
-def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=8):
+def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=6):
     """The same decode with the features in HOST memory (the reference's flow: features loaded from disk
     into host memory, crosstask.py:95-112, every batch moved to the device, semimarkov.py:349-354): the corpus packed
     into pinned slabs once (untimed, the loader's job), then K timed passes of SemiMarkovModel.decode_host -- upload on a
@@ -605,12 +605,15 @@ def logz_cpu_baseline(pc, budget_s=10.0):
     torch.cuda.synchronize()
     z_gpu = z_dev.cpu().numpy()
     g_gpu = {k: v.cpu().numpy() for k, v in g_dev.items()}
-    z_rel, g_abs, g_tol, n_checked = 0.0, 0.0, 0.0, 0
+    z_rel, g_abs, g_tol, g_rel, n_checked = 0.0, 0.0, 0.0, 0.0, 0
 
     def cmp(got, ref):
-        """max |got - ref| and max of |got - ref| / (2e-5 + 2e-5 |ref|) (<= 1: inside the tests' rtol = atol = 2e-5)"""
+        """max |got - ref|, max of |got - ref| / (2e-5 + 2e-5 |ref|) (<= 1: inside the tests' rtol = atol = 2e-5) and
+        max of |got - ref| / max(1, |ref|) (the path's tolerance, SURVEY 8c(3): 1e-4 on posteriors; a gradient entry is a
+        sum of posteriors, an expected count of up to ~1e3)"""
         err = np.abs(got - ref)
-        return float(err.max()), float((err / (2e-5 + 2e-5 * np.abs(ref))).max())
+        return (float(err.max()), float((err / (2e-5 + 2e-5 * np.abs(ref))).max()),
+                float((err / np.maximum(1.0, np.abs(ref))).max()))
     cores = F.set_threads(F.host_cores())
     by_group = {}
     for i in range(pc.n_videos):
@@ -644,8 +647,8 @@ def logz_cpu_baseline(pc, budget_s=10.0):
             pairs += [(g_gpu['trans'][g, :c, :c], g_ref['trans']), (g_gpu['init'][g, :c], g_ref['init']),
                       (g_gpu['len'][g, :kp, :c], g_ref['len'])]
         for got, ref in pairs:
-            ea, et = cmp(got, ref)
-            g_abs, g_tol = max(g_abs, ea), max(g_tol, et)
+            ea, et, er = cmp(got, ref)
+            g_abs, g_tol, g_rel = max(g_abs, ea), max(g_tol, et), max(g_rel, er)
         n_checked += len(vids)
         frames += sum(pc.lengths[i] for i in vids)
         n_vid += len(vids)
@@ -655,8 +658,10 @@ def logz_cpu_baseline(pc, budget_s=10.0):
            "sample": "%d videos, oracle/smm_oracle.c log-partition forward + exact backward, OpenMP over the videos of a "
                      "task (%d host threads), %.1f s" % (n_vid, cores, dt)}
     return res, {"logz_videos_checked": n_checked, "logz_max_rel": z_rel, "grad_max_abs": g_abs,
-                 "grad_max_err_over_tol": g_tol,
-                 "grad_tolerance": "|got - ref| <= 2e-5 + 2e-5 |ref| (the tests' rtol = atol; expected transition counts reach 1e2..1e3)"}
+                 "grad_max_rel": g_rel, "grad_max_err_over_tol": g_tol,
+                 "grad_tolerance": "grad_max_rel = max |got - ref| / max(1, |ref|): the path's tolerance is 1e-4 on posteriors "
+                                   "(SURVEY 8c(3); a gradient entry is a sum of posteriors, an expected count of up to ~1e3); "
+                                   "grad_max_err_over_tol measures against the unit tests' tighter rtol = atol = 2e-5"}
 
 
 def pmc_traffic(workload):

@@ -196,8 +196,10 @@ int smm_band_probe(const double *elp, int t, int c, const double *trans, const d
 
 /*
  * Third probe: the banded push AS BUILT (smm_viterbi.hip, BAND mode).  Band 0 = lengths 9..127, always evaluated.
- * Band m = 1..8 covers lengths 16+112m .. 127+112m with sources delayed by 112m; tests per group of `grp` sources:
- *   skip (state c, band m, undelayed group g)  iff  hmax[g - 112m/grp] + lenmax[m]  <=  hmax[g-1] + min_{17<=k<=grp+142} len[k]
+ * Band m = 1..8 covers lengths 16+112m .. 127+112m with sources delayed by 112m; tests per group of `grp` sources; the
+ * witness of the lower bound is the group before the last one (the last one is still being pushed when the decision
+ * is due):
+ *   skip (state c, band m, undelayed group g)  iff  hmax[g - 112m/grp] + lenmax[m]  <=  hmax[g-2] + min_{2 grp + 1 <= k <= 3 grp + 126} len[k]
  * out[0] = band-groups with sources (m >= 1), out[1] = evaluated, out[2] = activation edges (inactive -> active),
  * out[3] = cells of the lattice, out[4] = cells evaluated (bands) + band 0 + chain lengths.
  */
@@ -234,10 +236,10 @@ int smm_band_probe2(const double *elp, int t, int c, const double *trans, const 
             for (int s = g * grp; s < g * grp + grp && s < t; ++s) m = dmax(m, h[(size_t)s * c + j]);
             hmax[(size_t)g * c + j] = m;
         }
-    const int reach = grp + grp - 1 + 127;        /* n - witness <= grp + (grp - 1) + 127 */
+    const int reach = 2 * grp + grp - 1 + 127;    /* n - witness <= 2 grp + (grp - 1) + 127 */
     for (int j = 0; j < c; ++j) {
         double lmin = INFINITY;
-        for (int k = 17; k <= reach && k <= kp - 1; ++k) lmin = dmin(lmin, len[(size_t)k * c + j]);
+        for (int k = 2 * grp + 1; k <= reach && k <= kp - 1; ++k) lmin = dmin(lmin, len[(size_t)k * c + j]);
         if (reach > kp - 1) lmin = -INFINITY;
         for (int m = 1; m <= 8; ++m) {
             double lm = -INFINITY;
@@ -248,7 +250,7 @@ int smm_band_probe2(const double *elp, int t, int c, const double *trans, const 
                 if (s0 + grp - 1 < 0) continue;
                 const int ga = (s0 < 0 ? 0 : s0) / grp, gb = (s0 + grp - 1) / grp;
                 double hm = dmax(hmax[(size_t)ga * c + j], hmax[(size_t)gb * c + j]);
-                const double lb = (g >= 1) ? hmax[(size_t)(g - 1) * c + j] + lmin : -INFINITY;
+                const double lb = (g >= 2) ? hmax[(size_t)(g - 2) * c + j] + lmin : -INFINITY;
                 out[0] += 1.0;
                 const int act = hm + lm > lb;
                 if (act) {

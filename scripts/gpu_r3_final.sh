@@ -1,0 +1,70 @@
+# round 3 acceptance pass: smoke, GPU suite, bench lines (cfg3 default, cfg2, cfg1, cfg4, refdef, cfg5 strong leg on one rank over a
+# one-rank RCCL group, a 2-rank gloo rehearsal), rocprofv3 kernel stats + PMC passes of the default bench, SQ counters, B1 series
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T=r3_final
+python -c "import __graft_entry__ as g; g.smoke()"
+timeout -k 10 900 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/${T}_pytest.log 2>&1 ; echo "all tests rc=$?"
+tail -14 gpurun_out/${T}_pytest.log
+timeout -k 10 600 python bench.py --steps 20 --warmup 3 2>gpurun_out/${T}_cfg3.err | tail -1 > gpurun_out/${T}_cfg3.json
+timeout -k 10 600 python bench.py --workload cfg2 --steps 20 --warmup 3 2>gpurun_out/${T}_cfg2.err | tail -1 > gpurun_out/${T}_cfg2.json
+timeout -k 10 600 python bench.py --workload cfg1 --steps 20 --warmup 3 2>gpurun_out/${T}_cfg1.err | tail -1 > gpurun_out/${T}_cfg1.json
+timeout -k 10 600 python bench.py --workload cfg4 --steps 20 --warmup 3 2>gpurun_out/${T}_cfg4.err | tail -1 > gpurun_out/${T}_cfg4.json
+timeout -k 10 600 python bench.py --workload refdef --steps 20 --warmup 3 --no-predict-e2e 2>gpurun_out/${T}_refdef.err | tail -1 > gpurun_out/${T}_refdef.json
+SMM_DIST_SINGLE_RANK=1 timeout -k 10 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-predict-e2e --strong-leg --scaling strong 2>gpurun_out/${T}_cfg5.err | tail -1 > gpurun_out/${T}_cfg5_strong_1rank_rccl.json
+timeout -k 10 900 python bench.py --gpus 2 --backend gloo --share-gpus --steps 3 --warmup 1 --no-cpu-baseline --strong-workload cfg3 2>gpurun_out/${T}_2r.err | tail -1 > gpurun_out/${T}_2ranks_gloo_rehearsal.json
+rm -rf gpurun_out/prof_cfg3 gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/prof_cfg4 gpurun_out/pmc_sq
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg3 -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-predict-e2e > gpurun_out/prof_cfg3.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-predict-e2e --second-seed -1 > gpurun_out/pmc_$c.log 2>&1
+done
+python scripts/pmc_summary.py gpurun_out cfg3 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of \`python bench.py --steps 2 --warmup 1\` (scripts/gpu_r3_final.sh), kernels as of commit ${SMM_COMMIT:-unknown}" > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg4 -- python bench.py --workload cfg4 --steps 5 --warmup 1 --no-cpu-baseline --no-predict-e2e > gpurun_out/prof_cfg4.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-predict-e2e --no-strong-leg --second-seed -1 > gpurun_out/pmc_sq.log 2>&1
+python - > gpurun_out/${T}_sq_counters.txt <<'PY'
+import csv, glob, collections
+rows = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for f in glob.glob('gpurun_out/pmc_sq/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'][:70]
+        if 'smm_' not in k: continue
+        rows[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Counter_Name'] == 'SQ_WAVES': cnt[k] += 1
+for k, d in rows.items():
+    n = cnt[k] or 1
+    print(k, 'launches', n, {c: round(v / n) for c, v in d.items()})
+PY
+cat gpurun_out/${T}_sq_counters.txt
+timeout -k 10 900 python scripts/b1_series.py 150 > gpurun_out/${T}_b1_series.txt 2>&1; echo "b1 rc=$?"
+timeout -k 10 200 python scripts/probe_predict_cfg4.py > gpurun_out/${T}_probe_predict_cfg4.txt 2>&1
+timeout -k 10 200 python scripts/probe_small.py > gpurun_out/${T}_probe_small.txt 2>&1
+python - <<'PY'
+import json, csv, glob
+T = 'r3_final'
+for w in ('cfg3', 'cfg2', 'cfg1', 'cfg4', 'refdef'):
+    try:
+        r = json.load(open('gpurun_out/%s_%s.json' % (T, w)))
+        print(w, round(r['value']/1e6, 1), 'Mframes/s', round(r['ms_per_step'], 3), 'ms/step dp_ms', round(r['roofline']['kernel_ms'], 3),
+              'frac', round(r['roofline']['frac'], 4), 'mof', round(r['mof'], 4), 'cpu', r.get('cpu_baseline', {}).get('value'), r.get('cpu_factored', {}).get('value'),
+              'parity', {k: v for k, v in r.get('parity', {}).items() if k not in ('what', 'grad_tolerance')})
+    except Exception as e:
+        print(w, 'failed', e)
+r = json.load(open('gpurun_out/%s_cfg3.json' % T))
+for k in ('predict_end_to_end', 'host_features', 'reference_default', 'other_draw', 'evaluation', 'fit_stats'):
+    v = r.get(k)
+    if isinstance(v, dict): v = {a: b for a, b in v.items() if a not in ('what', 'stats', 'roofline')}
+    print(k, v)
+r = json.load(open('gpurun_out/%s_cfg4.json' % T)); print('cfg4 e2e', r.get('predict_end_to_end')); print('cfg4 logz', json.dumps(r.get('logz_fwd_bwd'))[:900])
+r = json.load(open('gpurun_out/%s_cfg5_strong_1rank_rccl.json' % T)); print('cfg5 strong 1 rank', r['scaling'], r['value'], json.dumps(r.get('strong_scaling'))[:600])
+r = json.load(open('gpurun_out/%s_2ranks_gloo_rehearsal.json' % T)); print('2 ranks (gloo, shared GPU)', r['n_gpus'], r['scaling'], r['value'])
+for w in ('cfg3', 'cfg4'):
+    f = glob.glob('gpurun_out/prof_%s/**/*kernel_stats.csv' % w, recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r['TotalDurationNs']))
+    for r in rows:
+        if 'smm_' in r['Name']:
+            print(w, r['Name'][:70], '| calls', r['Calls'], '| avg_us', round(float(r['AverageNs'])/1e3, 1))
+print(open('gpurun_out/pmc_summary.json').read()[:200])
+PY

@@ -13,7 +13,8 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             key = name.split('(')[0].replace('void ', '')
             # the DP kernel's recovery launches (template argument PAIR = 0 behind a gang launch: two empty grids per
             # decode) are their own rows; everything else is keyed without template arguments
-            if key.startswith('smm_viterbi_kernel') and not key.rstrip('>').endswith(', 1'):
+            # (PAIR = 1: gang launch, PAIR = 2: BAND mode -- the main DP kernels)
+            if key.startswith('smm_viterbi_kernel') and not key.rstrip('>').endswith((', 1', ', 2')):
                 key = 'smm_viterbi_kernel (recovery / non-gang launches)'
             else:
                 key = key.split('<')[0]

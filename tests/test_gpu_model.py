@@ -37,7 +37,7 @@ def oracle_predictions(data, args, model):
         cons = cons_fn(b) if cons_fn else None
         addl = model.make_additional_allowed_ends(b['task_name'], b['lengths'])
         r = O.viterbi_full(p, b['features'].double(), b['lengths'], b['task_indices'][0], True, addl,
-                           None if cons is None else cons.double())
+                           None if cons is None else cons.cpu().double())
         lab = O.spans_to_labels(r['spans'].numpy())
         for i, (name, t) in enumerate(zip(b['video_name'], b['lengths'].tolist())):
             preds[name] = lab[i, :t]

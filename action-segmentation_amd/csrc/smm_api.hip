@@ -168,10 +168,12 @@ struct Staged {
     bool band_mode;        // Viterbi: BAND mode (one workgroup per video, exact band skipping) instead of 1024-slot rings / gangs
     int32_t *pair_flags;
     int32_t *em_cum;       // emission: workgroups before each video of `order` ([b + 1])
+    std::vector<int32_t> em_cum_host;   // (decode split: the same table on the host)
     int em_tpw, em_blocks;
     int kp_max, c_need;
     int n_pairs;           // Viterbi only: the first n_pairs videos of `order` may run on two CUs each
     bool pairs_cover_big;  // every video with more than 21 states is among them
+    int n_split;           // decode only: the first n_split videos of `order` are the launch's critical path (0: no split)
 };
 
 // Gangs of two or three CUs for the most expensive videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the
@@ -312,9 +314,39 @@ static bool band_mode(int kp_max, int c_need);
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
 // want_gangs: plan gangs for the Viterbi kernel (a list-schedule simulation, ~0.3 ms of host time at 360 videos: only
 // the entry points that launch that kernel ask for it)
+// Split of a decode (smm_decode_f32) into [critical videos | the rest].  The DP kernel's time is the time of the launch's
+// longest videos (one workgroup each, ~0.3 us per frame), while the emission scorer in front of it streams EVERY video's
+// features (0.6 ms on cfg3).  With the few longest videos scored first, their DP can start at once and the rest of the
+// corpus is scored -- and then decoded -- on a second stream beside it: the second part must be through before the first
+// is, i.e. its longest video has to be shorter than the launch's longest by the time the emission scorer takes.
+// Returns how many videos of `order` (reordered: critical ones first, both parts keep their order) form the first part;
+// 0: no split (few videos, a flat length distribution, or nothing to hide).
+static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_max, int64_t total_frames)
+{
+    if (b < 24 || std::getenv("SMM_NO_SPLIT")) return 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n_cu = 0;
+        if (n_cu <= 0) { n_cu = 0; return 0; }
+    }
+    const double em_us = (double)total_frames * (4.0 * d + 8.0 * c_max) / 4.0e6;      // ~4 TB/s of algorithmic bytes
+    const char *mn = std::getenv("SMM_SPLIT_MIN_US");                                  // (test hook: split small launches too)
+    if (em_us < (mn ? std::atof(mn) : 100.0)) return 0;
+    int tmax = 0;
+    for (int i = 0; i < b; ++i) tmax = std::max(tmax, hv[i].T);
+    const int thr = tmax - (int)(1.15 * em_us * 1000.0 / 300.0) - 400;                 // (~300 ns per frame of DP)
+    int n1 = 0;
+    for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
+    if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16) return 0;
+    std::stable_partition(order, order + b, [&](int32_t v) { return hv[v].T >= thr; });
+    return n1;
+}
+
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                  const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                 bool want_gangs = false, int cum_chunk = 0)
+                 bool want_gangs = false, int cum_chunk = 0, bool want_split = false)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
     if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
@@ -364,6 +396,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     out->pairs_cover_big = false;
     out->band_mode = want_gangs && band_mode(kp_max, c_need);
     if (want_gangs && !out->band_mode) out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
+    out->n_split = (want_split && out->n_pairs == 0) ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
     {
         // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
         int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
@@ -377,6 +410,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
         if (cum > 0x7fffffff) return SMM_ERR_UNSUPPORTED;
         hc[s->b] = (int32_t)cum;
         out->em_blocks = (int)cum;
+        if (out->n_split > 0) out->em_cum_host.assign(hc, hc + s->b + 1);
     }
 
     char *base = static_cast<char *>(ws);
@@ -418,20 +452,26 @@ static int ring_regs(int kp_max)
 
 // ------------------------------------------------------------------------------------------------ pieces
 static int run_emission(const smm_shape *s, const Staged &st, const float *x, const double *w, const double *cst,
-                        const double *inv_var, const float *cons, double *elp64, float *elp32, hipStream_t stream)
+                        const double *inv_var, const float *cons, double *elp64, float *elp32, hipStream_t stream,
+                        int first = 0, int count = -1)
 {
     if (!x || !w || !cst || !inv_var || s->d < 1 || (!elp64 && !elp32)) return SMM_ERR_ARG;
     if ((size_t)((s->d + 15) & ~15) * (st.c_need <= 16 ? 21 : 37) * sizeof(double) > 160 * 1024)
         return SMM_ERR_UNSUPPORTED;   // the group's weight table must fit the CU's LDS (D <= 640 at 32 states)
     SmmEmArgs a{st.videos, st.order, st.n_states, x, w, cst, inv_var, cons, elp64, elp32, s->d, s->c_max, s->b};
-    smm_launch_emission(a, st.c_need, st.em_tpw, st.em_blocks, st.em_cum, s->total_frames, stream);
+    if (count < 0) smm_launch_emission(a, st.c_need, st.em_tpw, st.em_blocks, st.em_cum, s->total_frames, stream);
+    else smm_launch_emission(a, st.c_need, st.em_tpw, st.em_cum_host[first + count] - st.em_cum_host[first], st.em_cum,
+                             s->total_frames, stream, st.em_cum_host[first], first, count);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }
 
+// first / count: only the videos order[first .. first + count) (count < 0: all); prep: launch the band tables kernel (a
+// split decode launches it once, in front of both parts)
 static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, const double *trans, const double *init,
                        const double *len_scores, const double *endpen, const int64_t *class_map, int64_t *spans,
-                       int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream)
+                       int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream, int first = 0, int count = -1,
+                       bool prep = true, bool launch = true)
 {
     if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
     SmmDpArgs a{};
@@ -440,6 +480,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     a.elp = elp; a.trans = trans; a.init = init; a.len = len_scores; a.endpen = no_eos ? nullptr : endpen; a.class_map = class_map;
     a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
     a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
+    if (count >= 0) { a.order = st.order + first; a.b = count; }
     {
         const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling / test aid, see SmmDpArgs::flags
         a.flags = dbg ? std::atoi(dbg) : 0;
@@ -450,7 +491,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     if (st.pairs_cover_big) a.flags |= 4;
     if (st.band_mode) {
         double *len_t = st.band, *band_tab = st.band + (size_t)s->n_groups * s->c_max * SMM_BAND_ROW;
-        smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, s->n_groups, s->c_max, s->k_rows, stream);
+        if (prep) smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, s->n_groups, s->c_max, s->k_rows, stream);
         a.len_t = len_t;
         a.band_tab = band_tab;
         a.flags |= 128;
@@ -463,6 +504,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         const size_t bytes = sizeof(double) * ((size_t)3 * w + st.c_need + st.kp_max) * st.c_need;
         if (bytes <= 126 * 1024) { a.bt_window = w; a.bt_dyn_bytes = (int32_t)bytes; }
     }
+    if (!launch) { SMM_HIP(hipGetLastError()); return SMM_OK; }      // (prep only)
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
     if (rc != SMM_OK) return rc;
     // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant
@@ -546,6 +588,26 @@ extern "C" int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_ho
     return run_viterbi(shape, st, st.elp, t64, i64, l64, endpen ? e64 : nullptr, class_map, spans, labels, best, n_segs, hs);
 }
 
+// The second stream of a split decode: one per device, created on first use with the lowest priority (the critical videos'
+// DP on the caller's stream goes first), never destroyed.  It is the one piece of state the library keeps; every use is
+// bracketed by events on the caller's stream, so from the caller's point of view the call is still ordered on ITS stream
+// (and captures into a hipGraph like before: the event wait pulls the second stream into the capture).
+#include <mutex>
+static hipStream_t aux_stream()
+{
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[dev]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least) != hipSuccess) streams[dev] = nullptr;
+    }
+    return streams[dev];
+}
+
 extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
                               const int32_t *group_host, const int32_t *kp_host, const int32_t *n_states_host,
                               const float *x, const double *w, const double *cst, const double *inv_var, const float *cons,
@@ -556,11 +618,35 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     Staged st;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
-                   hs, &st, true);
+                   hs, &st, true, 0, true);
     if (rc != SMM_OK) return rc;
-    rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs);
+    hipStream_t aux = st.n_split > 0 ? aux_stream() : nullptr;
+    if (!aux) {
+        rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs);
+        if (rc != SMM_OK) return rc;
+        return run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
+    }
+    // split decode (choose_split): [band tables, emission of the critical videos] on the caller's stream, then their DP
+    // there, while the second stream scores and decodes the rest; the caller's stream waits for it at the end
+    const int n1 = st.n_split, n2 = shape->b - st.n_split;
+    rc = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs, 0, n1, true, false);
     if (rc != SMM_OK) return rc;
-    return run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs);
+    rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs, 0, n1);
+    if (rc != SMM_OK) return rc;
+    hipEvent_t fork = nullptr, join = nullptr;
+    SMM_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    SMM_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    int rc2 = SMM_OK;
+    if (hipEventRecord(fork, hs) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) rc2 = SMM_ERR_HIP;
+    if (rc2 == SMM_OK) rc2 = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, aux, n1, n2);
+    if (rc2 == SMM_OK)
+        rc2 = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, aux, n1, n2, false);
+    rc = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs, 0, n1, false);
+    // the join is made even after an error on the way, so that the caller's stream never runs ahead of the second one
+    if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(hs, join, 0) != hipSuccess) rc2 = SMM_ERR_HIP;
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
+    return rc != SMM_OK ? rc : rc2;
 }
 
 extern "C" int smm_logz_f64(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(SMM_EM_WAVES * 64)
 smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
                     const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                     const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
-                    float *__restrict__ elp32, int D, int cm, int tpw, const int32_t *__restrict__ blk_cum, int nvid)
+                    float *__restrict__ elp32, int D, int cm, int tpw, const int32_t *__restrict__ blk_cum, int nvid, int blk_base)
 {
     // LDS: this group's weights (zero padded), row d = w[d][0 .. 16 NT), then inv_var[D16].  Row stride 20 (NT = 1) /
     // 36 (NT = 2) doubles: rows 4 apart -- the two k groups of a ds_read_b64 half-wave -- land 128 B apart modulo the
@@ -66,8 +66,11 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     // profiles/round2_ubench_mfma_f64_4x4.txt): 21..24 states cost 96 cycles instead of 128, 17..20 cost 80.
     extern __shared__ __attribute__((aligned(16))) double wl[];
     // flat grid: blk_cum[i] = workgroups of the videos order[0..i) (longest videos first: no long workgroup starts late)
-    const int slot = smm_em_find_video(blk_cum, nvid, blockIdx.x);
-    const int chunk = blockIdx.x - blk_cum[slot];
+    // (blk_base: a launch may cover only the videos order[v0 .. v0 + nvid) -- blk_cum and order arrive offset by v0 and the
+    // cumulative block counts stay absolute)
+    const int bid = blockIdx.x + blk_base;
+    const int slot = smm_em_find_video(blk_cum, nvid, bid);
+    const int chunk = bid - blk_cum[slot];
     const int vid = order[slot];
     const SmmVideo mv = videos[vid];
     const int T = mv.T, g = mv.group;
@@ -282,11 +285,14 @@ smm_emission_lds_kernel(const SmmVideo *__restrict__ videos, const int32_t *__re
                         const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
                         const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
                         float *__restrict__ elp32, int D, int cm, int RS, int64_t x_floats,
-                        const int32_t *__restrict__ blk_cum, int nvid)
+                        const int32_t *__restrict__ blk_cum, int nvid, int blk_base)
 {
     extern __shared__ __attribute__((aligned(16))) double wl[];
-    const int slot = smm_em_find_video(blk_cum, nvid, blockIdx.x);
-    const int chunk = blockIdx.x - blk_cum[slot];
+    // (blk_base: a launch may cover only the videos order[v0 .. v0 + nvid) -- blk_cum and order arrive offset by v0 and the
+    // cumulative block counts stay absolute)
+    const int bid = blockIdx.x + blk_base;
+    const int slot = smm_em_find_video(blk_cum, nvid, bid);
+    const int chunk = bid - blk_cum[slot];
     const int vid = order[slot];
     const SmmVideo mv = videos[vid];
     const int T = mv.T, g = mv.group;
@@ -470,8 +476,14 @@ int smm_emission_blocks(int t, int tpw)
 }
 
 void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
-                         hipStream_t stream)
+                         hipStream_t stream, int blk_base, int vid0, int nvid)
 {
+    // blk_base / vid0 / nvid: only the videos order[vid0 .. vid0 + nvid) = the workgroups blk_base .. blk_base + n_blocks
+    // of the flat grid (nvid < 0: all of them)
+    if (nvid < 0) { vid0 = 0; nvid = a.b; blk_base = 0; }
+    if (n_blocks <= 0 || nvid <= 0) return;
+    const int32_t *order_v = a.order + vid0;
+    blk_cum += vid0;
     const int d16 = (a.d + 15) & ~15;
     dim3 grid(n_blocks), block(SMM_EM_WAVES * 64);
     const size_t lds_w = sizeof(double) * d16 * (ct <= 16 ? 21 : 37);        // weights (row stride 20 / 36) + inv_var
@@ -490,15 +502,15 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
     auto go1 = [&](auto kern) {
         if (lds_w > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-        hipLaunchKernelGGL(kern, grid, block, lds_w, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
-                           a.elp64, a.elp32, a.d, a.c_max, tpw, blk_cum, a.b);
+        hipLaunchKernelGGL(kern, grid, block, lds_w, stream, a.videos, order_v, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
+                           a.elp64, a.elp32, a.d, a.c_max, tpw, blk_cum, nvid, blk_base);
     };
     auto go2 = [&](auto kern) {
         const size_t lds = lds_w2 + lds_x;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, a.order, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
-                           a.elp64, a.elp32, a.d, a.c_max, rs, (int64_t)total_frames * a.d, blk_cum, a.b);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, order_v, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
+                           a.elp64, a.elp32, a.d, a.c_max, rs, (int64_t)total_frames * a.d, blk_cum, nvid, blk_base);
     };
     if (v2) {
 #define SMM_EM_V2(NLD_)                                                                         \

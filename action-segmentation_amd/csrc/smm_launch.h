@@ -28,7 +28,7 @@ int smm_zero_async(void *dst_dev, size_t bytes, hipStream_t stream);
 int smm_emission_tiles_per_wave(int64_t total_frames, int b);
 int smm_emission_blocks(int t, int tpw);
 void smm_launch_emission(const SmmEmArgs &a, int c_need, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
-                         hipStream_t stream);
+                         hipStream_t stream, int blk_base = 0, int vid0 = 0, int nvid = -1);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);
 
 // chain rule through the emission scorer (smm_emission.hip): outputs must be zero at launch

@@ -1432,16 +1432,23 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
     const bool live = c < n_states[g];
     for (int k = threadIdx.x; k < SMM_BAND_ROW; k += blockDim.x)
         dst[k] = (live && k >= 1 && k - 1 < k_rows) ? src[(size_t)(k - 1) * cm] : SMM_NEG_INF;
-    if (threadIdx.x <= SMM_BAND_N) {
-        const int m = threadIdx.x;
+    // nine bounds per state, a wave each (lanes stride over the lengths, then a butterfly): this kernel sits in front of the
+    // DP kernel on the critical path of every decode (nine serial loops of ~140 strided loads took 35 us)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    for (int m = wv; m <= SMM_BAND_N; m += 4) {
         const int k0 = m ? SMM_BAND_LO + SMM_BAND_DELAY * m : 33, k1 = m ? 127 + SMM_BAND_DELAY * m : 174;
         double v = m ? SMM_NEG_INF : __builtin_huge_val();
-        for (int k = k0; k <= k1 && k < k_rows; ++k) {
+        for (int k = k0 + ln; k <= k1 && k < k_rows; k += 64) {
             const double x = src[(size_t)k * cm];
             v = m ? fmax(v, x) : fmin(v, x);
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(v, off);
+            v = m ? fmax(v, o) : fmin(v, o);
+        }
         if (!live) v = SMM_NEG_INF;
-        band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + m] = v;
+        if (ln == 0) band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + m] = v;
     }
 }
 

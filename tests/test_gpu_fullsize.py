@@ -259,3 +259,18 @@ def test_cfg3_whole_corpus_one_ragged_launch_equals_the_twin():
     _, par = bench.cpu_factored(pc, model, gpu_labels=labels, budget_s=1e9)
     assert par['videos_checked'] == 360 and par['frames_checked'] == pc.n_frames
     assert par['label_mismatches'] == 0
+
+
+@pytest.mark.parametrize('k', [1024, 64])
+def test_split_decode_equals_single_stream_decode_and_the_twin(k, monkeypatch):
+    """smm_decode_f32 splits a launch whose few longest videos set the DP's time: those are scored and decoded on the
+    caller's stream, the rest on a second stream beside them (smm_api.hip: choose_split).  Same labels, spans and scores
+    as the single-stream decode and as the twin."""
+    monkeypatch.setenv('SMM_SPLIT_MIN_US', '0')
+    cp = make_corpus(91, [5000, 4800, 4700] + [1200 + 13 * i for i in range(40)], 9, k, rate=(20, 200) if k > 64 else (5, 40))
+    res = decode_both(cp)
+    check_equivalent(cp, *res)
+    monkeypatch.setenv('SMM_NO_SPLIT', '1')
+    one = decode_both(cp)
+    for key in ('spans', 'labels', 'best', 'n_segs'):
+        np.testing.assert_array_equal(res[0][key].cpu().numpy(), one[0][key].cpu().numpy())

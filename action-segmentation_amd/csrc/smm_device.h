@@ -39,7 +39,7 @@ struct SmmDpArgs {
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
     int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] gangs that timed out, [2] gangs repaired;
-                               // [3] Viterbi BAND mode, diagnostic: delayed band-blocks (4 sources x one band of one state) evaluated
+                               // [3] Viterbi BAND mode, diagnostic: delayed band-blocks (the sources of one hand-over block, 8 or under SMM_BAND_B=4 4, x one band of one state) evaluated
     int32_t c_max, k_rows, t_max, b;
     int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
                                // backward; bit 2: every video with more than 21 states is in the paired prefix;

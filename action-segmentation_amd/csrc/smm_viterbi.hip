@@ -45,7 +45,7 @@
 // block barrier and arriving at the next one ("busy") and cycles spent in the barrier, summed over the blocks and
 // written behind the workspace's error word (uint64 slots 8+w and 24+w; slot 7 = number of blocks).
 #ifdef SMM_PROFILE
-#define SMM_PROF_DECL unsigned long long p_busy = 0, p_wait = 0, p_t0 = __builtin_readcyclecounter()
+#define SMM_PROF_DECL unsigned long long p_busy = 0, p_wait = 0, p_t0 = __builtin_readcyclecounter(), p_ph[4] = {0, 0, 0, 0}, p_mx = 0
 #define SMM_BLOCK_BARRIER()                                                        \
     do {                                                                          \
         const unsigned long long t1 = __builtin_readcyclecounter();               \
@@ -58,12 +58,17 @@
         const unsigned long long t1 = __builtin_readcyclecounter();               \
         smm_lds_barrier();                                                        \
         const unsigned long long t2 = __builtin_readcyclecounter();               \
-        p_busy += t1 - p_t0; p_wait += t2 - t1; p_t0 = t2;                        \
+        p_busy += t1 - p_t0; p_wait += t2 - t1;                                   \
+        if (SMM_PROFILE == 2) { if (t2 - t1 < 150) { p_mx += 1; p_ph[jj & 3] += 1; p_ph[0] += (t1 - p_t0) << 20; } } \
+        else { p_ph[jj & 3] += t1 - p_t0; p_mx = (t1 - p_t0 > p_mx) ? t1 - p_t0 : p_mx; } \
+        p_t0 = t2;                                                                \
     } while (0)
+// (BAND mode, 8 waves: slots 16+w = the longest block, 32+4w+ph = busy cycles of the blocks with j mod 4 = ph)
 #define SMM_PROF_OUT()                                                            \
     if (blockIdx.x == 0 && lane == 0) {                                           \
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err);   \
         pp[8 + w] = p_busy; pp[24 + w] = p_wait; pp[7] = (unsigned long long)J;   \
+        if (BAND) { pp[16 + w] = p_mx; for (int ph = 0; ph < 4; ++ph) pp[32 + 4 * w + ph] = p_ph[ph]; } \
     }
 #else
 #define SMM_PROF_DECL do { } while (0)
@@ -89,6 +94,17 @@ __device__ __forceinline__ void smm_lds_barrier()
 #endif
 #ifndef SMM_D
 #define SMM_D 1
+#endif
+#ifndef SMM_PF2
+#define SMM_PF2 0      // 1: the mover wave's elp rows are in flight for two blocks instead of one
+#endif
+#ifndef SMM_BAND_LDSB
+#define SMM_BAND_LDSB 0   // 1 (experiment): BAND pushers read every source row with every lane (no broadcast instruction, 16x the LDS traffic)
+#endif
+#ifndef SMM_ABLATE
+#define SMM_ABLATE 0   // development builds only (results are WRONG, timing experiments): bit 0 chain wave without the
+                       // candidates k = 2..K0, bit 1 without the cumE add / store, bit 2 pushers push nothing, bit 3 mover
+                       // keeps no books, bit 4 transition over a third of the sources
 #endif
 #ifndef SMM_B8_MAX_R
 #define SMM_B8_MAX_R 0   // (experiment: blocks of 8 positions for rings of up to 64 * this many slots; measured 5-9 % slower)
@@ -450,6 +466,23 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 // off = B + D - t (odd).  The state-major table is stored shifted by one (row[k + 1] = len[k]) so that a lane's two
 // lengths are one aligned 16-byte load; a delayed band keeps NO ring between blocks -- it is read again from the table
 // (8 KB per state, L1-resident while the state is active) at the phase of every block it is switched on for.
+// Lane N of every row of 16 lanes, broadcast to its row (one v_mov_b64_dpp row_newbcast: the only DPP control the 64-bit
+// ALU takes).
+__device__ __forceinline__ double smm_row_bcast(double x, int n)   // n: a constant after unrolling (the switch folds away)
+{
+    // (`old` is never read -- every lane is written -- but an operand tied to x would cost a copy of x per broadcast:
+    // a fresh undefined register instead)
+    double u;
+    asm volatile("" : "=v"(u));
+#define SMM_RB(k) case k: return __builtin_amdgcn_update_dpp(u, x, 0x150 + k, 0xf, 0xf, false);
+    switch (n & 15) {
+        SMM_RB(0) SMM_RB(1) SMM_RB(2) SMM_RB(3) SMM_RB(4) SMM_RB(5) SMM_RB(6) SMM_RB(7)
+        SMM_RB(8) SMM_RB(9) SMM_RB(10) SMM_RB(11) SMM_RB(12) SMM_RB(13) SMM_RB(14)
+        default: return __builtin_amdgcn_update_dpp(u, x, 0x150 + 15, 0xf, 0xf, false);
+    }
+#undef SMM_RB
+}
+
 __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double *lent_row, int off, int m, int kp, int lane)
 {
     const int kr0 = (lane * 2 + off) & 127;                       // odd; kr0 = 127: the second slot wraps to 0 (masked)
@@ -476,7 +509,9 @@ template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    static_assert(!PAIR || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair / band mode: K <= 1024, 8 waves");
+    static_assert(PAIR != 1 || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair mode: K <= 1024, 8 waves");
+    static_assert(PAIR != 2 || (R == 16 && NW == 8 && CP == 0 && ((B == 4 && D == 1) || (B == 8 && D == 0))),
+                  "band mode: K <= 1024, 8 waves, blocks of 4 (pushers lag a source) or 8 positions");
     constexpr bool GANG = PAIR == 1, BAND = PAIR == 2;
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
@@ -647,15 +682,16 @@ smm_viterbi_kernel(SmmDpArgs a)
                 // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
                 auto partial = [&](int i) {                  // max(A'[n], max_{k=2..K0} h[n-k] + len[k]), n = jB+1+i
                     double sq[K0 + 1];
+                    double acc = ap[i];
+                    if constexpr (SMM_ABLATE & 1) return acc;
 #pragma unroll
                     for (int k = 2; k <= K0; ++k) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
-                    double acc = ap[i];
 #pragma unroll
                     for (int k = K0; k >= 2; --k) acc = smm_fmax(acc, sq[k]);
                     return acc;
                 };
                 double pacc = partial(0);
-                double cumn = cum + ev[0];
+                double cumn = (SMM_ABLATE & 2) ? ev[0] : cum + ev[0];
 #pragma unroll
                 for (int i = 0; i < B; ++i) {
                     // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
@@ -674,23 +710,23 @@ smm_viterbi_kernel(SmmDpArgs a)
                     // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
                     if constexpr (GAMROW) st_gam[0] = gm;
                     st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
-                    st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
+                    if constexpr (!(SMM_ABLATE & 2)) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
                     if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
                     if (TAILFREE || n < T) {
                         // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
                         const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HF] : &sh_g[jj & 1][i][half * HF]);
                         double2 gv[HF / 2];
 #pragma unroll
-                        for (int q = 0; q < HF / 2; ++q) gv[q] = gp[q];
+                        for (int q = 0; q < HF / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
                         __builtin_amdgcn_sched_barrier(0);
                         if (i + 1 < B) {
                             pacc = partial(i + 1 < B ? i + 1 : 0);
-                            cumn = cum + ev[i + 1 < B ? i + 1 : 0];
+                            cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         double bq[4];                                // 4 independent max chains
 #pragma unroll
-                        for (int q = 0; q < HF / 2; ++q) {
+                        for (int q = 0; q < ((SMM_ABLATE & 16) ? 2 : HF / 2); ++q) {
                             if (q < 2) {
                                 bq[2 * q] = gv[q].x + tr[2 * q];
                                 bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
@@ -867,7 +903,29 @@ smm_viterbi_kernel(SmmDpArgs a)
         const double *lent = a.len_t + (size_t)g * cm * SMM_BAND_ROW;       // [c][k + 1]: a state's lengths are contiguous
         const double *btab = a.band_tab + (size_t)g * cm * SMM_BAND_TAB;
         const bool bound_ok = kp - 1 >= 32 + 15 + 127;                       // the lower bound's witness needs lengths up to 174
-        double As[SPS][RS], L0[SPS][RS], hds[SPS];
+        double As[SPS][RS], L0[SPS][RS];
+        // The rows a wave pushes (its states' h of the block, B x SPS values) come from LDS with ONE read per 16 values:
+        // lane e % 16 of every row of register e / 16 holds element e = B js + i, and a push broadcasts its source along
+        // the rows (smm_row_bcast).  Every lane reading every value (a ds_read2_b64 per state and pair of rows) was 16
+        // times the LDS traffic, in one burst of all pusher waves right behind the barrier, in front of the chain wave's
+        // own reads.
+        constexpr int NHR = (SPS * B + 15) / 16;
+        // A group (the unit of the skip test) is 16 sources = BPG blocks; block j pushes the sources (j-1)B + 1 - D ..
+        // jB - D, so group g = sources 16g + 1 - D .. 16g + 16 - D is pushed in blocks g BPG + 1 .. (g+1) BPG, and the ring
+        // indices 1 .. 2B - 1 + D (= K0) of a push are slots that were handed over already (K0 < SMM_BAND_LO = 16).
+        constexpr int BPG = 16 / B;
+        static_assert(!BAND || (UB == BPG && K0 < SMM_BAND_LO), "a group is one unrolled iteration of the block loop");
+        int hoff[NHR];
+        double hvp[NHR];                                                     // the previous block's rows (D = 1: its last row is pushed first)
+#pragma unroll
+        for (int r = 0; r < NHR; ++r) {
+            const int e = 16 * r + (lane & 15), ejs = e / B, ec = ejs * NPS + rank;
+            hoff[r] = (e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0);
+            hvp[r] = SMM_NEG_INF;
+        }
+        double hdl[SMM_BAND_LDSB ? SPS : 1];
+#pragma unroll
+        for (int js = 0; js < (SMM_BAND_LDSB ? SPS : 1); ++js) hdl[js] = SMM_NEG_INF;
         uint32_t act[SPS];                                                   // bit m-1: band m is switched on for the current group
         uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
 #pragma unroll
@@ -875,7 +933,6 @@ smm_viterbi_kernel(SmmDpArgs a)
             const int c = js * NPS + rank;
             const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
             smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
-            hds[js] = SMM_NEG_INF;
             act[js] = 0;
         }
         // The mover wave also keeps the books of the skip test, one lane per state: max h over every group of 16 sources
@@ -884,7 +941,9 @@ smm_viterbi_kernel(SmmDpArgs a)
         // last one (G - 2: the last one is still being pushed when the decision is due), so the test reads
         //     hm[G - 7m] + max_{band m} len  >  hm[G - 2] + min_{33 <= k <= 174} len      <=>  band m on for group G.
         constexpr int NPASS = SMM_MAX_STATES_DEV / 8;
-        double hmx = SMM_NEG_INF, hdm = SMM_NEG_INF;                         // lane = state: running max, last row of the previous block
+        constexpr int PPB = NPASS / BPG;                                     // decision passes per block
+        static_assert(!BAND || NPASS % BPG == 0, "whole passes per block");
+        double hmx = SMM_NEG_INF, hdm = SMM_NEG_INF;                         // lane = state: running max, last row of the previous block (D = 1)
         double lmx[NPASS], lbm[NPASS];
         if (w == MW) {
 #pragma unroll
@@ -902,6 +961,12 @@ smm_viterbi_kernel(SmmDpArgs a)
         double hq[B];
 #pragma unroll
         for (int i = 0; i < B; ++i) hq[i] = SMM_NEG_INF;
+        constexpr int NPRE = 2;                   // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
+                                                  // (six measured 7 % SLOWER than two: registers and code for a case that is rare)
+        double Lp[NPRE][RS];                      // in ascending 8 js + (m - 1), the order the push loop meets them in
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) { Lp[k][0] = SMM_NEG_INF; Lp[k][1] = SMM_NEG_INF; }
+        int npre = 0, pk = 0;                     // pairs fetched for this block; pairs met so far in this block
         // mover role (wave MW), as in the plain configuration below
         int lo[NE], row[NE];
 #pragma unroll
@@ -910,20 +975,26 @@ smm_viterbi_kernel(SmmDpArgs a)
             row[q] = e / cm;
             lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
         }
-        int slo[NE], srw[NE];
+        int slo[NE], srw[NE], sloc[NE], hloc[NE];                           // (sloc, hloc: the mover's unconditional reads)
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
             const int e = lane + 64 * q;
             srw[q] = e / C;
             slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
+            sloc[q] = slo[q] >= 0 ? slo[q] : 0;
+            hloc[q] = (e / B < C) ? (e % B) * SMM_MAX_STATES_DEV + e / B : 0;
         }
         const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE];
+        double pre[NE], pre2[SMM_PF2 ? NE : 1];
         if (w == MW) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
                 pre[q] = elp[e < e_last ? e : e_last];
+                if constexpr (SMM_PF2) {
+                    const int64_t e2 = e + (int64_t)B * cm;                        // block 2
+                    pre2[SMM_PF2 ? q : 0] = elp[e2 < e_last ? e2 : e_last];
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): tables and rings have arrived
@@ -948,42 +1019,85 @@ smm_viterbi_kernel(SmmDpArgs a)
                 const int j = j0 + jj;
                 if (j >= J) break;
                 if (w == MW) {
+                    // Every LDS read of the block is issued first, unconditionally (clamped offsets), as ONE batch: the
+                    // history rows of block j-1, the rows the pushers push in this block (group maxima), the two group
+                    // maxima of this block's decision pass.  (Reads inside the `if (row <= T)` of each store were
+                    // ds_read / wait / store ten times over: ten LDS round trips, 2200 busy cycles for 80 instructions.)
+                    double hist[3][NE];
+#pragma unroll
+                    for (int x = 0; x < NE; ++x) {
+                        hist[0][x] = (&sh_cum[(jj + 1) & 1][0][0])[sloc[x]];
+                        hist[1][x] = (&sh_h[(jj + 1) & 1][0][0])[hloc[x]];
+                        hist[2][x] = (&sh_g[(jj + 1) & 1][0][0])[sloc[x]];
+                    }
+                    const double *h_blk = &sh_h[(jj + 1) & 1][0][lane & (SMM_MAX_STATES_DEV - 1)];
+                    double hrow[B];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) hrow[i] = h_blk[i * SMM_MAX_STATES_DEV];
+                    // decisions for group G = j/BPG + 1, PPB passes (of 8 states) per block of group G - 1 (all passes in one
+                    // block made that block wait for this wave); hm[G - 2] is complete since the first block of this group
+                    // (that block's passes read it behind its store below)
+                    const int G = j / BPG + 1;
+                    int dc[PPB], gi[PPB];
+                    double hsrc[PPB], hwit[PPB];
+#pragma unroll
+                    for (int pp = 0; pp < PPB; ++pp) {
+                        const int dm = (lane & 7) + 1;
+                        dc[pp] = 8 * (jj * PPB + pp) + (lane >> 3);
+                        gi[pp] = G - 7 * dm;
+                        hsrc[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? (gi[pp] & 63) : 0];
+                        hwit[pp] = SMM_NEG_INF;
+                        if (jj != 0) hwit[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? ((G - 2) & 63) : 0];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
                     for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+                        if (lo[q] >= 0) dst[lo[q]] = (SMM_PF2 && (jj & 1)) ? pre2[SMM_PF2 ? q : 0] : pre[q];
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
-                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                        pre[q] = elp[e < e_last ? e : e_last];
+                        if constexpr (SMM_PF2) {                               // in flight for two blocks (buffers by block parity)
+                            const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
+                            if (jj & 1) pre2[SMM_PF2 ? q : 0] = elp[e < e_last ? e : e_last];
+                            else pre[q] = elp[e < e_last ? e : e_last];
+                        } else {
+                            const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                            pre[q] = elp[e < e_last ? e : e_last];
+                        }
                     }
                     if (j >= 1) {
-                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
-                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
-                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
-                    }
-                    // the sources the pushers push in this block: positions (j-1)B .. jB-1, lane = state
-                    {
-                        const double *h_blk = &sh_h[(jj + 1) & 1][0][lane & (SMM_MAX_STATES_DEV - 1)];
-                        double gm = hdm;
+                        const int q = j - 1;
 #pragma unroll
-                        for (int i = 0; i < B - 1; ++i) gm = smm_fmax(gm, h_blk[i * SMM_MAX_STATES_DEV]);
-                        hdm = h_blk[(B - 1) * SMM_MAX_STATES_DEV];
-                        hmx = smm_fmax(hmx, gm);
-                        if (jj == 0) {                                         // group j/4 - 1 is complete
-                            if (j >= 4 && lane < SMM_MAX_STATES_DEV) sh_hm[BAND ? lane : 0][BAND ? ((j / 4 - 1) & 63) : 0] = hmx;
-                            hmx = SMM_NEG_INF;
+                        for (int x = 0; x < NE; ++x) {
+                            const int e = lane + 64 * x;
+                            if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) {
+                                hcum[(size_t)(q * B + 1) * C + e] = hist[0][x];
+                                hgam[(size_t)(q * B + 1) * C + e] = hist[2][x];
+                            }
+                            const int hc = e / B, hi = e % B;
+                            if (hc < C && q * B + 1 + hi <= T) hh[(size_t)hc * (T + 1) + q * B + 1 + hi] = hist[1][x];
                         }
-                        if (jj == UB - 1) {                                    // the next block ends with the switch to group G
-                            const int G = (j + 1) / 4;
+                    }
+                    // the sources the pushers push in this block (positions (j-1)B + 1 - D .. jB - D), lane = state
+                    if constexpr (!(SMM_ABLATE & 8)) {
+                        double gm = D ? hdm : hrow[B - 1];
 #pragma unroll
-                            for (int p = 0; p < NPASS; ++p) {
-                                if (8 * p >= C) break;
-                                const int c = 8 * p + (lane >> 3), m = (lane & 7) + 1;
-                                const int gi = G - 7 * m;
-                                const double hsrc = sh_hm[BAND ? c : 0][BAND ? (gi & 63) : 0];
-                                const double hwit = sh_hm[BAND ? c : 0][BAND ? ((G - 2) & 63) : 0];
-                                const bool on = c < C && gi >= 0 && (G < 2 || hsrc + lmx[p] > hwit + lbm[p]);
+                        for (int i = 0; i < B - 1; ++i) gm = smm_fmax(gm, hrow[i]);
+                        hdm = hrow[B - 1];
+                        hmx = smm_fmax(hmx, gm);
+                        if (jj == 0) {                                         // group j/BPG - 1 is complete
+                            // (j = 0: "group -1", slot 63 -- with D = 0 position 0, the start of every first segment, is its
+                            // one real source; with D = 1 it is empty and position 0 opens group 0)
+                            if (lane < SMM_MAX_STATES_DEV) sh_hm[BAND ? lane : 0][BAND ? ((j / BPG - 1) & 63) : 0] = hmx;
+                            hmx = SMM_NEG_INF;
+#pragma unroll
+                            for (int pp = 0; pp < PPB; ++pp) hwit[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? ((G - 2) & 63) : 0];
+                        }
+#pragma unroll
+                        for (int pp = 0; pp < PPB; ++pp) {
+                            const int p = jj * PPB + pp;
+                            if (8 * p < C) {
+                                const bool on = dc[pp] < C && gi[pp] >= -1 && (G < 2 || hsrc[pp] + lmx[p] > hwit[pp] + lbm[p]);
                                 const unsigned long long mask = __ballot(on);
                                 if (lane < 8) sh_act[G & 1][BAND ? 8 * p + lane : 0] = (uint32_t)(mask >> (8 * lane)) & 0xffu;
                             }
@@ -994,32 +1108,76 @@ smm_viterbi_kernel(SmmDpArgs a)
                 // on from the rows fetched during the previous block.  (Reading the rows of all states first and
                 // interleaving the states' pushes step by step measured 3 % SLOWER: the wave is not bound by the latency
                 // of one state's chain.)
+                // All LDS reads of the block are issued up front: the rows (above) and -- first block of a group -- the
+                // group's band switches, written by the mover wave during the previous group.
+                double hvl[NHR];
+                uint32_t actn[SPS];
+#pragma unroll
+                for (int r = 0; r < NHR; ++r) hvl[r] = (&sh_h[(jj + 1) & 1][0][0])[hoff[r]];
+                double hva[SMM_BAND_LDSB ? SPS : 1][B];
+                if constexpr (SMM_BAND_LDSB) {
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) {
+                        const int c = js * NPS + rank;
+#pragma unroll
+                        for (int i = 0; i < B; ++i) hva[SMM_BAND_LDSB ? js : 0][i] = sh_h[(jj + 1) & 1][i][c < C ? c : 0];
+                    }
+                }
+                auto src_row = [&](int js, int i) {          // h[(j-1)B + 1 + i] of the wave's js-th state
+                    if constexpr (SMM_BAND_LDSB) return hva[SMM_BAND_LDSB ? js : 0][i];
+                    else return smm_row_bcast(hvl[(B * js + i) / 16], (B * js + i) % 16);
+                };
+                if (jj == 0) {
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) {
+                        const int c = js * NPS + rank;
+                        actn[js] = sh_act[(j / BPG) & 1][BAND ? (c < C ? c : 0) : 0];
+                    }
+                }
+                // D = 1: the first source of every state is the previous block's last row: registers, no wait for LDS
+                if constexpr (D == 1 && !(SMM_ABLATE & 4)) {
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) {
+                        if (js * NPS + rank >= C) break;
+                        smm_push<RS>(As[js], L0[js], SMM_BAND_LDSB ? hdl[SMM_BAND_LDSB ? js : 0] : smm_row_bcast(hvp[(B * js + B - 1) / 16], (B * js + B - 1) % 16), (jj * B) % RS);
+                    }
+                }
 #pragma unroll
                 for (int js = 0; js < SPS; ++js) {
                     const int c = js * NPS + rank;
                     if (c >= C) break;
-                    const double *h_blk = &sh_h[(jj + 1) & 1][0][c];
-                    double hv[B];
+                    if constexpr (!(SMM_ABLATE & 4)) {
 #pragma unroll
-                    for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
-                    smm_push<RS>(As[js], L0[js], hds[js], (jj * B) % RS);
-#pragma unroll
-                    for (int i = 1; i < B; ++i) smm_push<RS>(As[js], L0[js], hv[i - 1], (jj * B + i) % RS);
-                    hds[js] = hv[B - 1];
+                        for (int i = D; i < B; ++i)
+                            smm_push<RS>(As[js], L0[js], src_row(js, i - D), (jj * B + i) % RS);
+                        if constexpr (SMM_BAND_LDSB) hdl[SMM_BAND_LDSB ? js : 0] = src_row(js, B - 1);
+                    }
                     if (act[js]) {
                         // the bands that are switched on (rarely any): their rings at this block's phase come from the table
+                        // -- the first two of the wave were fetched during the previous block (below), like their sources:
+                        // a table row costs an L2 round trip, and a pusher that waits for one makes the whole block wait
                         const double *lrow = lent + (size_t)c * SMM_BAND_ROW;
                         const int off = (B + D - j * B) & 127;
+                        auto ring = [&](double (&Lr)[RS], int m_) {      // the wave's pk-th pair of this block
+                            if (pk < npre) {                             // (wave-uniform: scalar branches)
+#pragma unroll
+                                for (int k = 0; k < NPRE; ++k)
+                                    if (pk == k) { Lr[0] = Lp[k][0]; Lr[1] = Lp[k][1]; }
+                            } else {
+                                smm_band_ring_load(Lr, lrow, off, m_, kp, lane);
+                            }
+                            ++pk;
+                        };
                         uint32_t mm = act[js];
                         nact += __builtin_popcount(mm);
                         int m = __builtin_ctz(mm) + 1;
                         double Lm[RS];
-                        smm_band_ring_load(Lm, lrow, off, m, kp, lane);
+                        ring(Lm, m);
                         while (true) {
                             mm &= mm - 1;
                             const int mn = mm ? __builtin_ctz(mm) + 1 : 0;
                             double Ln[RS];
-                            if (mn) smm_band_ring_load(Ln, lrow, off, mn, kp, lane);      // in flight while band m is pushed
+                            if (mn) ring(Ln, mn);                                         // in flight while band m is pushed
                             const int q = js * 8 + m - 1;
 #pragma unroll
                             for (int i = 0; i < B; ++i)
@@ -1046,22 +1204,39 @@ smm_viterbi_kernel(SmmDpArgs a)
                     for (int js = 0; js < SPS; ++js) {
                         const int c = js * NPS + rank;
                         if (c >= C) break;
-                        act[js] = sh_act[(j / 4) & 1][BAND ? c : 0];
+                        act[js] = __builtin_amdgcn_readfirstlane(actn[js]);
                     }
                 }
-                // fetch the delayed sources of block j+1: positions jB - 112m .. + B-1 of (state, band) = lane
+                // fetch the delayed sources of block j+1: positions jB + 1 - D - 112m .. + B-1 of (state, band) = lane, and the
+                // rings of the first NPRE (state, band) pairs at that block's phase
                 {
                     unsigned long long lanes = 0;
 #pragma unroll
                     for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)act[js] << (8 * js);
+                    npre = 0; pk = 0;
                     if (lanes) {                                  // (nearly always nothing is switched on: no loads at all)
                         const bool mine = (lanes >> lane) & 1ull;
-                        const int s0 = j * B - SMM_BAND_DELAY * qm;
-                        const double *src = qcol + ((mine && s0 >= 0) ? s0 : 0);
+                        const int s0 = j * B + 1 - D - SMM_BAND_DELAY * qm;
 #pragma unroll
-                        for (int i = 0; i < B; ++i) hq[i] = smm_ld_agent(src + i);
+                        for (int i = 0; i < B; ++i) {                                  // (positions before 0 do not exist)
+                            const double v = smm_ld_agent(qcol + ((mine && s0 + i >= 0) ? s0 + i : 0));
+                            hq[i] = (s0 + i >= 0) ? v : SMM_NEG_INF;
+                        }
+                        const int offn = (B + D - (j + 1) * B) & 127;
+                        unsigned long long rest = lanes;
+#pragma unroll
+                        for (int k = 0; k < NPRE; ++k) {
+                            if (rest) {
+                                const int pq = __builtin_ctzll(rest);
+                                smm_band_ring_load(Lp[k], lent + (size_t)((pq >> 3) * NPS + rank) * SMM_BAND_ROW, offn, (pq & 7) + 1, kp, lane);
+                                rest &= rest - 1;
+                                npre = k + 1;
+                            }
+                        }
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < NHR; ++r) hvp[r] = hvl[r];
                 SMM_LDS_BARRIER();                               // end of block j
             }
         }
@@ -1111,12 +1286,16 @@ smm_viterbi_kernel(SmmDpArgs a)
         // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
         const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE];
+        double pre[NE], pre2[SMM_PF2 ? NE : 1];
         if (w == MW) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
                 pre[q] = elp[e < e_last ? e : e_last];
+                if constexpr (SMM_PF2) {
+                    const int64_t e2 = e + (int64_t)B * cm;                        // block 2
+                    pre2[SMM_PF2 ? q : 0] = elp[e2 < e_last ? e2 : e_last];
+                }
             }
         }
         // Everything loaded so far (tables, rings) has to have arrived before the loop: the compiler's wait-count
@@ -1150,11 +1329,17 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
                     for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+                        if (lo[q] >= 0) dst[lo[q]] = (SMM_PF2 && (jj & 1)) ? pre2[SMM_PF2 ? q : 0] : pre[q];
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
-                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                        pre[q] = elp[e < e_last ? e : e_last];
+                        if constexpr (SMM_PF2) {                               // in flight for two blocks (buffers by block parity)
+                            const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
+                            if (jj & 1) pre2[SMM_PF2 ? q : 0] = elp[e < e_last ? e : e_last];
+                            else pre[q] = elp[e < e_last ? e : e_last];
+                        } else {
+                            const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                            pre[q] = elp[e < e_last ? e : e_last];
+                        }
                     }
                     if (j >= 1) {
                         store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
@@ -1508,11 +1693,21 @@ static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
     // six state-owning pusher waves: up to 18 states with 3 each, 24 with 4, 28 (30) with 5; HF = source states per lane
     // group of the chain wave (4: four groups of 16 lanes)
     const dim3 grid(a.b), block(512);
+    // hand-over blocks of 8 positions (the pushers push the block's own 8 sources, D = 0) or, SMM_BAND_B=4, of 4 (D = 1)
+    static const bool b8 = [] { const char *e = std::getenv("SMM_BAND_B"); return !(e && std::atoi(e) == 4); }();
 #ifdef SMM_DEV_BAND_ONE   // development builds: one instantiation
     (void)c_need;
-    hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
     return SMM_OK;
 #else
+    if (b8) {
+        if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 8, 0, 2>), grid, block, 0, stream, a);
+        else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
+        else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
+        else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 8, 0, 2>), grid, block, 0, stream, a);
+        else return SMM_ERR_UNSUPPORTED;
+        return SMM_OK;
+    }
     if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 4, 1, 2>), grid, block, 0, stream, a);
     else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
     else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);

@@ -1,0 +1,13 @@
+# development aid: libsmmdp_<tag>.so = the shipped objects + smm_viterbi.hip compiled with extra flags, BAND kernels only
+# usage: bash scripts/build_variants.sh tag1 "-DSMM_ABLATE=1" tag2 "-DSMM_ABLATE=3" ...   (objects of the normal build must exist)
+set -e
+cd "$(dirname "$0")/../action-segmentation_amd/csrc"
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -mllvm -pragma-unroll-threshold=1048576 -mllvm -unroll-threshold=1048576"
+pids=""
+while [ $# -ge 2 ]; do
+  tag=$1; flags=$2; shift 2
+  ( hipcc $F -DSMM_DEV_BAND_ONLY $flags -c -o _obj/smm_viterbi_$tag.o smm_viterbi.hip &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsmmdp_$tag.so $(ls _obj/*.o | grep -v smm_viterbi) _obj/smm_viterbi_$tag.o && echo built $tag ) &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done

@@ -47,11 +47,20 @@ def run(b, T, C, K, lib='libsmmdp_prof16.so'):
     pp = raw.view(np.uint64).astype(np.float64)
     nblk = pp[7]
     print(f"b={b} T={T} C={C} K={K}: {e0.elapsed_time(e1):.3f} ms = {e0.elapsed_time(e1) * 1e6 / T:.0f} ns/frame; band-blocks evaluated "
-          f"{raw.view(np.int32)[3]} of {b * (T // 4) * C * 8}; cycles per block (busy / in barrier) by wave:")
+          f"{raw.view(np.int32)[3]} of {b * (T // (4 if os.environ.get('SMM_BAND_B') == '4' else 8)) * C * 8}; cycles per block (busy / in barrier) by wave:")
     if nblk:
         for w in range(16):
             if pp[8 + w] or pp[24 + w]:
-                print("   wave %2d  busy %6.0f  barrier %6.0f" % (w, pp[8 + w] / nblk, pp[24 + w] / nblk))
+                extra = ''
+                if w < 8 and pp[32 + 4 * w] and os.environ.get('SMM_PROF_LAST'):
+                    # -DSMM_PROFILE=2: blocks this wave reached the barrier last (waited < 150 cycles), by j mod 4, and its mean busy time in those
+                    raw4 = [int(pp[32 + 4 * w + ph]) for ph in range(4)]
+                    cnt = [raw4[0] & 0xfffff] + raw4[1:]
+                    tot = raw4[0] >> 20
+                    extra = '  last in %5d blocks (by j mod 4: %s), mean busy then %5.0f' % (pp[16 + w], ' '.join('%4d' % c for c in cnt), tot / max(1, pp[16 + w]))
+                elif w < 8 and pp[32 + 4 * w]:
+                    extra = '  longest %6.0f  busy by j mod 4: %s' % (pp[16 + w], ' '.join('%5.0f' % (pp[32 + 4 * w + ph] / (nblk / 4)) for ph in range(4)))
+                print("   wave %2d  busy %6.0f  barrier %6.0f%s" % (w, pp[8 + w] / nblk, pp[24 + w] / nblk, extra))
     sys.stdout.flush()
 
 

@@ -2,6 +2,7 @@
 
 Bit-exact bar: spans, frame labels and the best score must equal oracle/smm_oracle.c (same fp64 expressions).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -647,10 +648,12 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
     spans, v = run_oracle(p)
     check(p, out, spans, v)
     assert out['_err'][0] == 0
-    # the diagnostic counter: delayed band-blocks evaluated, of (frames / 4) x states x (bands with a valid length)
+    # the diagnostic counter: delayed band-blocks evaluated, of (frames / block) x states x (bands with a valid length);
+    # a hand-over block is 8 positions (4 under SMM_BAND_B=4)
     kp = min(k, max(lengths))
     bands = sum(1 for m in range(1, 9) if 16 + 112 * m <= kp - 1)
-    possible = sum(-(-int(t) // 4) for t in lengths) * c * bands
+    blk = 4 if os.environ.get('SMM_BAND_B') == '4' else 8
+    possible = sum(-(-int(t) // blk) for t in lengths) * c * bands
     frac = out['_err'][3] / possible
     if kind == 'structured':
         assert frac < 0.12, frac                       # (long videos: ~1-3 %; the first 1000 frames of a video cost the most)

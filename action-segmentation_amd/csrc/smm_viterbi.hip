@@ -101,6 +101,9 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_BAND_LDSB
 #define SMM_BAND_LDSB 0   // 1 (experiment): BAND pushers read every source row with every lane (no broadcast instruction, 16x the LDS traffic)
 #endif
+#ifndef SMM_NPRE
+#define SMM_NPRE 2
+#endif
 #ifndef SMM_ABLATE
 #define SMM_ABLATE 0   // development builds only (results are WRONG, timing experiments): bit 0 chain wave without the
                        // candidates k = 2..K0, bit 1 without the cumE add / store, bit 2 pushers push nothing, bit 3 mover
@@ -510,9 +513,19 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
 smm_viterbi_kernel(SmmDpArgs a)
 {
     static_assert(PAIR != 1 || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair mode: K <= 1024, 8 waves");
-    static_assert(PAIR != 2 || (R == 16 && NW == 8 && CP == 0 && ((B == 4 && D == 1) || (B == 8 && D == 0))),
-                  "band mode: K <= 1024, 8 waves, blocks of 4 (pushers lag a source) or 8 positions");
+    static_assert(PAIR != 2 || (R == 16 && NW == 8 && CP == 0 && B == 8 && D == 0),
+                  "band mode: K <= 1024, 8 waves, blocks of 8 positions, the pushers push the block's own sources");
     constexpr bool GANG = PAIR == 1, BAND = PAIR == 2;
+#ifndef SMM_TRI
+#define SMM_TRI 1
+#endif
+    // TRI (BAND mode with D = 0): a TRIANGULAR split of the short lengths.  When target n = (j+1)B + 1 + i is handed over
+    // the pushers have pushed every source up to jB into its slot, i.e. every length k >= B + 1 + i -- if the rings
+    // carry the lengths from B + 1 on.  The chain wave then evaluates k <= B + i only (B(B-1)/2 candidates per block less
+    // than with the uniform split at K0 = 2B - 1).  A slot keeps receiving those lengths for up to B - 1 pushes after
+    // its hand-over, addressed to a target that is gone: the slots are cleared a second time one block later, before
+    // anything real reaches them (band 0 comes back at k = 127, the delayed bands stay off ring indices < 16).
+    constexpr bool TRI = BAND && D == 0 && SMM_TRI;
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
@@ -581,7 +594,6 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ __attribute__((aligned(16))) double sh_along[GANG ? 2 : 1][GANG ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ double sh_hm[BAND ? SMM_MAX_STATES_DEV : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
-    __shared__ uint32_t sh_act[2][BAND ? SMM_MAX_STATES_DEV : 1];             // band mode: bit m-1 = band m of the state is switched on
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
@@ -604,7 +616,6 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
             if (GANG) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[GANG ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
-        if (BAND) { sh_act[0][BAND ? c : 0] = 0; sh_act[1][BAND ? c : 0] = 0; }
         sh_gam[c] = SMM_NEG_INF;
         sh_gfin[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
@@ -628,7 +639,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         // The serial chain is the critical path of a block; its SIMD partner is a pusher wave with an endless
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
-        constexpr bool GAMROW = (B > 4) || (R < 4);       // a separate gamma broadcast row (see the position loop)
+#ifndef SMM_BAND_GAMROW
+#define SMM_BAND_GAMROW 0   // (same-box A/B at B = 8: the history row as broadcast row, one LDS store less per position, -2 %)
+#endif
+        constexpr bool GAMROW = BAND ? bool(SMM_BAND_GAMROW) : ((B > 4) || (R < 4));   // a separate gamma broadcast row (see the position loop)
         constexpr bool TAILFREE = R < 16 || BAND;          // no bounds tests inside a block (see the position loop; BAND:
                                                            // the chain wave alone bounds the frame, whatever the state count)
         constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
@@ -684,10 +698,13 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double sq[K0 + 1];
                     double acc = ap[i];
                     if constexpr (SMM_ABLATE & 1) return acc;
+                    const int kmax = TRI ? B + i : K0;     // (i is a constant at every call site)
 #pragma unroll
-                    for (int k = 2; k <= K0; ++k) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
+                    for (int k = 2; k <= K0; ++k)
+                        if (k <= kmax) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
 #pragma unroll
-                    for (int k = K0; k >= 2; --k) acc = smm_fmax(acc, sq[k]);
+                    for (int k = K0; k >= 2; --k)
+                        if (k <= kmax) acc = smm_fmax(acc, sq[k]);
                     return acc;
                 };
                 double pacc = partial(0);
@@ -914,6 +931,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         // jB - D, so group g = sources 16g + 1 - D .. 16g + 16 - D is pushed in blocks g BPG + 1 .. (g+1) BPG, and the ring
         // indices 1 .. 2B - 1 + D (= K0) of a push are slots that were handed over already (K0 < SMM_BAND_LO = 16).
         constexpr int BPG = 16 / B;
+#ifndef SMM_BAND_UBX
+#define SMM_BAND_UBX 1
+#endif
+        constexpr int UBB = UB * SMM_BAND_UBX;                               // blocks per iteration of the block loop (whole groups)
         static_assert(!BAND || (UB == BPG && K0 < SMM_BAND_LO), "a group is one unrolled iteration of the block loop");
         int hoff[NHR];
         double hvp[NHR];                                                     // the previous block's rows (D = 1: its last row is pushed first)
@@ -932,36 +953,32 @@ smm_viterbi_kernel(SmmDpArgs a)
         for (int js = 0; js < SPS; ++js) {
             const int c = js * NPS + rank;
             const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
-            smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
+            smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, TRI ? B + 1 : 2 * B + D, kshort, c < C, lane);
             act[js] = 0;
         }
-        // The mover wave also keeps the books of the skip test, one lane per state: max h over every group of 16 sources
-        // (ring sh_hm), and -- a block before a group starts -- which bands are switched on for it (sh_act): lane
-        // 8 s + (m - 1) of pass p tests band m of state 8 p + s.  The witness of the lower bound is the group before the
-        // last one (G - 2: the last one is still being pushed when the decision is due), so the test reads
+        // The skip test.  The mover wave keeps max h over every group of 16 sources, one lane per state (ring sh_hm);
+        // every pusher decides the bands of its own states, lane q = 8 js + (m - 1) for (state js, band m), in the block
+        // BEFORE the last one of the previous group -- early enough for the delayed sources to be fetched two blocks ahead
+        // of their pushes.  The witness of the lower bound is the group before the last one (G - 2: complete when the
+        // decision is due), so the test reads
         //     hm[G - 7m] + max_{band m} len  >  hm[G - 2] + min_{33 <= k <= 174} len      <=>  band m on for group G.
-        constexpr int NPASS = SMM_MAX_STATES_DEV / 8;
-        constexpr int PPB = NPASS / BPG;                                     // decision passes per block
-        static_assert(!BAND || NPASS % BPG == 0, "whole passes per block");
-        double hmx = SMM_NEG_INF, hdm = SMM_NEG_INF;                         // lane = state: running max, last row of the previous block (D = 1)
-        double lmx[NPASS], lbm[NPASS];
-        if (w == MW) {
-#pragma unroll
-            for (int p = 0; p < NPASS; ++p) {
-                const int c = 8 * p + (lane >> 3), m = (lane & 7) + 1;
-                const bool mine = c < C && SMM_BAND_LO + SMM_BAND_DELAY * m <= kp - 1;
-                lmx[p] = mine ? btab[(size_t)c * SMM_BAND_TAB + m] : SMM_NEG_INF;
-                lbm[p] = (c < C && bound_ok) ? btab[(size_t)c * SMM_BAND_TAB] : SMM_NEG_INF;
-            }
-        }
-        // lane q = 8 js + (m - 1) fetches the delayed sources of (state js, band m), one block ahead
+        static_assert(!BAND || BPG == 2, "a group is two blocks: decided in the second block of the previous group");
+        double hmx = SMM_NEG_INF;                                            // mover, lane = state: running max of the group
+        // lane q = 8 js + (m - 1) decides (state js, band m) and fetches its delayed sources, two blocks ahead
         const int qjs = lane >> 3, qm = (lane & 7) + 1;
         const int qc = qjs * NPS + rank;
+        const bool qok = qjs < SPS && qc < C && SMM_BAND_LO + SMM_BAND_DELAY * qm <= kp - 1;
         const double *qcol = hh + (size_t)((qjs < SPS && qc < C) ? qc : 0) * (T + 1);
-        double hq[B];
+        const double qlmx = qok ? btab[(size_t)qc * SMM_BAND_TAB + qm] : SMM_NEG_INF;
+        const double qlbm = (qok && bound_ok) ? btab[(size_t)qc * SMM_BAND_TAB] : SMM_NEG_INF;
+        const double *qhm = &sh_hm[BAND ? ((qjs < SPS && qc < C) ? qc : 0) : 0][0];
+        double hq[2][B];                                                     // by parity of the block that pushes them
 #pragma unroll
-        for (int i = 0; i < B; ++i) hq[i] = SMM_NEG_INF;
-        constexpr int NPRE = 2;                   // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
+        for (int i = 0; i < B; ++i) { hq[0][i] = SMM_NEG_INF; hq[1][i] = SMM_NEG_INF; }
+        uint32_t actp[SPS];                                                  // the next group's bands, once decided
+#pragma unroll
+        for (int js = 0; js < SPS; ++js) actp[js] = 0;
+        constexpr int NPRE = SMM_NPRE;            // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
                                                   // (six measured 7 % SLOWER than two: registers and code for a case that is rare)
         double Lp[NPRE][RS];                      // in ascending 8 js + (m - 1), the order the push loop meets them in
 #pragma unroll
@@ -1013,11 +1030,12 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
         };
         SMM_PROF_DECL;
-        for (int j0 = 0; j0 < J; j0 += UB) {
+        for (int j0 = 0; j0 < J; j0 += UBB) {
 #pragma unroll
-            for (int jj = 0; jj < UB; ++jj) {
+            for (int jj = 0; jj < UBB; ++jj) {
                 const int j = j0 + jj;
                 if (j >= J) break;
+                const int ph = jj % BPG;                                   // block of its group
                 if (w == MW) {
                     // Every LDS read of the block is issued first, unconditionally (clamped offsets), as ONE batch: the
                     // history rows of block j-1, the rows the pushers push in this block (group maxima), the two group
@@ -1034,21 +1052,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double hrow[B];
 #pragma unroll
                     for (int i = 0; i < B; ++i) hrow[i] = h_blk[i * SMM_MAX_STATES_DEV];
-                    // decisions for group G = j/BPG + 1, PPB passes (of 8 states) per block of group G - 1 (all passes in one
-                    // block made that block wait for this wave); hm[G - 2] is complete since the first block of this group
-                    // (that block's passes read it behind its store below)
-                    const int G = j / BPG + 1;
-                    int dc[PPB], gi[PPB];
-                    double hsrc[PPB], hwit[PPB];
-#pragma unroll
-                    for (int pp = 0; pp < PPB; ++pp) {
-                        const int dm = (lane & 7) + 1;
-                        dc[pp] = 8 * (jj * PPB + pp) + (lane >> 3);
-                        gi[pp] = G - 7 * dm;
-                        hsrc[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? (gi[pp] & 63) : 0];
-                        hwit[pp] = SMM_NEG_INF;
-                        if (jj != 0) hwit[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? ((G - 2) & 63) : 0];
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
@@ -1078,29 +1081,16 @@ smm_viterbi_kernel(SmmDpArgs a)
                             if (hc < C && q * B + 1 + hi <= T) hh[(size_t)hc * (T + 1) + q * B + 1 + hi] = hist[1][x];
                         }
                     }
-                    // the sources the pushers push in this block (positions (j-1)B + 1 - D .. jB - D), lane = state
+                    // the sources the pushers push in this block (positions (j-1)B + 1 .. jB), lane = state
                     if constexpr (!(SMM_ABLATE & 8)) {
-                        double gm = D ? hdm : hrow[B - 1];
+                        double gm = hrow[B - 1];
 #pragma unroll
                         for (int i = 0; i < B - 1; ++i) gm = smm_fmax(gm, hrow[i]);
-                        hdm = hrow[B - 1];
                         hmx = smm_fmax(hmx, gm);
-                        if (jj == 0) {                                         // group j/BPG - 1 is complete
-                            // (j = 0: "group -1", slot 63 -- with D = 0 position 0, the start of every first segment, is its
-                            // one real source; with D = 1 it is empty and position 0 opens group 0)
+                        if (ph == 0) {                                         // group j/BPG - 1 is complete
+                            // (j = 0: "group -1", slot 63: position 0, the start of every first segment, is its one real source)
                             if (lane < SMM_MAX_STATES_DEV) sh_hm[BAND ? lane : 0][BAND ? ((j / BPG - 1) & 63) : 0] = hmx;
                             hmx = SMM_NEG_INF;
-#pragma unroll
-                            for (int pp = 0; pp < PPB; ++pp) hwit[pp] = sh_hm[BAND ? dc[pp] : 0][BAND ? ((G - 2) & 63) : 0];
-                        }
-#pragma unroll
-                        for (int pp = 0; pp < PPB; ++pp) {
-                            const int p = jj * PPB + pp;
-                            if (8 * p < C) {
-                                const bool on = dc[pp] < C && gi[pp] >= -1 && (G < 2 || hsrc[pp] + lmx[p] > hwit[pp] + lbm[p]);
-                                const unsigned long long mask = __ballot(on);
-                                if (lane < 8) sh_act[G & 1][BAND ? 8 * p + lane : 0] = (uint32_t)(mask >> (8 * lane)) & 0xffu;
-                            }
                         }
                     }
                 }
@@ -1111,7 +1101,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                 // All LDS reads of the block are issued up front: the rows (above) and -- first block of a group -- the
                 // group's band switches, written by the mover wave during the previous group.
                 double hvl[NHR];
-                uint32_t actn[SPS];
+                double dsrc = SMM_NEG_INF, dwit = SMM_NEG_INF;               // decision of group (j+1)/2, due in its block 2G - 1
+                const int dG = (j + 1) / BPG;
 #pragma unroll
                 for (int r = 0; r < NHR; ++r) hvl[r] = (&sh_h[(jj + 1) & 1][0][0])[hoff[r]];
                 double hva[SMM_BAND_LDSB ? SPS : 1][B];
@@ -1127,12 +1118,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if constexpr (SMM_BAND_LDSB) return hva[SMM_BAND_LDSB ? js : 0][i];
                     else return smm_row_bcast(hvl[(B * js + i) / 16], (B * js + i) % 16);
                 };
-                if (jj == 0) {
-#pragma unroll
-                    for (int js = 0; js < SPS; ++js) {
-                        const int c = js * NPS + rank;
-                        actn[js] = sh_act[(j / BPG) & 1][BAND ? (c < C ? c : 0) : 0];
-                    }
+                if (ph == 1 && !(SMM_ABLATE & 32)) {
+                    dsrc = qhm[(dG - 7 * qm) & 63];
+                    dwit = qhm[(dG - 2) & 63];
                 }
                 // D = 1: the first source of every state is the previous block's last row: registers, no wait for LDS
                 if constexpr (D == 1 && !(SMM_ABLATE & 4)) {
@@ -1181,7 +1169,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                             const int q = js * 8 + m - 1;
 #pragma unroll
                             for (int i = 0; i < B; ++i)
-                                smm_push<RS>(As[js], Lm, smm_readlane(hq[i], q), (jj * B + i) % RS);
+                                smm_push<RS>(As[js], Lm, smm_readlane(hq[ph][i], q), (jj * B + i) % RS);
                             if (!mn) break;
                             Lm[0] = Ln[0]; Lm[1] = Ln[1];
                             m = mn;
@@ -1197,42 +1185,67 @@ smm_viterbi_kernel(SmmDpArgs a)
                             As[js][r] = ninf;
                         }
                     }
-                }
-                if (jj == 0) {
-                    // the next block starts group G = j/4: the mover wave decided its bands a block ago
+                    if constexpr (TRI) {
+                        // the slots handed over a block ago (the B/RS lanes before these, around the ring): see TRI above
+                        const int dp = (d + 64) & 63;
+                        if (dp >= 64 - B / RS) {
 #pragma unroll
-                    for (int js = 0; js < SPS; ++js) {
-                        const int c = js * NPS + rank;
-                        if (c >= C) break;
-                        act[js] = __builtin_amdgcn_readfirstlane(actn[js]);
+                            for (int r = 0; r < RS; ++r) As[js][r] = ninf;
+                        }
                     }
                 }
-                // fetch the delayed sources of block j+1: positions jB + 1 - D - 112m .. + B-1 of (state, band) = lane, and the
-                // rings of the first NPRE (state, band) pairs at that block's phase
+                if (ph == 1 && !(SMM_ABLATE & 32)) {
+                    // group dG = (j+1)/2 (pushed in blocks j+2, j+3): which of this wave's (state, band) pairs are on
+                    const bool on = qok && dG - 7 * qm >= -1 && dsrc + qlmx > dwit + qlbm;
+                    const unsigned long long mask = __ballot(on);
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) actp[js] = (uint32_t)(mask >> (8 * js)) & 0xffu;
+                }
+                unsigned long long lanes2 = 0;                    // group (j+1)/2 (`actp` in either block of a group)
+#pragma unroll
+                for (int js = 0; js < SPS; ++js) lanes2 |= (unsigned long long)actp[js] << (8 * js);
+                if (ph == 0) {
+                    // the next block starts group j/2
+#pragma unroll
+                    for (int js = 0; js < SPS; ++js) act[js] = actp[js];
+                }
+                // the rings of the next block's first NPRE (state, band) pairs at that block's phase (the tables stay in L2)
                 {
                     unsigned long long lanes = 0;
 #pragma unroll
                     for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)act[js] << (8 * js);
                     npre = 0; pk = 0;
-                    if (lanes) {                                  // (nearly always nothing is switched on: no loads at all)
-                        const bool mine = (lanes >> lane) & 1ull;
-                        const int s0 = j * B + 1 - D - SMM_BAND_DELAY * qm;
-#pragma unroll
-                        for (int i = 0; i < B; ++i) {                                  // (positions before 0 do not exist)
-                            const double v = smm_ld_agent(qcol + ((mine && s0 + i >= 0) ? s0 + i : 0));
-                            hq[i] = (s0 + i >= 0) ? v : SMM_NEG_INF;
-                        }
+                    if (lanes) {                                  // (nearly always nothing is switched on)
                         const int offn = (B + D - (j + 1) * B) & 127;
                         unsigned long long rest = lanes;
 #pragma unroll
                         for (int k = 0; k < NPRE; ++k) {
-                            if (rest) {
+                            if (rest && !(SMM_ABLATE & 128)) {
                                 const int pq = __builtin_ctzll(rest);
                                 smm_band_ring_load(Lp[k], lent + (size_t)((pq >> 3) * NPS + rank) * SMM_BAND_ROW, offn, (pq & 7) + 1, kp, lane);
                                 rest &= rest - 1;
                                 npre = k + 1;
                             }
                         }
+                    }
+                }
+                // The delayed sources of block j+2 (positions (j+1)B + 1 - 112m .. + B-1 of (state, band) = lane), TWO blocks
+                // ahead: they come from HBM or the far cache, and a fetch that is not back when its block starts makes
+                // every wave wait (the chain wave waited 700 cycles per block for the pushers, 280 without these loads).
+                // Issued in EVERY block, after the ring loads, whether a band is on or not: the wave's loads complete in
+                // order and a wait can only name a count, so the wait for the next block's rings must know that exactly
+                // these B loads are younger -- behind a branch the compiler has to wait for everything.
+                if constexpr (!(SMM_ABLATE & 64)) {
+                    const bool mine = (lanes2 >> lane) & 1ull;
+                    const int s0 = (j + 1) * B + 1 - SMM_BAND_DELAY * qm;
+                    // (s0 in 1-B .. -1: the words before the row are read and masked below)
+                    const double *src = qcol + ((mine && s0 > -B) ? s0 : 0);
+#pragma unroll
+                    for (int i = 0; i < B; ++i) hq[ph][i] = smm_ld_agent(src + i);
+                    if ((j + 1) * B + 1 < SMM_BAND_DELAY * SMM_BAND_N) {               // (positions before 0 do not exist)
+#pragma unroll
+                        for (int i = 0; i < B; ++i)
+                            if (s0 + i < 0) hq[ph][i] = SMM_NEG_INF;
                     }
                 }
 #pragma unroll
@@ -1247,6 +1260,9 @@ smm_viterbi_kernel(SmmDpArgs a)
             store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
         }
         if (lane == 0 && nact) atomicAdd(a.err + 3, (int)nact);             // error block word 3: see ops.error_words
+#ifdef SMM_PROFILE
+        if (lane == 0 && blockIdx.x == 0 && w != MW && w < 7) reinterpret_cast<unsigned long long *>(a.err)[w < MW ? w + 1 : w] = nact;   // slots 2..6: workgroup 0's waves 1, 2, 3, 5, 6
+#endif
       }
     } else {
         // ============================================================================ pusher waves
@@ -1693,25 +1709,15 @@ static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
     // six state-owning pusher waves: up to 18 states with 3 each, 24 with 4, 28 (30) with 5; HF = source states per lane
     // group of the chain wave (4: four groups of 16 lanes)
     const dim3 grid(a.b), block(512);
-    // hand-over blocks of 8 positions (the pushers push the block's own 8 sources, D = 0) or, SMM_BAND_B=4, of 4 (D = 1)
-    static const bool b8 = [] { const char *e = std::getenv("SMM_BAND_B"); return !(e && std::atoi(e) == 4); }();
 #ifdef SMM_DEV_BAND_ONE   // development builds: one instantiation
     (void)c_need;
     hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
     return SMM_OK;
 #else
-    if (b8) {
-        if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 8, 0, 2>), grid, block, 0, stream, a);
-        else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
-        else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
-        else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 8, 0, 2>), grid, block, 0, stream, a);
-        else return SMM_ERR_UNSUPPORTED;
-        return SMM_OK;
-    }
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 4, 1, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 4, 1, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 4, 1, 2>), grid, block, 0, stream, a);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 8, 0, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
+    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 8, 0, 2>), grid, block, 0, stream, a);
     else return SMM_ERR_UNSUPPORTED;
     return SMM_OK;
 #endif

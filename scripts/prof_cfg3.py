@@ -41,7 +41,7 @@ for tag in sys.argv[1:]:
           % (tag, float(np.mean(ms)), min(ms), raw.view(np.int32)[3], tot, 100.0 * raw.view(np.int32)[3] / tot, same))
     nblk = pp[7]
     if nblk:
-        print('   workgroup 0: %d blocks' % nblk)
+        print('   workgroup 0: %d blocks; delayed band-blocks of its waves 1 2 3 5 6: %s' % (nblk, ' '.join('%d' % pp[k] for k in range(2, 7))))
         for w in range(8):
             extra = ''
             if os.environ.get('SMM_PROF_LAST'):

@@ -7,7 +7,7 @@ LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(HERE, "libsmmdp.so")  
 
 SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
-    "smm_error_word_offset",
+    "smm_error_word_offset", "smm_dp_timing_enable", "smm_dp_timing_read",
     "smm_emission_f64", "smm_emission_bwd_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
     "smm_factor_tables_f64", "smm_factor_tables_bwd_f64",
     "smm_dense_workspace_bytes", "smm_dense_dp_f32", "smm_dense_marginals_f32",
@@ -78,6 +78,10 @@ def load():
     lib.smm_fit_error_word_offset.argtypes = [ctypes.c_int32]
     lib.smm_error_word_offset.restype = ctypes.c_size_t
     lib.smm_error_word_offset.argtypes = [ctypes.POINTER(SmmShape)]
+    lib.smm_dp_timing_enable.restype = None
+    lib.smm_dp_timing_enable.argtypes = [ctypes.c_int]
+    lib.smm_dp_timing_read.restype = ctypes.c_int
+    lib.smm_dp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     _lib = lib
     return lib
 

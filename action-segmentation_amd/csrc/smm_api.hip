@@ -6,6 +6,8 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
+#include <mutex>
+#include <utility>
 
 #include "../../include/smmdp.h"
 #include "smm_device.h"
@@ -336,7 +338,7 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
     if (em_us < (mn ? std::atof(mn) : 100.0)) return 0;
     int tmax = 0;
     for (int i = 0; i < b; ++i) tmax = std::max(tmax, hv[i].T);
-    const int thr = tmax - (int)(1.15 * em_us * 1000.0 / 300.0) - 400;                 // (~300 ns per frame of DP)
+    const int thr = tmax - (int)(1.15 * em_us * 1000.0 / 230.0) - 500;                 // (~230 ns per frame of DP: BAND kernel, round 3)
     int n1 = 0;
     for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
     if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16) return 0;
@@ -468,6 +470,56 @@ static int run_emission(const smm_shape *s, const Staged &st, const float *x, co
 
 // first / count: only the videos order[first .. first + count) (count < 0: all); prep: launch the band tables kernel (a
 // split decode launches it once, in front of both parts)
+// smm_dp_timing_*: event pairs around the DP kernel launches (measurement aid, smmdp.h)
+namespace {
+struct DpTiming {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec, pool;
+} g_dp_timing;
+
+bool dp_timing_begin(hipStream_t stream, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    std::lock_guard<std::mutex> lock(g_dp_timing.mu);
+    if (!g_dp_timing.on) return false;
+    if (!g_dp_timing.pool.empty()) { ev = g_dp_timing.pool.back(); g_dp_timing.pool.pop_back(); }
+    else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return false;
+    return hipEventRecord(ev.first, stream) == hipSuccess;
+}
+
+void dp_timing_end(hipStream_t stream, const std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    (void)hipEventRecord(ev.second, stream);
+    std::lock_guard<std::mutex> lock(g_dp_timing.mu);
+    g_dp_timing.rec.push_back(ev);
+}
+}  // namespace
+
+extern "C" void smm_dp_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_dp_timing.mu);
+    g_dp_timing.on = on != 0;
+}
+
+extern "C" int smm_dp_timing_read(float *ms, int cap)
+{
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec;
+    {
+        std::lock_guard<std::mutex> lock(g_dp_timing.mu);
+        rec.swap(g_dp_timing.rec);
+    }
+    int n = 0;
+    for (auto &ev : rec) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess && ms && n < cap)
+            ms[n] = t;
+        ++n;
+    }
+    std::lock_guard<std::mutex> lock(g_dp_timing.mu);
+    for (auto &ev : rec) g_dp_timing.pool.push_back(ev);
+    return n;
+}
+
 static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, const double *trans, const double *init,
                        const double *len_scores, const double *endpen, const int64_t *class_map, int64_t *spans,
                        int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream, int first = 0, int count = -1,
@@ -505,7 +557,10 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         if (bytes <= 126 * 1024) { a.bt_window = w; a.bt_dyn_bytes = (int32_t)bytes; }
     }
     if (!launch) { SMM_HIP(hipGetLastError()); return SMM_OK; }      // (prep only)
+    std::pair<hipEvent_t, hipEvent_t> tev;
+    const bool timed = dp_timing_begin(stream, tev);
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
+    if (timed) dp_timing_end(stream, tev);
     if (rc != SMM_OK) return rc;
     // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant
     // may hold the CUs): a gang that gives up flags itself and its video is decoded again here, on one CU, behind the

@@ -109,9 +109,9 @@ __device__ __forceinline__ void smm_lds_barrier()
                        // candidates k = 2..K0, bit 1 without the cumE add / store, bit 2 pushers push nothing, bit 3 mover
                        // keeps no books, bit 4 transition over a third of the sources
 #endif
-#ifndef SMM_B8_MAX_R
-#define SMM_B8_MAX_R 0   // (experiment: blocks of 8 positions for rings of up to 64 * this many slots; measured 5-9 % slower)
-#endif
+#ifndef SMM_B8_R
+#define SMM_B8_R 4       // blocks of 8 positions for the 256-slot rings (round 3, same box: cfg2 DP 0.481 -> 0.456 ms; the 64-slot
+#endif                   // rings of cfg4 measured 10 % SLOWER with them, 0.406 -> 0.445 ms, and keep blocks of 4)
 
 // wave-level lexicographic arg-max: larger val first, then smaller k, then smaller c
 __device__ __forceinline__ void smm_best3(double &v, int &k, int &c, double v2, int k2, int c2)
@@ -1672,7 +1672,7 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
 {
     if (spw != SPW || nw != NW) return 0;
     // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
-    constexpr int B = (NW == 16 && R >= 8) ? 2 : ((R <= SMM_B8_MAX_R && NW == 8) ? 8 : SMM_B);
+    constexpr int B = (NW == 16 && R >= 8) ? 2 : ((R == SMM_B8_R && NW == 8) ? 8 : SMM_B);
     if constexpr (R == 16 && NW == 8 && B == 4 && SMM_D == 1) {
         if (a.n_pairs > 0) {                                     // gangs of 3 workgroups first: a.b + 2 n_pairs workgroups
             const dim3 grid(a.b + 2 * a.n_pairs);

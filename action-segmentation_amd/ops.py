@@ -482,3 +482,15 @@ def fit_stats(x, labels, lengths, frame_offset, n_classes, max_k):
     off = lib.smm_fit_error_word_offset(b)
     out['_err'] = ws[off:off + 4].view(torch.int32).clone()     # (a copy, stream-ordered behind the kernels: the shared
     return out                                                   #  workspace may be reused by the next call)
+
+
+def dp_timing(on):
+    """Measurement aid (smmdp.h: smm_dp_timing_enable): HIP event pairs around every DP kernel launch the library makes."""
+    _lib.load().smm_dp_timing_enable(1 if on else 0)
+
+
+def dp_timing_read(cap=4096):
+    """Durations (ms, launch order) of the DP kernel launches recorded since the last read; waits for them."""
+    buf = (ctypes.c_float * cap)()
+    n = _lib.load().smm_dp_timing_read(buf, cap)
+    return [float(buf[i]) for i in range(min(n, cap))]

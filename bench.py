@@ -285,7 +285,7 @@ def fit_model(a, cfg, data, dev, D, world):
 
 def timed_decode(a, pc, world, want_events=True):
     """W warm-up + exactly K timed decode steps of this rank's packed corpus, bracketed by barrier + synchronize.
-    Returns (wall seconds of the K steps, mean DP kernel ms, last labels (host int64))."""
+    Returns (wall seconds of the K steps, DP kernel launch statistics of those steps or None, last labels (host int64))."""
     from action_segmentation_amd import ops
     empty = pc is None or pc.n_videos == 0
     t = None if empty else pc.tables
@@ -304,20 +304,6 @@ def timed_decode(a, pc, world, want_events=True):
         stream.synchronize()          # the kernel wrote the labels into pinned host memory: they are on the host now
         return out['labels']
 
-    def dp_kernel_ms():
-        """The DP kernel alone, HIP events on the stream it is launched on: the same decode as two calls (emission, then
-        the DP over ALL videos in one launch), K times, right behind the timed region."""
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-        lab_out = torch.empty(pc.batch.total_frames, dtype=torch.int64, device=pc.x.device)
-        for e0, e1 in evs:
-            elp64, _ = ops.emission(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], cons=pc.cons)
-            e0.record(stream)
-            ops.viterbi(pc.batch, elp64, t['trans'], t['init'], t['len'], endpen=pc.endpen, class_map=t['class_map'],
-                        want_spans=False, want_labels=True, labels_out=lab_out)
-            e1.record(stream)
-        torch.cuda.synchronize()
-        return float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
-
     def sync():
         torch.cuda.synchronize()
         if torch.distributed.is_initialized():
@@ -331,17 +317,30 @@ def timed_decode(a, pc, world, want_events=True):
     import gc
     gc.collect()
     gc.disable()                      # a collection inside a 0.5 ms step would be a quarter of it
+    # HIP events around every DP kernel launch of the timed region, recorded by the library on the streams it launches on
+    # (smm_dp_timing_*: smm_decode_f32 launches the kernel once, or twice on two streams -- the launch's critical videos
+    # first, the rest beside them); two event records per launch, a few microseconds of the step
+    timing = want_events and not empty
+    if timing:
+        ops.dp_timing_read()
+        ops.dp_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         labels = step()
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    dp = None
+    if timing:
+        ops.dp_timing(False)
+        ms = ops.dp_timing_read()
+        if ms:
+            dp = {"launch_ms": float(np.mean(ms)), "launches_per_step": len(ms) / a.steps, "per_step_sum_ms": float(np.sum(ms)) / a.steps,
+                  "max_launch_ms": float(np.max(ms))}
     if not empty:
         ops.check_decoded(pc.batch, last.get('out'))
         labels = labels.clone()       # (the pinned staging buffer is reused by the next decode)
-    dp_ms = dp_kernel_ms() if (want_events and not empty) else None
-    return dt, dp_ms, labels
+    return dt, dp, labels
 
 
 def gt_on_device(pc, data, dev):
@@ -375,7 +374,8 @@ def strong_leg(a, rank, world, dev, D):
     D.broadcast_parameters(model.model, src=0)
     pc = model.prepare(data, shard=(rank, world))
     assert sorted(pc.video_names) == sorted(n for i in mine for (_, n) in batches[i])
-    dt, dp_ms, labels = timed_decode(a, pc, world, want_events=True)
+    dt, dp, labels = timed_decode(a, pc, world, want_events=True)
+    dp_ms = dp["per_step_sum_ms"] if dp else None                    # DP kernel time of a step, all its launches
     space = evaluation.LabelSpace.from_corpus(data.corpus, list(data._videos_by_task))
     if pc.n_videos:
         stats_by_task = evaluation.evaluate_labels(labels.to(dev), gt_on_device(pc, data, dev), pc.lengths, pc.frame_offset,
@@ -395,10 +395,11 @@ def strong_leg(a, rank, world, dev, D):
     roof = None
     if pc.n_videos and dp_ms:
         dp_bytes = sum(ln * (32 * pc.n_states[g] + 8) for ln, g in zip(pc.lengths, pc.group))
+        nl = dp["launches_per_step"]
         roof = {"bound": "hbm", "achieved": dp_bytes / (dp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dp_bytes / (dp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "smm_viterbi_kernel",
-                "kernel_ms": dp_ms, "algorithmic_bytes_per_launch": dp_bytes,
-                "note": "rank 0's shard of the sharded corpus; the DP is fp64-VALU / latency-bound, not HBM-bound"}
+                "kernel_ms": dp["launch_ms"], "launches_per_step": nl, "algorithmic_bytes_per_launch": dp_bytes / nl,
+                "note": "rank 0's shard of the sharded corpus; the DP is latency-bound (one serial chain per video), not HBM-bound"}
     return {"scaling": "strong", "roofline_rank0": roof, "workload": "%s seed %d: %d videos, %d frames, sharded by video (whole single-task "
             "batches of %d, greedy LPT on the DP work)" % (a.strong_workload, a.seed, int(tot[1]), int(tot[0]), cfg['batch_size']),
             "value": float(tot[0]) * a.steps / dt_all, "unit": "frames/s", "n_gpus": world, "ms_per_step": dt_all / a.steps * 1e3,
@@ -732,7 +733,8 @@ def main():
     pc = model.prepare(data)                                         # inputs resident in HBM from here on
     frames = pc.n_frames
     stream = torch.cuda.current_stream()
-    dt, dp_ms, labels = timed_decode(a, pc, world)
+    dt, dp, labels = timed_decode(a, pc, world)
+    dp_ms = dp["per_step_sum_ms"]                                    # DP kernel time of a step, all its launches
     labels_dev = labels.to(dev)      # the evaluation kernels below (outside the timed region) read device labels
 
     # evaluation, outside the timed region: the reference's per-task statistics from device counters
@@ -802,17 +804,18 @@ def main():
                                       "SUM all-reduced over: %s" % (world, par)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "smm_viterbi_kernel", "kernel_ms": dp_ms,
-                         "kernel_ms_source": "HIP events on the launch stream around the DP kernel, mean over K decodes made as "
-                                             "two calls (emission, then ONE DP launch over all videos) right behind the timed "
-                                             "region; the timed step is smm_decode_f32, which -- on a corpus whose longest "
-                                             "videos set the DP's time -- scores and decodes the other videos on a second "
-                                             "stream beside them (smm_api.hip: choose_split)",
-                         "algorithmic_bytes_per_launch": dp_bytes,
-                         "note": "the DP is fp64-VALU-bound, not HBM-bound: %.3g lattice cells/launch = %.2f T cell/s "
-                                 "= %.3f of the 2-op-per-cell fp64 VALU peak" % (
-                                     cells, cells / (dp_ms * 1e-3) / 1e12,
-                                     2 * cells / (dp_ms * 1e-3) / FP64_VALU_PEAK)},
+                         "kernel": "smm_viterbi_kernel", "kernel_ms": dp["launch_ms"], "launches_per_step": dp["launches_per_step"],
+                         "kernel_ms_per_step": dp_ms, "kernel_ms_longest_launch": dp["max_launch_ms"],
+                         "kernel_ms_source": "HIP events recorded by the library (smm_dp_timing_*) around every DP kernel launch "
+                                             "of the K timed steps, on the stream each launch runs on: smm_decode_f32 launches "
+                                             "the kernel twice per step on a corpus whose longest videos set the DP's time (those "
+                                             "videos first, the others on a second stream beside them: smm_api.hip choose_split); "
+                                             "kernel_ms is the mean launch (what rocprofv3 --stats averages), achieved = the "
+                                             "step's algorithmic bytes / the step's summed launch time",
+                         "algorithmic_bytes_per_launch": dp_bytes / dp["launches_per_step"],
+                         "note": "the DP is latency-bound, not HBM-bound: one serial chain per video (a few hundred cycles per "
+                                 "position), and the launch lasts as long as its longest video; %.3g lattice cells per step, "
+                                 "of which the BAND kernel evaluates the part its bound tests cannot exclude" % cells},
             "mof": float(counters[0] / counters[1]),
             "weak_scaling": dict(weak, scaling="weak", n_gpus=world,
                                  note="every rank decodes its own corpus of this size (seed + rank)"),
@@ -872,6 +875,7 @@ def main():
             _, model2 = fit_model(a, cfg, data2, dev, D, world)
             pc2 = model2.prepare(data2)
             dt2, dp2, _ = timed_decode(a, pc2, world)
+            dp2 = dp2["per_step_sum_ms"] if dp2 else None
             res["other_draw"] = {"seed": a.second_seed, "value": pc2.n_frames * a.steps / dt2, "unit": "frames/s",
                                  "ms_per_step": dt2 / a.steps * 1e3, "dp_kernel_ms": dp2, "frames": pc2.n_frames,
                                  "states_per_task": ' '.join(str(c) for c in sorted(pc2.n_states))}

@@ -102,6 +102,17 @@ size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 size_t smm_error_word_offset(const smm_shape *shape);
 
 /*
+ * Measurement aid (bench.py's roofline; not part of the reference's interface): while enabled, every launch of the
+ * Viterbi DP kernel made by smm_viterbi_* / smm_decode_f32 is bracketed by a pair of HIP events on the stream it is
+ * launched on (smm_decode_f32 may launch the kernel twice per call, on two streams: smmdp.h / DESIGN.md "split decode").
+ * smm_dp_timing_read waits for the recorded launches, writes their durations in milliseconds (launch order, at most
+ * `cap`) and forgets them; it returns the number of launches recorded since the last read (which may exceed cap).
+ * Not to be enabled around a stream capture.  The two event records cost a few microseconds per launch.
+ */
+void smm_dp_timing_enable(int on);
+int smm_dp_timing_read(float *ms, int cap);
+
+/*
  * Emission scorer.  elp[t][c] = cst[g][c] + sum_d x[t][d]*w[g][c][d] - 0.5*sum_d x[t][d]^2*inv_var[d] (+ cons[t][c])
  * which is the diagonal-Gaussian log density of modules:324-381 with w = mu/sigma^2,
  * cst = -0.5*sum mu^2/sigma^2 - sum log sigma - D/2 log 2pi.

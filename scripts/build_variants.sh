@@ -6,7 +6,7 @@ F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -mllvm -pragma-u
 pids=""
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
-  ( hipcc $F -DSMM_DEV_BAND_ONLY $flags -c -o _obj/smm_viterbi_$tag.o smm_viterbi.hip &&
+  ( hipcc $F ${SMM_VARIANT_FULL:--DSMM_DEV_BAND_ONLY} $flags -c -o _obj/smm_viterbi_$tag.o smm_viterbi.hip &&
     hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsmmdp_$tag.so $(ls _obj/*.o | grep -v smm_viterbi) _obj/smm_viterbi_$tag.o && echo built $tag ) &
   pids="$pids $!"
 done

@@ -17,7 +17,7 @@ SMM_DIST_SINGLE_RANK=1 timeout -k 10 900 python bench.py --steps 3 --warmup 1 --
 timeout -k 10 900 python bench.py --gpus 2 --backend gloo --share-gpus --steps 3 --warmup 1 --no-cpu-baseline --strong-workload cfg3 2>gpurun_out/${T}_2r.err | tail -1 > gpurun_out/${T}_2ranks_gloo_rehearsal.json
 rm -rf gpurun_out/prof_cfg3 gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/prof_cfg4 gpurun_out/pmc_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg3 -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-predict-e2e --second-seed -1 > gpurun_out/prof_cfg3.log 2>&1
-tail -1 gpurun_out/prof_cfg3.log > gpurun_out/${T}_cfg3_under_rocprof.json
+grep "^{\"metric" gpurun_out/prof_cfg3.log | tail -1 > gpurun_out/${T}_cfg3_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-predict-e2e --second-seed -1 > gpurun_out/pmc_$c.log 2>&1
 done

@@ -666,6 +666,53 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         np.testing.assert_array_equal(out[key], ring[key])
 
 
+@pytest.mark.parametrize('first', [127, 128, 129, 239, 240, 241, 600, 1023])
+def test_viterbi_band_mode_first_segment_from_position_zero(first, monkeypatch):
+    """The first segment of a video starts at position 0, and position 0 belongs to no group of 16 sources of the skip
+    test's bookkeeping (with 8-position blocks the groups are 1..16, 17..32, ...): the delayed bands of "group -1" must be
+    decided on the initial scores alone.  One long first segment of exactly `first` frames on either side of every band
+    boundary (128 = band 1's first length, 240 = band 2's), then ordinary segments."""
+    ops = _ops()
+    monkeypatch.delenv('SMM_PAIRS', raising=False)
+    monkeypatch.delenv('SMM_BAND', raising=False)
+    from scipy.special import gammaln
+    g = np.random.default_rng(first)
+    c, k, t = 7, 1024, 1400
+    lab = np.concatenate([np.full(first, 2), np.repeat((np.arange(40) * 3 + 1) % c, 60)])[:t]
+    e = -300.0 + 2.0 * g.standard_normal((1, t, c))
+    e[0, np.arange(t), lab] += 25.0
+    rates = np.array([60.0, 60.0, float(first), 60.0, 60.0, 60.0, 60.0])
+    kk = np.arange(k)[:, None]
+    lens = kk * np.log(rates) - rates - gammaln(kk + 1)
+    trans = np.log(np.full((c, c), 1.0 / c))
+    init = np.log(np.full(c, 1.0 / c))
+    p = dict(elp=e, lengths=np.asarray([t]), trans=trans, init=init, lens=lens, endpen=None, c=c, c_max=c, k=k)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    assert out['_err'][0] == 0
+    lab_gpu = np.asarray(out['labels']).reshape(-1)[:t]
+    assert (lab_gpu[:first] == 2).all() and lab_gpu[first] != 2      # the decode does find the long first segment
+
+
+def test_dp_timing_diagnostic():
+    """smm_dp_timing_*: one positive duration per DP kernel launch made while it is enabled, none otherwise."""
+    ops = _ops()
+    p = make_problem(3, 2, 300, 6, 40)
+    ops.dp_timing_read()
+    run_gpu(p)
+    assert ops.dp_timing_read() == []
+    ops.dp_timing(True)
+    try:
+        run_gpu(p)
+        run_gpu(p)
+    finally:
+        ops.dp_timing(False)
+    ms = ops.dp_timing_read()
+    assert len(ms) == 2 and all(0.0 < m < 100.0 for m in ms), ms
+    assert ops.dp_timing_read() == []
+
+
 def test_viterbi_band_mode_no_eos_and_end_penalties(monkeypatch):
     """The two closing variants on the BAND kernel: add_eos=False, and per-video allowed ends."""
     ops = _ops()

@@ -763,7 +763,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if constexpr (CP) {
                     if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
                 }
-                if constexpr (BAND) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j
+                if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j (LDS-only: see smm_lds_barrier)
             }
         }
         SMM_PROF_OUT();
@@ -1292,12 +1292,14 @@ smm_viterbi_kernel(SmmDpArgs a)
             row[q] = e / cm;
             lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
         }
-        int slo[NE], srw[NE];                                              // history block element e (rows C wide) -> LDS offset, row
+        int slo[NE], srw[NE], sloc[NE], hloc[NE];                          // history block element e (rows C wide) -> LDS offset, row
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
             const int e = lane + 64 * q;
             srw[q] = e / C;
             slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
+            sloc[q] = slo[q] >= 0 ? slo[q] : 0;                            // (the mover's unconditional reads)
+            hloc[q] = (e / B < C) ? (e % B) * SMM_MAX_STATES_DEV + e / B : 0;
         }
         // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
@@ -1341,6 +1343,16 @@ smm_viterbi_kernel(SmmDpArgs a)
                 const int j = j0 + jj;
                 if (j >= J) break;
                 if (w == MW) {
+                    // the history rows of block j-1: every LDS read first, unconditionally (clamped offsets), as ONE batch
+                    // (a read inside the `if (row <= T)` of each store is a round trip of its own: see the BAND mover)
+                    double hist[3][NE];
+#pragma unroll
+                    for (int x = 0; x < NE; ++x) {
+                        hist[0][x] = (&sh_cum[(jj + 1) & 1][0][0])[sloc[x]];
+                        hist[1][x] = (&sh_h[(jj + 1) & 1][0][0])[hloc[x]];
+                        hist[2][x] = (&sh_g[(jj + 1) & 1][0][0])[sloc[x]];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     // block j+1 (fetched a block ago) -> LDS, then fetch block j+2
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
@@ -1358,9 +1370,17 @@ smm_viterbi_kernel(SmmDpArgs a)
                         }
                     }
                     if (j >= 1) {
-                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
-                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
-                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
+                        const int q = j - 1;
+#pragma unroll
+                        for (int x = 0; x < NE; ++x) {
+                            const int e = lane + 64 * x;
+                            if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) {
+                                hcum[(size_t)(q * B + 1) * C + e] = hist[0][x];
+                                hgam[(size_t)(q * B + 1) * C + e] = hist[2][x];
+                            }
+                            const int hc = e / B, hi = e % B;
+                            if (hc < C && q * B + 1 + hi <= T) hh[(size_t)hc * (T + 1) + q * B + 1 + hi] = hist[1][x];
+                        }
                     }
                 }
 #pragma unroll
@@ -1369,7 +1389,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     const int c = js * NP + rank;
                     smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
-                SMM_BLOCK_BARRIER();                             // end of block j
+                if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j
             }
         }
         SMM_PROF_OUT();

@@ -104,6 +104,9 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_NPRE
 #define SMM_NPRE 2
 #endif
+#ifndef SMM_MOVER_STATES
+#define SMM_MOVER_STATES 0   // 1 (A/B aid): the mover wave of the 8-wave kernels always owns states, as in rounds 1-2
+#endif
 #ifndef SMM_ABLATE
 #define SMM_ABLATE 0   // development builds only (results are WRONG, timing experiments): bit 0 chain wave without the
                        // candidates k = 2..K0, bit 1 without the cumE add / store, bit 2 pushers push nothing, bit 3 mover
@@ -1269,19 +1272,29 @@ smm_viterbi_kernel(SmmDpArgs a)
         // pusher rank: the wave that shares a SIMD with the chain wave (wave 4 when there are 8) goes last, so that it
         // owns the fewest states
         int rank = w - 1;
+        // 8 waves, and the states fit six pushers at the same states-per-wave: wave 4 -- the chain wave's SIMD partner, at
+        // the lower priority -- owns NO states and only moves data (as in BAND mode).  With two states it was the wave the
+        // block barrier waited for (stamps on cfg2's shape: busy 3720 cycles per block of 8, the chain wave 3470, the
+        // other pushers <= 2600).
+        const bool stateless = NW == 8 && !GANG && C <= (NP - 1) * SPW && !(SMM_MOVER_STATES);
+        const int NPd = stateless ? NP - 1 : NP;                           // state-owning pushers
         if (NW == 8) {
-            rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
-            // ... unless that leaves one SIMD with two of the fuller waves (smm_device.h: smm_rebalanced_rank)
-            const int swap = smm_rebalanced_rank(C);
-            if (swap >= 0) rank = (rank == swap) ? NP - 1 : ((rank == NP - 1) ? swap : rank);
+            if (stateless) {
+                rank = (w == MW) ? (1 << 20) : ((w < MW) ? w - 1 : w - 2);
+            } else {
+                rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
+                // ... unless that leaves one SIMD with two of the fuller waves (smm_device.h: smm_rebalanced_rank)
+                const int swap = smm_rebalanced_rank(C);
+                if (swap >= 0) rank = (rank == swap) ? NP - 1 : ((rank == NP - 1) ? swap : rank);
+            }
         }
         // (12 waves: every pusher owns SPW states, nothing to rebalance)
-        const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
+        const int nv_all = (C - rank + NPd - 1) / NPd;                     // states rank, rank+NPd, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
         double A[SPW][R], L[SPW][R], hd[SPW];
 #pragma unroll
         for (int js = 0; js < SPW; ++js) {
-            smm_ring_init<R, B, D>(A[js], L[js], len + js * NP + rank, cm, kp, js < nv, lane);
+            smm_ring_init<R, B, D>(A[js], L[js], len + (js < nv ? js * NPd + rank : 0), cm, kp, js < nv, lane);
             hd[js] = SMM_NEG_INF;
         }
         // mover role of this wave: block-relative element e = lane + 64 q  <->  HBM offset e, LDS offset (e / cm, e % cm)
@@ -1386,7 +1399,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                 for (int js = 0; js < SPW; ++js) {
                     if (js >= nv) break;
-                    const int c = js * NP + rank;
+                    const int c = js * NPd + rank;
                     smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
                 if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j

@@ -158,7 +158,7 @@ __device__ __forceinline__ void smm_push(double (&A)[R], double (&L)[R], double 
 // those slots (everything they still receive before they wrap is -inf).  D = 1: the first source is the LAST row of the
 // previous block, kept in a register (hd), so the pushes that follow a barrier do not wait for LDS; the last row of
 // this block is kept for the next one.
-template <int R, int B, int D>
+template <int R, int B, int D, bool TRIB = false>
 __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], double &hd, const double *h_blk,
                                                double *a_blk, int j, int jj, int lane, const double &ninf)
 {
@@ -197,6 +197,14 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
                 A[r] = ninf;
             }
         }
+        if constexpr (TRIB) {
+            // triangular split (see TRI in the kernel): the slots handed over a block ago have since received lengths that
+            // were meant for their old targets; nothing real reaches them before this second clearing
+            if (((d + 64) & 63) >= 64 - B / R) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) A[r] = ninf;
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
@@ -225,11 +233,11 @@ __device__ __forceinline__ void smm_ring_init_range(double (&A)[R], double (&L)[
 
 // Block protocol (source position -(B-1+D) at push step 0): slot p waits for k = (p + B + D) mod RING; lengths up to
 // K0 = 2B+D-1 belong to the chain wave.
-template <int R, int B, int D>
+template <int R, int B, int D, bool TRIB = false>
 __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], const double *len_col, int cm, int kp,
                                               bool on, int lane)
 {
-    smm_ring_init_range<R>(A, L, len_col, cm, B + D, 2 * B + D, kp - 1, on, lane);
+    smm_ring_init_range<R>(A, L, len_col, cm, B + D, TRIB ? B + D + 1 : 2 * B + D, kp - 1, on, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -522,13 +530,14 @@ smm_viterbi_kernel(SmmDpArgs a)
 #ifndef SMM_TRI
 #define SMM_TRI 1
 #endif
-    // TRI (BAND mode with D = 0): a TRIANGULAR split of the short lengths.  When target n = (j+1)B + 1 + i is handed over
-    // the pushers have pushed every source up to jB into its slot, i.e. every length k >= B + 1 + i -- if the rings
-    // carry the lengths from B + 1 on.  The chain wave then evaluates k <= B + i only (B(B-1)/2 candidates per block less
-    // than with the uniform split at K0 = 2B - 1).  A slot keeps receiving those lengths for up to B - 1 pushes after
-    // its hand-over, addressed to a target that is gone: the slots are cleared a second time one block later, before
-    // anything real reaches them (band 0 comes back at k = 127, the delayed bands stay off ring indices < 16).
-    constexpr bool TRI = BAND && D == 0 && SMM_TRI;
+    // TRI (blocks of 8: BAND mode, D = 0, and the 256-slot rings, D = 1): a TRIANGULAR split of the short lengths.  When
+    // target n = (j+1)B + 1 + i is handed over the pushers have pushed every source up to jB - D into its slot, i.e. every
+    // length k >= B + D + 1 + i -- if the rings carry the lengths from B + D + 1 on.  The chain wave then evaluates
+    // k <= B + D + i only (B(B-1)/2 candidates per block less than with the uniform split at K0 = 2B + D - 1).  A slot keeps
+    // receiving those lengths for up to B - 1 pushes after its hand-over, addressed to a target that is gone: the slots
+    // are cleared a second time one block later, before anything real reaches them (a ring's own lengths come back at
+    // its far end, the delayed bands of BAND mode stay off ring indices < 16).
+    constexpr bool TRI = SMM_TRI && ((BAND && D == 0) || (PAIR == 0 && B == 8 && B % R == 0 && NW == 8 && CP == 0));
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
@@ -701,7 +710,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double sq[K0 + 1];
                     double acc = ap[i];
                     if constexpr (SMM_ABLATE & 1) return acc;
-                    const int kmax = TRI ? B + i : K0;     // (i is a constant at every call site)
+                    const int kmax = TRI ? B + D + i : K0;     // (i is a constant at every call site)
 #pragma unroll
                     for (int k = 2; k <= K0; ++k)
                         if (k <= kmax) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
@@ -1294,7 +1303,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         double A[SPW][R], L[SPW][R], hd[SPW];
 #pragma unroll
         for (int js = 0; js < SPW; ++js) {
-            smm_ring_init<R, B, D>(A[js], L[js], len + (js < nv ? js * NPd + rank : 0), cm, kp, js < nv, lane);
+            smm_ring_init<R, B, D, TRI>(A[js], L[js], len + (js < nv ? js * NPd + rank : 0), cm, kp, js < nv, lane);
             hd[js] = SMM_NEG_INF;
         }
         // mover role of this wave: block-relative element e = lane + 64 q  <->  HBM offset e, LDS offset (e / cm, e % cm)
@@ -1400,7 +1409,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 for (int js = 0; js < SPW; ++js) {
                     if (js >= nv) break;
                     const int c = js * NPd + rank;
-                    smm_ring_block<R, B, D>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
+                    smm_ring_block<R, B, D, TRI>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
                 if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j
             }

@@ -338,7 +338,14 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
     if (em_us < (mn ? std::atof(mn) : 100.0)) return 0;
     int tmax = 0;
     for (int i = 0; i < b; ++i) tmax = std::max(tmax, hv[i].T);
-    const int thr = tmax - (int)(1.15 * em_us * 1000.0 / 230.0) - 500;                 // (~230 ns per frame of DP: BAND kernel, round 3)
+    // a video of the second part starts em_us later than the critical ones and must not outlast them: the critical set is
+    // the videos within em_us / split_ns + margin frames of the longest.  Same-box scan on cfg3 (scripts/gpu_ab_cfg3.sh,
+    // BAND kernel of round 3, ~250 ns per frame beside a full GPU): 230 / 250 ns 3.72-3.74 ms per step, 300 3.58-3.62,
+    // 400 3.59-3.62, 600 3.65-3.71, 1000+ 3.68-3.70 -- the em_us estimate below (4 TB/s) is already on the long side.
+    // SMM_SPLIT_NS / SMM_SPLIT_MARGIN: tuning aids
+    static const double split_ns = [] { const char *e = std::getenv("SMM_SPLIT_NS"); return e ? std::atof(e) : 330.0; }();
+    static const int split_margin = [] { const char *e = std::getenv("SMM_SPLIT_MARGIN"); return e ? std::atoi(e) : 400; }();
+    const int thr = tmax - (int)(em_us * 1000.0 / split_ns) - split_margin;
     int n1 = 0;
     for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
     if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16) return 0;

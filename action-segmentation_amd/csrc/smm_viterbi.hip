@@ -95,15 +95,6 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_D
 #define SMM_D 1
 #endif
-#ifndef SMM_PF2
-#define SMM_PF2 0      // 1: the mover wave's elp rows are in flight for two blocks instead of one
-#endif
-#ifndef SMM_BAND_LDSB
-#define SMM_BAND_LDSB 0   // 1 (experiment): BAND pushers read every source row with every lane (no broadcast instruction, 16x the LDS traffic)
-#endif
-#ifndef SMM_NPRE
-#define SMM_NPRE 2
-#endif
 #ifndef SMM_MOVER_STATES
 #define SMM_MOVER_STATES 0   // 1 (A/B aid): the mover wave of the 8-wave kernels always owns states, as in rounds 1-2
 #endif
@@ -943,10 +934,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // jB - D, so group g = sources 16g + 1 - D .. 16g + 16 - D is pushed in blocks g BPG + 1 .. (g+1) BPG, and the ring
         // indices 1 .. 2B - 1 + D (= K0) of a push are slots that were handed over already (K0 < SMM_BAND_LO = 16).
         constexpr int BPG = 16 / B;
-#ifndef SMM_BAND_UBX
-#define SMM_BAND_UBX 1
-#endif
-        constexpr int UBB = UB * SMM_BAND_UBX;                               // blocks per iteration of the block loop (whole groups)
+        constexpr int UBB = UB;                                              // blocks per iteration of the block loop (one group)
         static_assert(!BAND || (UB == BPG && K0 < SMM_BAND_LO), "a group is one unrolled iteration of the block loop");
         int hoff[NHR];
         double hvp[NHR];                                                     // the previous block's rows (D = 1: its last row is pushed first)
@@ -956,9 +944,6 @@ smm_viterbi_kernel(SmmDpArgs a)
             hoff[r] = (e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0);
             hvp[r] = SMM_NEG_INF;
         }
-        double hdl[SMM_BAND_LDSB ? SPS : 1];
-#pragma unroll
-        for (int js = 0; js < (SMM_BAND_LDSB ? SPS : 1); ++js) hdl[js] = SMM_NEG_INF;
         uint32_t act[SPS];                                                   // bit m-1: band m is switched on for the current group
         uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
 #pragma unroll
@@ -990,7 +975,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         uint32_t actp[SPS];                                                  // the next group's bands, once decided
 #pragma unroll
         for (int js = 0; js < SPS; ++js) actp[js] = 0;
-        constexpr int NPRE = SMM_NPRE;            // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
+        constexpr int NPRE = 2;                   // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
                                                   // (six measured 7 % SLOWER than two: registers and code for a case that is rare)
         double Lp[NPRE][RS];                      // in ascending 8 js + (m - 1), the order the push loop meets them in
 #pragma unroll
@@ -1014,16 +999,12 @@ smm_viterbi_kernel(SmmDpArgs a)
             hloc[q] = (e / B < C) ? (e % B) * SMM_MAX_STATES_DEV + e / B : 0;
         }
         const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE], pre2[SMM_PF2 ? NE : 1];
+        double pre[NE];
         if (w == MW) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
                 pre[q] = elp[e < e_last ? e : e_last];
-                if constexpr (SMM_PF2) {
-                    const int64_t e2 = e + (int64_t)B * cm;                        // block 2
-                    pre2[SMM_PF2 ? q : 0] = elp[e2 < e_last ? e2 : e_last];
-                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): tables and rings have arrived
@@ -1068,17 +1049,11 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
                     for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = (SMM_PF2 && (jj & 1)) ? pre2[SMM_PF2 ? q : 0] : pre[q];
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
-                        if constexpr (SMM_PF2) {                               // in flight for two blocks (buffers by block parity)
-                            const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
-                            if (jj & 1) pre2[SMM_PF2 ? q : 0] = elp[e < e_last ? e : e_last];
-                            else pre[q] = elp[e < e_last ? e : e_last];
-                        } else {
-                            const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                            pre[q] = elp[e < e_last ? e : e_last];
-                        }
+                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                        pre[q] = elp[e < e_last ? e : e_last];
                     }
                     if (j >= 1) {
                         const int q = j - 1;
@@ -1117,18 +1092,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                 const int dG = (j + 1) / BPG;
 #pragma unroll
                 for (int r = 0; r < NHR; ++r) hvl[r] = (&sh_h[(jj + 1) & 1][0][0])[hoff[r]];
-                double hva[SMM_BAND_LDSB ? SPS : 1][B];
-                if constexpr (SMM_BAND_LDSB) {
-#pragma unroll
-                    for (int js = 0; js < SPS; ++js) {
-                        const int c = js * NPS + rank;
-#pragma unroll
-                        for (int i = 0; i < B; ++i) hva[SMM_BAND_LDSB ? js : 0][i] = sh_h[(jj + 1) & 1][i][c < C ? c : 0];
-                    }
-                }
                 auto src_row = [&](int js, int i) {          // h[(j-1)B + 1 + i] of the wave's js-th state
-                    if constexpr (SMM_BAND_LDSB) return hva[SMM_BAND_LDSB ? js : 0][i];
-                    else return smm_row_bcast(hvl[(B * js + i) / 16], (B * js + i) % 16);
+                    return smm_row_bcast(hvl[(B * js + i) / 16], (B * js + i) % 16);
                 };
                 if (ph == 1 && !(SMM_ABLATE & 32)) {
                     dsrc = qhm[(dG - 7 * qm) & 63];
@@ -1139,7 +1104,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                     for (int js = 0; js < SPS; ++js) {
                         if (js * NPS + rank >= C) break;
-                        smm_push<RS>(As[js], L0[js], SMM_BAND_LDSB ? hdl[SMM_BAND_LDSB ? js : 0] : smm_row_bcast(hvp[(B * js + B - 1) / 16], (B * js + B - 1) % 16), (jj * B) % RS);
+                        smm_push<RS>(As[js], L0[js], smm_row_bcast(hvp[(B * js + B - 1) / 16], (B * js + B - 1) % 16), (jj * B) % RS);
                     }
                 }
 #pragma unroll
@@ -1150,7 +1115,6 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                         for (int i = D; i < B; ++i)
                             smm_push<RS>(As[js], L0[js], src_row(js, i - D), (jj * B + i) % RS);
-                        if constexpr (SMM_BAND_LDSB) hdl[SMM_BAND_LDSB ? js : 0] = src_row(js, B - 1);
                     }
                     if (act[js]) {
                         // the bands that are switched on (rarely any): their rings at this block's phase come from the table
@@ -1250,8 +1214,10 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if constexpr (!(SMM_ABLATE & 64)) {
                     const bool mine = (lanes2 >> lane) & 1ull;
                     const int s0 = (j + 1) * B + 1 - SMM_BAND_DELAY * qm;
-                    // (s0 in 1-B .. -1: the words before the row are read and masked below)
-                    const double *src = qcol + ((mine && s0 > -B) ? s0 : 0);
+                    // (s0 in 1-B .. -1: the words before the row are read and masked below -- a video with a band switched
+                    // on has >= 128 positions of history in front of that row.  Lanes with nothing to fetch read the head of
+                    // the length table: always there, whatever the video's size)
+                    const double *src = (mine && s0 > -B) ? qcol + s0 : lent;
 #pragma unroll
                     for (int i = 0; i < B; ++i) hq[ph][i] = smm_ld_agent(src + i);
                     if ((j + 1) * B + 1 < SMM_BAND_DELAY * SMM_BAND_N) {               // (positions before 0 do not exist)
@@ -1326,16 +1292,12 @@ smm_viterbi_kernel(SmmDpArgs a)
         // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
         // a predicated load has to wait for the previous one into the same register.
         const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE], pre2[SMM_PF2 ? NE : 1];
+        double pre[NE];
         if (w == MW) {
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
                 pre[q] = elp[e < e_last ? e : e_last];
-                if constexpr (SMM_PF2) {
-                    const int64_t e2 = e + (int64_t)B * cm;                        // block 2
-                    pre2[SMM_PF2 ? q : 0] = elp[e2 < e_last ? e2 : e_last];
-                }
             }
         }
         // Everything loaded so far (tables, rings) has to have arrived before the loop: the compiler's wait-count
@@ -1379,17 +1341,11 @@ smm_viterbi_kernel(SmmDpArgs a)
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
                     for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = (SMM_PF2 && (jj & 1)) ? pre2[SMM_PF2 ? q : 0] : pre[q];
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
-                        if constexpr (SMM_PF2) {                               // in flight for two blocks (buffers by block parity)
-                            const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
-                            if (jj & 1) pre2[SMM_PF2 ? q : 0] = elp[e < e_last ? e : e_last];
-                            else pre[q] = elp[e < e_last ? e : e_last];
-                        } else {
-                            const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                            pre[q] = elp[e < e_last ? e : e_last];
-                        }
+                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                        pre[q] = elp[e < e_last ? e : e_last];
                     }
                     if (j >= 1) {
                         const int q = j - 1;

@@ -695,6 +695,21 @@ def test_viterbi_band_mode_first_segment_from_position_zero(first, monkeypatch):
     assert (lab_gpu[:first] == 2).all() and lab_gpu[first] != 2      # the decode does find the long first segment
 
 
+def test_resident_plans_do_not_go_stale():
+    """A staged call is kept by the library (smm_api.hip: resident plans) and reused when the inputs are bit-identical.
+    Two batches of the same size -- hence the same workspace -- but different lengths, decoded A, B, A, B: every decode
+    must equal its oracle, whichever plan the workspace saw last."""
+    pa = make_problem(21, 3, 90, 5, 24)
+    pb = make_problem(22, 3, 90, 5, 24)
+    pa['lengths'] = np.asarray([90, 41, 77])
+    pb['lengths'] = np.asarray([33, 90, 58])
+    ra, rb = run_oracle(pa), run_oracle(pb)
+    for p, (spans, v) in ((pa, ra), (pb, rb), (pa, ra), (pb, rb), (pb, rb), (pa, ra)):
+        out = run_gpu(p)
+        check(p, out, spans, v)
+        assert out['_err'][0] == 0
+
+
 def test_dp_timing_diagnostic():
     """smm_dp_timing_*: one positive duration per DP kernel launch made while it is enabled, none otherwise."""
     ops = _ops()

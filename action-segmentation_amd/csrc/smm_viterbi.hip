@@ -37,8 +37,9 @@
 //
 // HBM traffic per frame (c states): read elp 8c, write history 24c (cumE and gamma frame-major, h state-major), label 8 B.
 //
-// The most expensive videos of a launch -- and every video with 22..23 states -- run on TWO CUs (PAIR mode below: the
-// lattice is cut along the segment length).
+// K > 512 (up to 28 states): BAND mode below -- 128-slot rings shared by nine length bands, eight of them skipped by an
+// exact bound test, blocks of 8 positions.  29..32 states at K > 512, or SMM_BAND=0: the most expensive videos of a launch
+// run on TWO or THREE CUs (PAIR mode below: the lattice is cut along the segment length).
 #include "smm_device.h"
 
 // Diagnostic build only (-DSMM_PROFILE, never shipped or timed): per wave of workgroup 0, cycles between leaving a
@@ -440,17 +441,21 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 // ---------------------------------------------------------------------------------------------------------------
 // BAND mode (PAIR = 2): one workgroup per video at K > 512, the lattice cut along the segment length into BANDS that share
 // ONE ring of 128 upcoming targets per state, and whole bands skipped -- exactly -- while they cannot matter.
-//   band 0     lengths K0 < k <= 127, sources undelayed: always evaluated (what a gang leader's short rings do);
+//   band 0     lengths up to 127 that the chain wave does not evaluate itself (see TRI in the kernel), sources
+//              undelayed: always evaluated (what a gang leader's short rings do);
 //   band m>=1  lengths 16+112m .. 127+112m (m = 1..8 covers 128..1023), fed with the source of 112m positions ago:
 //              slot p of the shared ring, waiting for target n at ring distance kr = n - s, receives
-//              h[s - 112m] + len[kr + 112m]; ring distances below 16 carry -inf in these bands (around the hand-over a
-//              slot changes targets at kr = 6..9, block-wise; a band's own lengths never come that close).
+//              h[s - 112m] + len[kr + 112m]; ring distances below 16 carry -inf in these bands (a slot that was handed
+//              over changes targets; with blocks of 8 the slots within 15 of the current source have been, and a band's
+//              own lengths never come that close).
 // The accumulators A are shared by the bands of a state (all of them aim at the same 128 targets): 2 registers per
-// state for A and 2 per band for its length ring, 36 per state instead of the 64 of a 1024-slot ring.
+// state for A, 2 for band 0's length ring, none for the delayed bands.
+// Blocks are 8 positions and the pushers push the block's own 8 sources (B = 8, D = 0): half as many block barriers as
+// with blocks of 4, and the barrier is where a block's slowest wave makes the other seven wait.
 //
-// Skipping.  Per state and group of 16 sources (4 hand-over blocks) the mover wave keeps hm[g] = max h over the group
-// (LDS ring of 64 groups, lane = state).  A block before the sources of group G are pushed, band m is switched off for
-// the group when
+// Skipping.  Per state and group of 16 sources (2 hand-over blocks) the mover wave keeps hm[g] = max h over the group
+// (LDS ring of 64 groups, lane = state).  Two blocks before the sources of group G are pushed, every pusher wave decides
+// for its own states (lane = (state, band)): band m is switched off for the group when
 //     hm[G - 7m] + max_{k in band m} len[k]   <=   hm[G - 2] + min_{33 <= k <= 174} len[k].
 // Left: an upper bound of every candidate the band would push (its 16 sources are group G - 7m).  Right: for every
 // target n the band can reach, n in [16G + 16, 16G + 142], the best source s* of group G - 2 (the newest group that is
@@ -462,15 +467,11 @@ __device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo 
 // skipped (14 % of the lattice cells are evaluated, profiles/round3_prune_survival.txt), so the frame time no longer
 // grows with K and hardly with the state count.
 // A band that is switched on reads its length ring from the state-major length table (len_t) at the phase of every
-// block -- no registers are kept for the delayed bands --; the h rows of the delayed sources come from the history the
-// mover wave writes anyway (lane = (state, band), 4 positions each, fetched one block ahead with sc1 loads and handed
-// to the pushes with v_readlane).
+// block -- no registers are kept for the delayed bands; the first two rings of a wave are fetched a block ahead --; the
+// h rows of the delayed sources come from the history the mover wave writes anyway (lane = (state, band), 8 positions
+// each, fetched TWO blocks ahead with agent-scope loads and handed to the pushes with v_readlane).
 // (SMM_BAND_DELAY = 112, SMM_BAND_LO = 16, SMM_BAND_N = 8 bands, SMM_BAND_TAB: smm_device.h)
 
-// Length ring of band m at push step t (a multiple of 4): slot p = 2 lane + r is at ring distance kr = (p + off) & 127,
-// off = B + D - t (odd).  The state-major table is stored shifted by one (row[k + 1] = len[k]) so that a lane's two
-// lengths are one aligned 16-byte load; a delayed band keeps NO ring between blocks -- it is read again from the table
-// (8 KB per state, L1-resident while the state is active) at the phase of every block it is switched on for.
 // Lane N of every row of 16 lanes, broadcast to its row (one v_mov_b64_dpp row_newbcast: the only DPP control the 64-bit
 // ALU takes).
 __device__ __forceinline__ double smm_row_bcast(double x, int n)   // n: a constant after unrolling (the switch folds away)
@@ -488,9 +489,13 @@ __device__ __forceinline__ double smm_row_bcast(double x, int n)   // n: a const
 #undef SMM_RB
 }
 
+// Length ring of band m at the phase of a block: slot p = 2 lane + r is at ring distance kr = (p + off) & 127, off = B + D
+// - (push step).  The state-major table is stored shifted by one (row[k + 1] = len[k]): one 16-byte load per lane.  A
+// delayed band keeps NO ring between blocks -- it is read again from the table (8 KB per state, L2-resident) at the phase
+// of every block it is switched on for.
 __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double *lent_row, int off, int m, int kp, int lane)
 {
-    const int kr0 = (lane * 2 + off) & 127;                       // odd; kr0 = 127: the second slot wraps to 0 (masked)
+    const int kr0 = (lane * 2 + off) & 127;                       // (kr0 = 127: the second slot wraps to 0, masked)
     const int k0 = kr0 + SMM_BAND_DELAY * m;
     const double2 v = *reinterpret_cast<const double2 *>(lent_row + k0 + 1);
     L[0] = (kr0 >= SMM_BAND_LO && k0 <= kp - 1) ? v.x : SMM_NEG_INF;

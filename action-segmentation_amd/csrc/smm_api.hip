@@ -378,7 +378,7 @@ struct PlanEntry {
 struct PlanCache {
     std::mutex mu;
     std::unordered_map<uint64_t, std::vector<PlanEntry *>> entries;     // by FNV-1a of the key; compared in full on a hit
-    size_t n = 0, bytes = 0;
+    size_t n = 0, bytes = 0, key_bytes = 0;                            // plans, device bytes, host bytes of their keys
     char *slab = nullptr;                                               // metadata buffers are cut from 1 MB device slabs
     size_t slab_left = 0;
 } g_plans;
@@ -498,7 +498,8 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     bool keep = !capturing;
     if (keep) {
         std::lock_guard<std::mutex> lock(g_plans.mu);
-        keep = g_plans.bytes + p0.o_err <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES;
+        keep = g_plans.bytes + p0.o_err <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES &&
+               g_plans.key_bytes + key.size() <= SMM_PLAN_MAX_BYTES;
         if (keep) {
             dev_meta = plan_alloc(p0.o_err);
             keep = dev_meta != nullptr;
@@ -525,6 +526,7 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     std::lock_guard<std::mutex> lock(g_plans.mu);
     g_plans.entries[hk].push_back(e);
     g_plans.n += 1;
+    g_plans.key_bytes += key.size();
     return SMM_OK;
 }
 

@@ -1,0 +1,43 @@
+"""Randomised soak of the BAND kernel (K > 512, 1..28 states) against the C twin: random / structured / integer lattices, ragged
+batches, lengths from 1 frame to a few thousand, spans clipped at random, with and without EOS.  usage: soak_band.py [seconds] [seed]"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import test_gpu_viterbi as tv
+from oracle import factored as F
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ops = tv._ops()
+t0, n, frames = time.time(), 0, 0
+while time.time() - t0 < budget:
+    c = int(g.integers(1, 29))
+    k = int(g.integers(513, 1025))
+    b = int(g.integers(1, 5))
+    kind = ('random', 'structured', 'integer')[int(g.integers(0, 3))]
+    tmax = int(g.choice([700, 1100, 1600, 2600]))
+    lengths = [int(x) for x in g.integers(1, tmax + 1, size=b)]
+    lengths[int(g.integers(0, b))] = tmax
+    if b > 1 and g.random() < 0.3:
+        lengths[(lengths.index(tmax) + 1) % b] = int(g.integers(1, 20))     # a tiny video beside the long ones
+    seed = int(g.integers(0, 10 ** 6))
+    if kind == 'structured':
+        p = tv.structured_problem(seed, lengths, c, k, margin=float(g.choice([4.0, 18.0])), rate=(5, int(g.choice([60, 400, 900]))))
+    else:
+        p = tv.make_problem(seed, b, tmax, c, k, integer=(kind == 'integer'))
+        p['lengths'] = np.asarray(lengths)
+    out = tv.run_gpu(p)
+    try:
+        spans, v = tv.run_oracle(p)
+    except AssertionError as e:
+        print('ORACLE REFUSED', dict(c=c, k=k, lengths=lengths, kind=kind, seed=seed), e, 'nan in inputs:',
+              {kk: bool(np.isnan(vv).any()) for kk, vv in p.items() if isinstance(vv, np.ndarray) and vv.dtype == np.float64})
+        sys.exit(1)
+    try:
+        tv.check(p, out, spans, v)
+        assert out['_err'][0] == 0
+    except AssertionError as e:
+        print('MISMATCH', dict(c=c, k=k, lengths=lengths, kind=kind, seed=seed), str(e)[:300])
+        sys.exit(1)
+    n += 1; frames += sum(lengths)
+print('soak ok: %d launches, %d frames, %.0f s' % (n, frames, time.time() - t0))

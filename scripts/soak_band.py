@@ -1,5 +1,6 @@
-"""Randomised soak of the BAND kernel (K > 512, 1..28 states) against the C twin: random / structured / integer lattices, ragged
-batches, lengths from 1 frame to a few thousand, spans clipped at random, with and without EOS.  usage: soak_band.py [seconds] [seed]"""
+"""Randomised soak of the Viterbi kernels against the C twin: random / structured / integer lattices, ragged batches, lengths from
+1 frame to a few thousand.  Default: the BAND kernel (K 513..1024, 1..28 states).
+usage: soak_band.py [seconds] [seed] [kmin kmax cmax]     (e.g. 120 2 2 512 32: the ring kernels of every size)"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
@@ -8,11 +9,12 @@ from oracle import factored as F
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+KMIN, KMAX, CMAX = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (513, 1024, 28)
 ops = tv._ops()
 t0, n, frames = time.time(), 0, 0
 while time.time() - t0 < budget:
-    c = int(g.integers(1, 29))
-    k = int(g.integers(513, 1025))
+    c = int(g.integers(1, CMAX + 1))
+    k = int(g.integers(KMIN, KMAX + 1))
     b = int(g.integers(1, 5))
     kind = ('random', 'structured', 'integer')[int(g.integers(0, 3))]
     tmax = int(g.choice([700, 1100, 1600, 2600]))
@@ -22,7 +24,7 @@ while time.time() - t0 < budget:
         lengths[(lengths.index(tmax) + 1) % b] = int(g.integers(1, 20))     # a tiny video beside the long ones
     seed = int(g.integers(0, 10 ** 6))
     if kind == 'structured':
-        p = tv.structured_problem(seed, lengths, c, k, margin=float(g.choice([4.0, 18.0])), rate=(5, int(g.choice([60, 400, 900]))))
+        p = tv.structured_problem(seed, lengths, c, k, margin=float(g.choice([4.0, 18.0])), rate=(min(5, max(1, k // 4)), max(2, min(k - 1, int(g.choice([60, 400, 900]))))))
     else:
         p = tv.make_problem(seed, b, tmax, c, k, integer=(kind == 'integer'))
         p['lengths'] = np.asarray(lengths)

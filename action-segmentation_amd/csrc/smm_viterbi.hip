@@ -40,6 +40,7 @@
 // K > 512 (up to 28 states): BAND mode below -- 128-slot rings shared by nine length bands, eight of them skipped by an
 // exact bound test, blocks of 8 positions.  29..32 states at K > 512, or SMM_BAND=0: the most expensive videos of a launch
 // run on TWO or THREE CUs (PAIR mode below: the lattice is cut along the segment length).
+#include <type_traits>
 #include "smm_device.h"
 
 // Diagnostic build only (-DSMM_PROFILE, never shipped or timed): per wave of workgroup 0, cycles between leaving a
@@ -98,6 +99,9 @@ __device__ __forceinline__ void smm_lds_barrier()
 #endif
 #ifndef SMM_MOVER_STATES
 #define SMM_MOVER_STATES 0   // 1 (A/B aid): the mover wave of the 8-wave kernels always owns states, as in rounds 1-2
+#endif
+#ifndef SMM_CHAIN_DUAL
+#define SMM_CHAIN_DUAL 1     // 0 (A/B aid): the chain wave folds the launch's HF sources per lane group for every video
 #endif
 #ifndef SMM_ABLATE
 #define SMM_ABLATE 0   // development builds only (results are WRONG, timing experiments): bit 0 chain wave without the
@@ -653,128 +657,140 @@ smm_viterbi_kernel(SmmDpArgs a)
         constexpr bool GAMROW = BAND ? bool(SMM_BAND_GAMROW) : ((B > 4) || (R < 4));   // a separate gamma broadcast row (see the position loop)
         constexpr bool TAILFREE = R < 16 || BAND;          // no bounds tests inside a block (see the position loop; BAND:
                                                            // the chain wave alone bounds the frame, whatever the state count)
-        constexpr int LG = (HF == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HF = 4, <= 16 states) four of 16
-        const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
-        const bool live = to < C;
-        double tr[HF];                                    // trans[to][half*HF + i]
-#pragma unroll
-        for (int i = 0; i < HF; ++i) {
-            const int f = half * HF + i;
-            tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
-        }
-        double lk[K0 + 1];                                // len[k][to], k = 1..K0
-#pragma unroll
-        for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
-        double hq[M];                                     // h[n][to], slot n mod M
-#pragma unroll
-        for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
-        hq[0] = live ? init[to] : SMM_NEG_INF;
-        double cum = 0.0;
-        // Both halves of the wave compute every position; only the lower half's results are wanted in LDS.  The upper
-        // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
-        // s_and_saveexec / branch / s_or groups per position) on the serial path.
-        double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
-        double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
-        double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
-        double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
-        double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
-        // own ring (CP): state cx, same code as a pusher with one state
-        constexpr int cx = NP * SPW;
-        const bool has1 = CP && cx < C;
-        double A1[CP ? R : 1], L1[CP ? R : 1], hd1 = SMM_NEG_INF;
-        if constexpr (CP) smm_ring_init<R, B, D>(A1, L1, len + cx, cm, kp, has1, lane);
-        constexpr int UM = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even,
-        constexpr int UC = (CP && UB > UM) ? UB : UM;     // and a multiple of UB when the wave owns a ring
-        SMM_PROF_DECL;
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
-        for (int j0 = 0; j0 < J; j0 += UC) {
-#pragma unroll
-            for (int jj = 0; jj < UC; ++jj) {
-                const int j = j0 + jj;
-                if (j >= J) break;
-                double ap[B], ev[B];
-#pragma unroll
-                for (int i = 0; i < B; ++i) {
-                    ap[i] = sh_apart[jj & 1][i][to];
-                    if (GANG) ap[i] = smm_fmax(ap[i], sh_along[GANG ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
-                    ev[i] = sh_e[jj & 1][i][to];
-                }
-                // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
-                // candidates k = 2..K0, A'[n+1], cumE[n+1] -- is evaluated in the shadow of position n's LDS round trip
-                // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
-                auto partial = [&](int i) {                  // max(A'[n], max_{k=2..K0} h[n-k] + len[k]), n = jB+1+i
-                    double sq[K0 + 1];
-                    double acc = ap[i];
-                    if constexpr (SMM_ABLATE & 1) return acc;
-                    const int kmax = TRI ? B + D + i : K0;     // (i is a constant at every call site)
-#pragma unroll
-                    for (int k = 2; k <= K0; ++k)
-                        if (k <= kmax) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
-#pragma unroll
-                    for (int k = K0; k >= 2; --k)
-                        if (k <= kmax) acc = smm_fmax(acc, sq[k]);
-                    return acc;
-                };
-                double pacc = partial(0);
-                double cumn = (SMM_ABLATE & 2) ? ev[0] : cum + ev[0];
-#pragma unroll
-                for (int i = 0; i < B; ++i) {
-                    // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
-                    // also those past T in the tail of the last block (their rows are never stored, published or read):
-                    // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
-                    // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
-                    // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
-                    // shares the chain wave's SIMD): those keep the tests.
-                    const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
-                    if constexpr (!TAILFREE) { if (n > T) break; }
-                    const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
-                    cum = cumn;
-                    const double gm = cum + acc;
-                    // The transition reads gamma back from its history staging row (one LDS store less per position:
-                    // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
-                    // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
-                    if constexpr (GAMROW) st_gam[0] = gm;
-                    st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
-                    if constexpr (!(SMM_ABLATE & 2)) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
-                    if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
-                    if (TAILFREE || n < T) {
-                        // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HF ..
-                        const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HF] : &sh_g[jj & 1][i][half * HF]);
-                        double2 gv[HF / 2];
-#pragma unroll
-                        for (int q = 0; q < HF / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (i + 1 < B) {
-                            pacc = partial(i + 1 < B ? i + 1 : 0);
-                            cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        double bq[4];                                // 4 independent max chains
-#pragma unroll
-                        for (int q = 0; q < ((SMM_ABLATE & 16) ? 2 : HF / 2); ++q) {
-                            if (q < 2) {
-                                bq[2 * q] = gv[q].x + tr[2 * q];
-                                bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
-                            } else {
-                                bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv[q].x + tr[2 * q]);
-                                bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
-                            }
-                        }
-                        double bm = smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3]));
-                        if constexpr (HF == 4) bm = smm_max_rows16(bm);
-                        const double beta = smm_max_halves(bm);
-                        const double hcur = beta - cum;
-                        hq[(jj * B + 1 + i) % M] = hcur;
-                        st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
-                    }
-                }
-                if constexpr (CP) {
-                    if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
-                }
-                if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j (LDS-only: see smm_lds_barrier)
+        // The transition's fold is compiled for the launch's largest class set (HF source states per lane group) AND,
+        // in BAND launches of more than 16 states, for <= 16 states (four lane groups of 16, four sources each): a
+        // corpus mixes tasks of 11..23 states in one launch, and a video of 11 states need not fold 24 sources.
+        auto chain = [&](auto hf_c) {
+            constexpr int HFC = decltype(hf_c)::value;
+            constexpr int LG = (HFC == 4) ? 16 : 32;           // lanes per group: two groups of 32, or (HFC = 4, <= 16 states) four of 16
+            const int to = lane & (LG - 1), half = lane / LG;  // (`half`: the lane's group)
+            const bool live = to < C;
+            double tr[HFC];                                    // trans[to][half*HFC + i]
+    #pragma unroll
+            for (int i = 0; i < HFC; ++i) {
+                const int f = half * HFC + i;
+                tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
             }
+            double lk[K0 + 1];                                // len[k][to], k = 1..K0
+    #pragma unroll
+            for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
+            double hq[M];                                     // h[n][to], slot n mod M
+    #pragma unroll
+            for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
+            hq[0] = live ? init[to] : SMM_NEG_INF;
+            double cum = 0.0;
+            // Both halves of the wave compute every position; only the lower half's results are wanted in LDS.  The upper
+            // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
+            // s_and_saveexec / branch / s_or groups per position) on the serial path.
+            double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
+            double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
+            double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
+            double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
+            double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
+            // own ring (CP): state cx, same code as a pusher with one state
+            constexpr int cx = NP * SPW;
+            const bool has1 = CP && cx < C;
+            double A1[CP ? R : 1], L1[CP ? R : 1], hd1 = SMM_NEG_INF;
+            if constexpr (CP) smm_ring_init<R, B, D>(A1, L1, len + cx, cm, kp, has1, lane);
+            constexpr int UM = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even,
+            constexpr int UC = (CP && UB > UM) ? UB : UM;     // and a multiple of UB when the wave owns a ring
+            SMM_PROF_DECL;
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
+            for (int j0 = 0; j0 < J; j0 += UC) {
+    #pragma unroll
+                for (int jj = 0; jj < UC; ++jj) {
+                    const int j = j0 + jj;
+                    if (j >= J) break;
+                    double ap[B], ev[B];
+    #pragma unroll
+                    for (int i = 0; i < B; ++i) {
+                        ap[i] = sh_apart[jj & 1][i][to];
+                        if (GANG) ap[i] = smm_fmax(ap[i], sh_along[GANG ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
+                        ev[i] = sh_e[jj & 1][i][to];
+                    }
+                    // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
+                    // candidates k = 2..K0, A'[n+1], cumE[n+1] -- is evaluated in the shadow of position n's LDS round trip
+                    // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
+                    auto partial = [&](int i) {                  // max(A'[n], max_{k=2..K0} h[n-k] + len[k]), n = jB+1+i
+                        double sq[K0 + 1];
+                        double acc = ap[i];
+                        if constexpr (SMM_ABLATE & 1) return acc;
+                        const int kmax = TRI ? B + D + i : K0;     // (i is a constant at every call site)
+    #pragma unroll
+                        for (int k = 2; k <= K0; ++k)
+                            if (k <= kmax) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
+    #pragma unroll
+                        for (int k = K0; k >= 2; --k)
+                            if (k <= kmax) acc = smm_fmax(acc, sq[k]);
+                        return acc;
+                    };
+                    double pacc = partial(0);
+                    double cumn = (SMM_ABLATE & 2) ? ev[0] : cum + ev[0];
+    #pragma unroll
+                    for (int i = 0; i < B; ++i) {
+                        // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
+                        // also those past T in the tail of the last block (their rows are never stored, published or read):
+                        // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
+                        // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
+                        // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
+                        // shares the chain wave's SIMD): those keep the tests.
+                        const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
+                        if constexpr (!TAILFREE) { if (n > T) break; }
+                        const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
+                        cum = cumn;
+                        const double gm = cum + acc;
+                        // The transition reads gamma back from its history staging row (one LDS store less per position:
+                        // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
+                        // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
+                        if constexpr (GAMROW) st_gam[0] = gm;
+                        st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
+                        if constexpr (!(SMM_ABLATE & 2)) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
+                        if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
+                        if (TAILFREE || n < T) {
+                            // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HFC ..
+                            const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HFC] : &sh_g[jj & 1][i][half * HFC]);
+                            double2 gv[HFC / 2];
+    #pragma unroll
+                            for (int q = 0; q < HFC / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (i + 1 < B) {
+                                pacc = partial(i + 1 < B ? i + 1 : 0);
+                                cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            double bq[4];                                // 4 independent max chains
+    #pragma unroll
+                            for (int q = 0; q < ((SMM_ABLATE & 16) ? 2 : HFC / 2); ++q) {
+                                if (q < 2) {
+                                    bq[2 * q] = gv[q].x + tr[2 * q];
+                                    bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
+                                } else {
+                                    bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv[q].x + tr[2 * q]);
+                                    bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
+                                }
+                            }
+                            double bm = smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3]));
+                            if constexpr (HFC == 4) bm = smm_max_rows16(bm);
+                            const double beta = smm_max_halves(bm);
+                            const double hcur = beta - cum;
+                            hq[(jj * B + 1 + i) % M] = hcur;
+                            st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
+                        }
+                    }
+                    if constexpr (CP) {
+                        if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
+                    }
+                    if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j (LDS-only: see smm_lds_barrier)
+                }
+            }
+            SMM_PROF_OUT();
+        };
+        if constexpr (BAND && HF > 4 && SMM_CHAIN_DUAL) {
+            if (C <= 16) chain(std::integral_constant<int, 4>{});
+            else chain(std::integral_constant<int, HF>{});
+        } else {
+            chain(std::integral_constant<int, HF>{});
         }
-        SMM_PROF_OUT();
     } else if (GANG && lead) {
         // ============================================================================ pusher waves of a pair's leader
         // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21, rank+28 and long range

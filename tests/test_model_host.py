@@ -103,3 +103,22 @@ def test_prepared_cache_key_covers_the_constraints():
     assert b is not a and float(b.cons.min()) == -123.0
     model.clear_prepared()
     assert model.prepare(data) is not b
+
+
+def test_shard_costs_follow_the_kernel_that_will_run():
+    """batch_cost balances shards: lattice cells for spans up to 512; for longer spans (the Viterbi kernel's BAND mode) a
+    time per frame that hardly depends on the state count -- and either way every batch lands on exactly one rank."""
+    from action_segmentation_amd.batching import batch_cost
+    from action_segmentation_amd.distributed import shard_batches
+    data = synth.SynthDatasplit('tiny', seed=3)
+    batches = data.batch_sampler(2, True, False).batches
+    for max_k in (12, 1024):
+        costs = [batch_cost(data, keys, max_k) for keys in batches]
+        assert all(c > 0 for c in costs)
+        owned = sorted(i for r in range(3) for i in shard_batches(batches, costs, r, 3))
+        assert owned == list(range(len(batches)))
+    # spans > 512: cost per frame between the 11- and the 23-state figure, i.e. nearly flat in the state count
+    keys = batches[0]
+    frames = sum(int(data[k]['features'].shape[0]) for k in keys)
+    per_frame = batch_cost(data, keys, 1024) / frames
+    assert 170.0 < per_frame < 170.0 + 3.3 * 33

@@ -19,6 +19,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
          "-mllvm", "-pragma-unroll-threshold=1048576", "-mllvm", "-unroll-threshold=1048576"]
 
 
+# per translation unit: the Viterbi kernels take fmax() as a bare v_max_f64 (smm_device.h: smm_fmax) -- no NaN ever enters
+# the DP (inputs are finite or -inf and nothing subtracts infinities), and -fno-honor-nans says so to the compiler
+UNIT_FLAGS = {"smm_viterbi.hip": ["-fno-honor-nans", "-DSMM_FMAX_BUILTIN"]}
+
+
 def _extra_flags():
     # development aid only (SMM_DEV_FLAGS="-DSMM_DEV_R=16"): never set by build() callers in the repo
     return os.environ.get("SMM_DEV_FLAGS", "").split()
@@ -51,7 +56,7 @@ def build(force=False, verbose=False):
     todo = [s for s in SOURCES if _stale_obj(s, force)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + _extra_flags() + ["-c", "-o", _obj(src), os.path.join(CSRC, src)]
+        cmd = [hipcc] + FLAGS + UNIT_FLAGS.get(src, []) + _extra_flags() + ["-c", "-o", _obj(src), os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

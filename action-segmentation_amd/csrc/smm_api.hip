@@ -720,6 +720,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         a.flags = dbg ? std::atoi(dbg) : 0;
     }
     if (no_eos) a.flags |= 8;
+    if (const char *e = std::getenv("SMM_SPEC")) { if (std::atoi(e) == 0) a.flags |= 256; }   // A/B aid: no speculative transition
     a.n_pairs = st.n_pairs;
     a.pair_flags = st.pair_flags;
     if (st.pairs_cover_big) a.flags |= 4;

@@ -45,7 +45,8 @@ struct SmmDpArgs {
                                // backward; bit 2: every video with more than 21 states is in the paired prefix;
                                // bit 3 (8): no EOS (add_eos=False; SmmVideo::T = frames - 1); bit 4 (16): recovery launch
                                // behind a gang launch; bit 5 (32): test hook -- gang 0's followers never show up;
-                               // bit 6 (64): logZ forward and time-reversed runs in one launch (2 workgroups per video)
+                               // bit 6 (64): logZ forward and time-reversed runs in one launch (2 workgroups per video);
+                               // bit 7 (128): Viterbi BAND mode; bit 8 (256): Viterbi without the speculative transition (A/B aid)
     int32_t n_pairs;           // the first n_pairs entries of order[] run as leader / follower pairs (smm_viterbi.hip)
     const double *trans_t;     // logZ, both directions in one launch (flags bit 6): transposed tables [g][c_max][c_max]
     double *logz_b;            // ... and where the reversed runs put their closing value [b]
@@ -104,9 +105,15 @@ __device__ __forceinline__ float smm_wave_ror1f(float x)
 // (no NaNs ever enter the DP: inputs are finite or -inf and nothing subtracts infinities).
 __device__ __forceinline__ double smm_fmax(double a, double b)
 {
+#ifdef SMM_FMAX_BUILTIN
+    // translation units compiled with -fno-honor-nans: fmax lowers to a bare v_max_f64 there, and -- unlike the inline asm --
+    // the compiler knows its latency and hazards (no s_nop behind every max, free scheduling)
+    return __builtin_fmax(a, b);
+#else
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 
 // max(x[lane], x[lane ^ 32]) in every lane: one v_permlane32_swap per 32-bit half

@@ -113,8 +113,12 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
     }
     // hand A' of block j+1 to the chain wave (nats, fp64) and clear those slots
     auto hand = [&](int r, double *dst) {
+        // (M + log2 S summed in fp64: in fp32 the sum of an exponent of magnitude ~8 and a fraction is rounded to 5e-7 --
+        // once per POSITION and state, a random walk that reached 5e-5 in log Z at T = 8192 (round 4:
+        // tests/test_gpu_fullsize.py::test_logz_gradient_error_does_not_grow_with_the_lattice); M is integer-valued,
+        // log2 S in [0, 10] carries 6e-8)
         const float lg = __builtin_amdgcn_logf(S[r]);      // log2; -inf for an empty slot
-        *dst = (S[r] > 0.f) ? (ref + (double)(M[r] + lg)) * SMM_LN2 : SMM_NEG_INF;
+        *dst = (S[r] > 0.f) ? ((ref + (double)M[r]) + (double)lg) * SMM_LN2 : SMM_NEG_INF;
         M[r] = SMM_M_EMPTY;
         S[r] = 0.f;
     };

@@ -108,6 +108,9 @@ __device__ __forceinline__ void smm_lds_barrier()
                        // candidates k = 2..K0, bit 1 without the cumE add / store, bit 2 pushers push nothing, bit 3 mover
                        // keeps no books, bit 4 transition over a third of the sources
 #endif
+#ifndef SMM_SPEC
+#define SMM_SPEC 1       // the chain wave's speculative transition (see SPEC in the kernel); 0: compiled out (A/B aid)
+#endif
 #ifndef SMM_B8_R
 #define SMM_B8_R 4       // blocks of 8 positions for the 256-slot rings (round 3, same box: cfg2 DP 0.481 -> 0.456 ms; the 64-slot
 #endif                   // rings of cfg4 measured 10 % SLOWER with them, 0.406 -> 0.445 ms, and keep blocks of 4)
@@ -609,6 +612,10 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
+    // speculative transition (see SPEC in the chain wave): the video's transition table and, per (leader cs, source c),
+    // how far gamma[c] must lie below gamma[cs] for source c to lose against cs at EVERY target
+    __shared__ double sh_tr[SMM_SPEC ? SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV : 1];     // [to][from]
+    __shared__ double sh_dl[SMM_SPEC ? SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV : 1];     // [cs][c]
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
     __shared__ int sh_guess[SMM_MAX_STATES_DEV + 1];   // back-trace: the predecessor state last seen / expected for each state
@@ -636,7 +643,35 @@ smm_viterbi_kernel(SmmDpArgs a)
             else hh[(size_t)c * (T + 1)] = init[c];
         }
     }
+    constexpr bool SPEC = SMM_SPEC && !GANG && (R < 16 || BAND);   // (the kernels whose chain wave computes whole blocks: TAILFREE below)
+    if constexpr (SPEC) {
+        for (int e = threadIdx.x; e < SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV; e += blockDim.x) {
+            const int to = e / SMM_MAX_STATES_DEV, f = e % SMM_MAX_STATES_DEV;
+            sh_tr[e] = (to < C && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
+        }
+    }
     __syncthreads();
+    if constexpr (SPEC) {
+        // dl[cs][c] = min over targets of (trans[to][cs] - trans[to][c]), clipped at 0 and pushed one part in 2^50 further
+        // down: gamma[c] - gamma[cs] <= dl[cs][c] (both sides rounded) then implies gamma[c] + trans[to][c] <=
+        // gamma[cs] + trans[to][cs] in real arithmetic for every target, hence -- rounding is monotone -- for the rounded
+        // sums the fold compares.  A target that source c cannot reach (-inf) asks for nothing; one that only cs cannot
+        // reach can never be granted (-inf).
+        for (int e = threadIdx.x; e < SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV; e += blockDim.x) {
+            const int cs = e / SMM_MAX_STATES_DEV, c = e % SMM_MAX_STATES_DEV;
+            double d = 0.0;
+            if (cs < C && c < C) {
+                for (int to = 0; to < C; ++to) {
+                    const double x = sh_tr[to * SMM_MAX_STATES_DEV + cs], y = sh_tr[to * SMM_MAX_STATES_DEV + c];
+                    if (y == SMM_NEG_INF) continue;
+                    d = fmin(d, x - y);
+                }
+                d = d * (1.0 + 0x1p-50);
+            }
+            sh_dl[e] = d;
+        }
+        __syncthreads();
+    }
 
     // The chain wave touches LDS only (a wave that waits for a load waits for its older stores as well: vmcnt is one
     // in-order counter).  HBM traffic is moved block-wise by pusher wave MW: it fetches the elp rows two blocks ahead
@@ -695,6 +730,26 @@ smm_viterbi_kernel(SmmDpArgs a)
             constexpr int UM = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even,
             constexpr int UC = (CP && UB > UM) ? UB : UM;     // and a multiple of UB when the wave owns a ring
             SMM_PROF_DECL;
+            // SPEC: the transition SPECULATED on one source.  beta[to] = max_c (gamma[c] + trans[to][c]) is the largest piece of
+            // a position (12 adds, 12 maxes, 6 LDS reads behind an LDS round trip at 17..24 states), and on real data its
+            // result is decided by ONE source nearly all the time: the state cs the frames currently belong to leads every
+            // other gamma by tens to hundreds of nats.  A FAST position reads gamma[cs] from lane cs (one v_readlane per
+            // half: no LDS on the serial path) and checks in every source lane c that gamma[c] - gamma[cs] <= dl[cs][c]
+            // (sh_dl, see the prologue: source c then loses against cs at every target, in the rounded sums too, so the
+            // maximum IS the cs term, bit for bit): one compare and one scalar branch; if every lane agrees,
+            // beta[to] = gamma[cs] + trans[to][cs], else the position takes the full fold below -- the check comes before
+            // anything is used, nothing is ever undone.  Behind a block with a full position the leader is looked for again
+            // (arg-max of the block's last gamma row + the same check); lattices on which it never holds -- masked transition tables (the
+            // check must hold for EVERY target), flat emissions -- try again with exponential back-off (every 32nd block at
+            // most) and otherwise run exactly as before.
+#ifdef SMM_PROFILE
+            unsigned long long p_fastn = 0;                   // (diagnostic: positions of workgroup 0 that took the fast transition -> slot 34: wave 0 has no blocks with j mod 4 = 2)
+#endif
+            bool spec = false;                                // the leader cs is believed to hold
+            int cs = 0, spec_wait = 0, spec_back = 1;         // leader; blocks until the next try; back-off
+            double trS = SMM_NEG_INF, dlt = SMM_NEG_INF;      // trans[to][cs], dl[cs][to] (-inf: no leader holds, every position takes the full fold)
+            const bool spec_off = !SPEC || (a.flags & 256);   // (SMM_SPEC=0: A/B aid)
+            if (spec_off) spec_wait = 0x7fffffff;
             __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the tables have arrived; the loop is LDS-only
             for (int j0 = 0; j0 < J; j0 += UC) {
     #pragma unroll
@@ -726,55 +781,126 @@ smm_viterbi_kernel(SmmDpArgs a)
                     };
                     double pacc = partial(0);
                     double cumn = (SMM_ABLATE & 2) ? ev[0] : cum + ev[0];
+                    const bool spec0 = spec;
+                    double gm_last = SMM_NEG_INF;                // gamma of the block's last position, if that one took the full fold
+                    // the full transition of position i of the block: beta[to] = max_from (gamma[from] + trans[to][from]); this
+                    // lane group folds sources half*HFC ..  (gamma comes back from LDS: the row the chain wave has just written)
+                    auto fold_read = [&](int i, double2 (&gv)[HFC / 2]) {
+                        const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HFC] : &sh_g[jj & 1][i][half * HFC]);
     #pragma unroll
-                    for (int i = 0; i < B; ++i) {
-                        // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
-                        // also those past T in the tail of the last block (their rows are never stored, published or read):
-                        // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
-                        // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
-                        // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
-                        // shares the chain wave's SIMD): those keep the tests.
-                        const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
-                        if constexpr (!TAILFREE) { if (n > T) break; }
-                        const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
-                        cum = cumn;
-                        const double gm = cum + acc;
-                        // The transition reads gamma back from its history staging row (one LDS store less per position:
-                        // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
-                        // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
-                        if constexpr (GAMROW) st_gam[0] = gm;
-                        st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
-                        if constexpr (!(SMM_ABLATE & 2)) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
-                        if (n == T) st_fin[0] = gm;                                  // (wave-uniform, once per video)
-                        if (TAILFREE || n < T) {
-                            // beta[to] = max_from (gamma[from] + trans[to][from]); this half folds sources half*HFC ..
-                            const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HFC] : &sh_g[jj & 1][i][half * HFC]);
-                            double2 gv[HFC / 2];
+                        for (int q = 0; q < HFC / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
+                    };
+                    auto fold_reduce = [&](const double2 (&gv)[HFC / 2]) {
+                        double bq[4];                                // 4 independent max chains
     #pragma unroll
-                            for (int q = 0; q < HFC / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (i + 1 < B) {
-                                pacc = partial(i + 1 < B ? i + 1 : 0);
-                                cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
+                        for (int q = 0; q < ((SMM_ABLATE & 16) ? 2 : HFC / 2); ++q) {
+                            if (q < 2) {
+                                bq[2 * q] = gv[q].x + tr[2 * q];
+                                bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
+                            } else {
+                                bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv[q].x + tr[2 * q]);
+                                bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
-                            double bq[4];                                // 4 independent max chains
+                        }
+                        double bm = smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3]));
+                        if constexpr (HFC == 4) bm = smm_max_rows16(bm);
+                        return smm_max_halves(bm);
+                    };
+                    // MODE 0: every position takes the full fold (no leader holds; kernels without SPEC): the next position's
+                    // candidates are evaluated in the shadow of the fold's LDS round trip.  MODE 1: a leader holds at the
+                    // block's start: the fast transition, checked per position, the full fold (unshadowed: rare) where it fails.
+                    auto run_block = [&](auto mode_c) {
+                        constexpr int MODE = decltype(mode_c)::value;
     #pragma unroll
-                            for (int q = 0; q < ((SMM_ABLATE & 16) ? 2 : HFC / 2); ++q) {
-                                if (q < 2) {
-                                    bq[2 * q] = gv[q].x + tr[2 * q];
-                                    bq[2 * q + 1] = gv[q].y + tr[2 * q + 1];
+                        for (int i = 0; i < B; ++i) {
+                            // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
+                            // also those past T in the tail of the last block (their rows are never stored, published or read):
+                            // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
+                            // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
+                            // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
+                            // shares the chain wave's SIMD): those keep the tests.
+                            const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
+                            if constexpr (!TAILFREE) { if (n > T) break; }
+                            const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
+                            cum = cumn;
+                            const double gm = cum + acc;
+                            // The transition reads gamma back from its history staging row (one LDS store less per position:
+                            // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
+                            // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
+                            if constexpr (GAMROW) st_gam[0] = gm;
+                            if constexpr (!(SMM_ABLATE & 256)) st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
+                            if constexpr (!(SMM_ABLATE & (2 | 256))) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
+                            // (TAILFREE: gamma[T] is read back from the block's rows behind the loop -- no test per position)
+                            if constexpr (!TAILFREE) { if (n == T) st_fin[0] = gm; }      // (wave-uniform, once per video)
+                            if (TAILFREE || n < T) {
+                                double hcur;
+                                if constexpr (MODE == 1) {
+                                    // (while no leader holds -- after a failed check earlier in this block -- dlt is -inf and lane cs
+                                    // itself objects)
+                                    const double gs = (SMM_ABLATE & 512) ? dlt : smm_readlane(gm, cs);
+                                    const bool bad = (SMM_ABLATE & 512) ? spec_wait == 12345 : __ballot(gm - gs > dlt) != 0;
+                                    const double hfast = (gs + trS) - cum;
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (i + 1 < B) {       // the next position's candidates: between the compare and the branch on it
+                                        pacc = partial(i + 1 < B ? i + 1 : 0);
+                                        cumn = cum + ev[i + 1 < B ? i + 1 : 0];
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    // (pins: the compiler would otherwise sink all of this behind the branch, which then waits for
+                                    // its compare with nothing else to issue)
+                                    asm volatile("" : "+v"(pacc), "+v"(cumn));
+                                    double hfast_p = hfast;
+                                    asm volatile("" : "+v"(hfast_p));
+                                    if (__builtin_expect(bad, 0)) {
+                                        double2 gv[HFC / 2];
+                                        fold_read(i, gv);
+                                        hcur = fold_reduce(gv) - cum;
+                                        if (spec) { spec = false; dlt = SMM_NEG_INF; }   // the leader lost its lead: the next one is looked for behind this block
+                                        if (i == B - 1) gm_last = gm;
+                                    } else {
+                                        hcur = hfast_p;
+#ifdef SMM_PROFILE
+                                        ++p_fastn;
+#endif
+                                    }
                                 } else {
-                                    bq[(2 * q) & 3] = smm_fmax(bq[(2 * q) & 3], gv[q].x + tr[2 * q]);
-                                    bq[(2 * q + 1) & 3] = smm_fmax(bq[(2 * q + 1) & 3], gv[q].y + tr[2 * q + 1]);
+                                    double2 gv[HFC / 2];
+                                    fold_read(i, gv);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (i + 1 < B) {
+                                        pacc = partial(i + 1 < B ? i + 1 : 0);
+                                        cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    hcur = fold_reduce(gv) - cum;
+                                    if (i == B - 1) gm_last = gm;
                                 }
+                                hq[(jj * B + 1 + i) % M] = hcur;
+                                if constexpr (!(SMM_ABLATE & 1024)) st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
                             }
-                            double bm = smm_fmax(smm_fmax(bq[0], bq[1]), smm_fmax(bq[2], bq[3]));
-                            if constexpr (HFC == 4) bm = smm_max_rows16(bm);
-                            const double beta = smm_max_halves(bm);
-                            const double hcur = beta - cum;
-                            hq[(jj * B + 1 + i) % M] = hcur;
-                            st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
+                        }
+                    };
+                    if (SPEC && spec) run_block(std::integral_constant<int, SPEC ? 1 : 0>{});
+                    else run_block(std::integral_constant<int, 0>{});
+                    if constexpr (SPEC) {
+                        if (spec0 && !spec) { spec_wait = 0; spec_back = 1; }    // a leader lost its lead in this block: try at once
+                        if (!spec && --spec_wait < 0) {
+                            // who leads the block's last gamma row (lane group 0; the other groups hold copies), and does every
+                            // other source lose against it at every target?  (a fast last position: its leader held, and the
+                            // flag is still up)
+                            const double v = (live && half == 0) ? gm_last : SMM_NEG_INF;
+                            const double rmax = smm_row_max16(v);
+                            const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
+                            const unsigned long long lead_m = __ballot(v == best && live && half == 0);
+                            bool ok = false;
+                            if (lead_m) {
+                                cs = __builtin_amdgcn_readfirstlane(__ffsll(lead_m) - 1);
+                                trS = sh_tr[to * SMM_MAX_STATES_DEV + cs];
+                                dlt = sh_dl[cs * SMM_MAX_STATES_DEV + to];
+                                ok = __ballot(gm_last - best > dlt) == 0;
+                            }
+                            if (ok) { spec = true; spec_back = 1; }
+                            else { dlt = SMM_NEG_INF; spec_wait = spec_back; spec_back = spec_back < 32 ? 2 * spec_back : 32; }
                         }
                     }
                     if constexpr (CP) {
@@ -783,6 +909,14 @@ smm_viterbi_kernel(SmmDpArgs a)
                     if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j (LDS-only: see smm_lds_barrier)
                 }
             }
+            if constexpr (TAILFREE) {
+                // gamma[T] for the closing step: the row of position T in the last block's staging rows (written by lane
+                // group 0; every wave reads sh_gfin behind the __syncthreads() that follows the loops)
+                if (half == 0) sh_gfin[to] = sh_g[(J - 1) & 1][(T - 1) % B][to];
+            }
+#ifdef SMM_PROFILE
+            p_ph[2] = p_fastn;                                // (slot 34 of the stamps: wave 0 has no blocks with j mod 4 = 2)
+#endif
             SMM_PROF_OUT();
         };
         if constexpr (BAND && HF > 4 && SMM_CHAIN_DUAL) {

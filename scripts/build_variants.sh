@@ -2,7 +2,7 @@
 # usage: bash scripts/build_variants.sh tag1 "-DSMM_ABLATE=1" tag2 "-DSMM_ABLATE=3" ...   (objects of the normal build must exist)
 set -e
 cd "$(dirname "$0")/../action-segmentation_amd/csrc"
-F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -mllvm -pragma-unroll-threshold=1048576 -mllvm -unroll-threshold=1048576"
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -mllvm -pragma-unroll-threshold=1048576 -mllvm -unroll-threshold=1048576 ${SMM_VARIANT_NAN--fno-honor-nans -DSMM_FMAX_BUILTIN}"
 pids=""
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2

@@ -49,6 +49,8 @@ def run(b, T, C, K, lib='libsmmdp_prof16.so'):
     print(f"b={b} T={T} C={C} K={K}: {e0.elapsed_time(e1):.3f} ms = {e0.elapsed_time(e1) * 1e6 / T:.0f} ns/frame; band-blocks evaluated "
           f"{raw.view(np.int32)[3]} of {b * (T // (4 if os.environ.get('SMM_BAND_B') == '4' else 8)) * C * 8}; cycles per block (busy / in barrier) by wave:")
     if nblk:
+        if pp[34]:
+            print("   chain wave of workgroup 0: %d of %d positions took the fast (speculated) transition" % (pp[34], T))
         for w in range(16):
             if pp[8 + w] or pp[24 + w]:
                 extra = ''

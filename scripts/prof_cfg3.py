@@ -42,6 +42,8 @@ for tag in sys.argv[1:]:
     nblk = pp[7]
     if nblk:
         print('   workgroup 0: %d blocks; delayed band-blocks of its waves 1 2 3 5 6: %s' % (nblk, ' '.join('%d' % pp[k] for k in range(2, 7))))
+        if pp[34]:
+            print('   chain wave of workgroup 0: %d positions took the fast (speculated) transition' % pp[34])
         for w in range(8):
             extra = ''
             if os.environ.get('SMM_PROF_LAST'):

@@ -16,14 +16,19 @@ while time.time() - t0 < budget:
     c = int(g.integers(1, CMAX + 1))
     k = int(g.integers(KMIN, KMAX + 1))
     b = int(g.integers(1, 5))
-    kind = ('random', 'structured', 'integer')[int(g.integers(0, 3))]
+    kind = ('random', 'structured', 'integer', 'masked', 'masked_inf')[int(g.integers(0, 5))]
     tmax = int(g.choice([700, 1100, 1600, 2600]))
     lengths = [int(x) for x in g.integers(1, tmax + 1, size=b)]
     lengths[int(g.integers(0, b))] = tmax
     if b > 1 and g.random() < 0.3:
         lengths[(lengths.index(tmax) + 1) % b] = int(g.integers(1, 20))     # a tiny video beside the long ones
     seed = int(g.integers(0, 10 ** 6))
-    if kind == 'structured':
+    if kind.startswith('masked'):
+        # the reference's constrained path: -1e9 (or -inf) masks, -1e4 narration penalties; -inf needs a feasible chain
+        if kind == 'masked_inf':
+            lengths = [max(t, c + 1) for t in lengths]
+        p = tv.masked_problem(seed, lengths, max(c, 2), k, neg_inf=(kind == 'masked_inf'))
+    elif kind == 'structured':
         p = tv.structured_problem(seed, lengths, c, k, margin=float(g.choice([4.0, 18.0])), rate=(min(5, max(1, k // 4)), max(2, min(k - 1, int(g.choice([60, 400, 900]))))))
     else:
         p = tv.make_problem(seed, b, tmax, c, k, integer=(kind == 'integer'))

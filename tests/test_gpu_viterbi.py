@@ -666,6 +666,88 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         np.testing.assert_array_equal(out[key], ring[key])
 
 
+def masked_problem(seed, lengths, c, k, neg_inf=False):
+    """The reference's CONSTRAINED decode (--sm_constrain_transitions, narration constraints) at K > 512: a left-to-right
+    chain with self loops whose forbidden transitions are masked with BIG_NEG = -1e9 BEFORE the softmax
+    (semimarkov_modules.py:298-322), only the first state may start (:284-296), only the last may end (:462-471), and a
+    -1e4 penalty on every step column outside the step's narration window (semimarkov.py:149-157).  Even videos are one
+    pass through the chain (explainable), odd ones cycle through it several times (explainable only through penalties).
+    ``neg_inf``: the masked entries are true -inf instead."""
+    from scipy.special import gammaln
+    g = np.random.default_rng(seed)
+    b, tmax = len(lengths), int(max(lengths))
+    rates = g.uniform(20, 400, size=c)
+    elp = np.zeros((b, tmax, c))
+    for i, t in enumerate(lengths):
+        if i % 2 == 0 and t > c:
+            cuts = np.sort(g.choice(np.arange(1, t), size=c - 1, replace=False))
+            lab = np.repeat(np.arange(c), np.diff(np.concatenate([[0], cuts, [t]])))
+        else:
+            out, cur, tot = [], 0, 0
+            while tot < t:
+                ln = int(np.clip(g.poisson(rates[cur] * 0.3), 1, k - 1))
+                out.append(np.full(ln, cur)); tot += ln; cur = (cur + 1) % c
+            lab = np.concatenate(out)[:t]
+        e = -290.0 - 18.0 + 6.0 * g.standard_normal((t, c))
+        e[np.arange(t), lab] += 18.0
+        for j in range(1, c, 2):                                   # odd states = steps: a narration window each
+            pos = np.flatnonzero(lab == j)
+            lo, hi = (0, t) if len(pos) == 0 else (max(0, pos.min() - int(g.integers(0, 20))), min(t, pos.max() + 1 + int(g.integers(0, 20))))
+            e[:lo, j] += -1e4
+            e[hi:, j] += -1e4
+        elp[i, :t] = e
+    kk = np.arange(k)[:, None]
+    lens = kk * np.log(rates) - rates - gammaln(kk + 1)
+    logits = g.standard_normal((c, c))
+    allowed = np.eye(c, dtype=bool)
+    for f in range(c - 1):
+        allowed[f + 1, f] = True                                   # [to, from]
+    masked = np.where(allowed, logits, -1e9)
+    mx = masked.max(0, keepdims=True)
+    trans = masked - (mx + np.log(np.exp(masked - mx).sum(0, keepdims=True)))
+    il = np.where(np.arange(c) == 0, g.standard_normal(c), -1e9)
+    init = il - (il.max() + np.log(np.exp(il - il.max()).sum()))
+    endpen = np.full((b, c), -1e9)
+    endpen[:, c - 1] = 0.0
+    if neg_inf:
+        trans = np.where(allowed, trans, -np.inf)
+        init = np.where(np.arange(c) == 0, init, -np.inf)
+        endpen = np.where(endpen < -1e8, -np.inf, endpen)
+    return dict(elp=elp, lengths=np.asarray(lengths), trans=trans, init=init, lens=lens, endpen=endpen, c=c, c_max=c, k=k)
+
+
+MASKED_BAND_SHAPES = [
+    ([2300, 1029, 700], 11, 1024), ([3000, 1400], 23, 1024), ([1800, 640, 1500], 28, 1024), ([1200, 1100, 515], 13, 600),
+    ([4100, 900], 21, 1024), ([1500, 1300], 17, 600),
+]
+
+
+@pytest.mark.parametrize('shape', MASKED_BAND_SHAPES)
+@pytest.mark.parametrize('neg_inf', [False, True])
+def test_viterbi_band_mode_masked_lattices(shape, neg_inf, monkeypatch):
+    """BAND mode on the lattices of the reference's constrained path: transitions / initial scores / ends masked at -1e9
+    before the softmax (or at true -inf), -1e4 narration penalties in the emissions.  The band skip test compares bounds
+    built from maxima of h, and h now jumps by 1e4..1e9 between neighbouring sources: bit-exact against the C twin and
+    against the 1024-slot rings (SMM_BAND=0), with the best path's score finite (the chain explains every video, through
+    penalties where it must)."""
+    lengths, c, k = shape
+    monkeypatch.delenv('SMM_PAIRS', raising=False)
+    monkeypatch.delenv('SMM_BAND', raising=False)
+    p = masked_problem(hash((tuple(lengths), c, k)) % 1000 + 11, lengths, c, k, neg_inf=neg_inf)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    assert np.all(np.isfinite(v))
+    if neg_inf:
+        assert np.all(v[::2] > -400.0 * np.asarray(lengths[::2]))   # one pass through the chain: no penalty is paid (~ -290 per frame)
+    check(p, out, spans, v)
+    assert out['_err'][0] == 0
+    monkeypatch.setenv('SMM_BAND', '0')
+    ring = run_gpu(p)
+    assert ring['_err'][3] == 0
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], ring[key])
+
+
 @pytest.mark.parametrize('first', [127, 128, 129, 239, 240, 241, 600, 1023])
 def test_viterbi_band_mode_first_segment_from_position_zero(first, monkeypatch):
     """The first segment of a video starts at position 0, and position 0 belongs to no group of 16 sources of the skip

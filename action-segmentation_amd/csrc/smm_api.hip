@@ -9,12 +9,84 @@
 #include <unordered_map>
 #include <mutex>
 #include <utility>
+#include <string>
 
 #include "../../include/smmdp.h"
 #include "smm_device.h"
 #include "smm_launch.h"
 
 static thread_local int g_last_hip = 0;
+
+// ------------------------------------------------------------------------------------------------ tuning switches
+// Read ONCE, when the library is first used, and again whenever smm_env_reload() is called (tests and A/B scripts that
+// flip a switch inside one process call it; nothing on the per-call path touches the environment).  Release builds know
+// the switches of the first block only; the ones that change RESULTS (profiling stops, half-run splits) exist in
+// -DSMM_DEV builds alone.
+namespace {
+struct SmmEnv {
+    int spec = 1;             // SMM_SPEC=0: Viterbi without the speculative transition (A/B aid; same results)
+    int no_split = 0;         // SMM_NO_SPLIT=1: smm_decode_f32 never splits a launch over two streams (same results)
+    double split_min_us = 100.0, split_ns = 330.0;   // SMM_SPLIT_MIN_US, SMM_SPLIT_NS, SMM_SPLIT_MARGIN: choose_split's model
+    int split_margin = 400;
+    int plan_cache = 1;       // SMM_PLAN_CACHE=0: no resident plans
+    int no_bt_window = 0;     // SMM_NO_BT_WINDOW=1: the general back-trace also for kp <= 64 (same results)
+    int fit_grid = 0;         // SMM_FIT_GRID: workgroups of the class-sums kernel (tuning aid)
+    int verbose = 0;          // SMM_VERBOSE
+#ifdef SMM_DEV
+    int debug_flags = 0;      // SMM_DEBUG_FLAGS: SmmDpArgs::flags bits (bit 0: stop after the forward pass -- outputs UNDEFINED)
+    int split_debug = 0;      // SMM_SPLIT_DEBUG: leave parts of a split decode out (results INCOMPLETE)
+    int upload_memcpy = 0;    // SMM_UPLOAD_MEMCPY: metadata by hipMemcpyAsync instead of kernel arguments
+    int emission_v2 = 0;      // SMM_EMISSION_V2: the LDS-staged emission variant (slower)
+#endif
+    std::string key;          // what the planning functions depend on, for the resident plans' keys
+};
+SmmEnv g_env;
+std::once_flag g_env_once;
+
+void env_read()
+{
+    SmmEnv e;
+    struct Item { const char *name; int *i; double *d; };
+    const Item items[] = {
+        {"SMM_SPEC", &e.spec, nullptr}, {"SMM_NO_SPLIT", &e.no_split, nullptr}, {"SMM_SPLIT_MIN_US", nullptr, &e.split_min_us},
+        {"SMM_SPLIT_NS", nullptr, &e.split_ns}, {"SMM_SPLIT_MARGIN", &e.split_margin, nullptr},
+        {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
+        {"SMM_FIT_GRID", &e.fit_grid, nullptr}, {"SMM_VERBOSE", &e.verbose, nullptr},
+#ifdef SMM_DEV
+        {"SMM_DEBUG_FLAGS", &e.debug_flags, nullptr}, {"SMM_SPLIT_DEBUG", &e.split_debug, nullptr},
+        {"SMM_UPLOAD_MEMCPY", &e.upload_memcpy, nullptr}, {"SMM_EMISSION_V2", &e.emission_v2, nullptr},
+#endif
+    };
+    for (const Item &it : items) {
+        const char *v = std::getenv(it.name);
+        if (!v) continue;
+        if (it.i) *it.i = (*v == 0) ? 1 : std::atoi(v);        // (a switch set to the empty string counts as set)
+        if (it.d) *it.d = std::atof(v);
+        e.key += it.name; e.key += '='; e.key += v; e.key += ';';
+    }
+    g_env = e;
+}
+const SmmEnv &env()
+{
+    std::call_once(g_env_once, env_read);
+    return g_env;
+}
+}  // namespace
+
+extern "C" void smm_env_reload(void)
+{
+    (void)env();
+    env_read();
+}
+int smm_env_fit_grid() { return env().fit_grid; }
+int smm_env_emission_v2()
+{
+#ifdef SMM_DEV
+    return env().emission_v2;
+#else
+    return 0;
+#endif
+}
 
 #define SMM_HIP(call)                                                         \
     do {                                                                      \
@@ -64,7 +136,9 @@ __global__ void __launch_bounds__(512) smm_meta_upload_kernel(SmmMetaChunk c, ui
 
 int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream)
 {
-    if (std::getenv("SMM_UPLOAD_MEMCPY")) return (int)hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream);   // (debug)
+#ifdef SMM_DEV
+    if (env().upload_memcpy) return (int)hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream);
+#endif
     const size_t words = (bytes + 3) / 4;                    // (every destination is padded to 256 B by the planners)
     const unsigned char *src = static_cast<const unsigned char *>(src_host);
     for (size_t off = 0; off < words; off += 512) {
@@ -108,11 +182,9 @@ int smm_zero_async(void *dst_dev, size_t bytes, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------ planning
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-#define SMM_MAX_PAIRS 256
-
 struct SmmPlan {
-    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | emission block table[b+1] | err | gang counters
-    size_t o_order, o_nstates, o_emcum, o_err, o_pflags;
+    size_t meta_bytes;     // SmmVideo[b] | order[b] | n_states[g] | emission block table[b+1] | err
+    size_t o_order, o_nstates, o_emcum, o_err;
     size_t hist_doubles;   // sum over videos of 8*c_max*(T+1): forward cumE/h/gamma, backward cumE/h/gamma, 2 transposes
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
@@ -132,8 +204,7 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
     p.o_emcum = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
     p.o_err = p.o_emcum + align_up(sizeof(int32_t) * ((size_t)s->b + 1), 256);
-    p.o_pflags = p.o_err + 512;     // error word + diagnostic counters, then 4 counters per leader / follower gang
-    p.meta_bytes = p.o_pflags + align_up(sizeof(int32_t) * 4 * (size_t)std::min(s->b, SMM_MAX_PAIRS), 256);
+    p.meta_bytes = p.o_err + 512;   // error word + diagnostic counters
     size_t h = 0;
     for (int i = 0; i < s->b; ++i) h += 8 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
     p.hist_doubles = h;
@@ -168,154 +239,18 @@ struct Staged {
     double *elp;
     double *tabs;
     double *band;          // [g][c_max][k_rows] len_t | [g][c_max][16] band bounds
-    bool band_mode;        // Viterbi: BAND mode (one workgroup per video, exact band skipping) instead of 1024-slot rings / gangs
-    int32_t *pair_flags;
+    bool band_mode;        // Viterbi at K > 512: BAND mode (smm_viterbi.hip)
     int32_t *em_cum;       // emission: workgroups before each video of `order` ([b + 1])
     std::vector<int32_t> em_cum_host;   // (decode split: the same table on the host)
     int em_tpw, em_blocks;
     int kp_max, c_need;
-    int n_pairs;           // Viterbi only: the first n_pairs videos of `order` may run on two CUs each
-    bool pairs_cover_big;  // every video with more than 21 states is among them
     int n_split;           // decode only: the first n_split videos of `order` are the launch's critical path (0: no split)
 };
-
-// Gangs of two or three CUs for the most expensive videos (smm_viterbi.hip, PAIR mode).  The DP kernel's time is the
-// time of its longest videos while other CUs idle; choose_pairs() below picks which videos ride in gangs by simulating a
-// longest-first list schedule with a measured cost model (ns per frame, see there).  frame_ns_single: one CU.
-static double frame_ns_single(int c)
-{
-    int nv[7];
-    for (int r = 0; r < 7; ++r) nv[r] = c > r ? (c - r + 6) / 7 : 0;
-    const int sw = smm_rebalanced_rank(c);                  // (smm_device.h: the kernel's wave <-> rank mapping)
-    if (sw >= 0) std::swap(nv[sw], nv[6]);
-    // SIMDs: ranks (0,4), (1,5), (2,3) and chain wave (+ its partner's mover duty: ~2.5 states) + rank 6
-    const double load = std::max(std::max<double>(std::max(nv[0] + nv[4], nv[1] + nv[5]), nv[2] + nv[3]), 2.5 + nv[6]);
-    return std::max(310.0, 73.0 * load) + 15.0;
-}
-
-// Reorders `order` (most work first on entry) into [gang videos | single videos], both most work first, sets
-// SmmVideo::nfol of the gang videos (1: leader + follower on two CUs, 2: leader + two followers on three) and returns
-// the number of gangs.  Videos with more than 21 states MUST ride in a gang (a single 8-wave workgroup holds 21
-// rings): *big_ok says whether all of them do (else the caller falls back to the 12-wave configuration, without
-// gangs).  Optional gangs: the n most expensive eligible videos, the first n3 of them (above 16 states) as triples;
-// (n, n3) chosen by simulating a list schedule in grid order.  Cost model, ns per frame including the back-trace
-// (measured at K = 1024, T = 4096, 64 videos at a time): one CU: the most loaded SIMD's states x 73, at least 310,
-// + 15; pair: 252 (<= 15 states), 300 (16), 330 (17..23); triple: 235 (round 2: per-video finish times on cfg3 seed 2).
-static int choose_pairs(SmmVideo *hv, int32_t *order, const int32_t *n_states, int b, int kp_max, int c_need, bool *big_ok)
-{
-    *big_ok = false;
-    int forced = -1, forced3 = -1;
-    if (const char *e = std::getenv("SMM_PAIRS")) forced = std::atoi(e);
-    if (const char *e = std::getenv("SMM_TRIPLES")) forced3 = std::atoi(e);
-    // gangs exist for 1024-slot rings, 8 waves; a leader's short rings hold every state (24..32: always a triple, whose
-    // two followers split the long rings, 16 each at most)
-    if (kp_max <= 512 || c_need > 32 || std::getenv("SMM_NW")) return 0;
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return 0;
-    std::vector<int32_t> must, opt, rest;
-    for (int i = 0; i < b; ++i) {
-        const SmmVideo &v = hv[order[i]];
-        const int c = n_states[v.group];
-        if (c > 21) must.push_back(order[i]);
-        else if ((forced > 0 || (v.T >= 1024 && v.kp >= 256 && c >= 4)) && opt.size() == (size_t)(i - (int)must.size()))
-            opt.push_back(order[i]);
-        else rest.push_back(order[i]);                                      // (optional gangs: a prefix of the <= 21-state order)
-    }
-    if ((int)must.size() > SMM_MAX_PAIRS) return 0;
-    if (c_need > 21 && forced == 0) return 0;                               // gangs switched off: 12-wave configuration
-    const int cap = std::max(0, std::min(SMM_MAX_PAIRS, n_cu / 2) - (int)must.size());
-    const int eligible = std::min((int)opt.size(), cap);
-    auto states = [&](int32_t v) { return n_states[hv[v].group]; };
-    auto gang_ns = [&](int32_t v, int nfol) {
-        const int c = states(v);
-        return hv[v].T * (nfol == 2 ? 235.0 : (c > 16 ? 330.0 : (c > 15 ? 300.0 : 252.0)));   // (measured, round 2: profiles/round2_gang_probe.txt)
-    };
-    auto single_ns = [&](int32_t v) { return hv[v].T * frame_ns_single(states(v)); };
-    // the gang list for (n optional gangs, n3 triples): must + opt[0..n), most expensive first; the first n3 of its
-    // videos above 16 states become triples
-    std::vector<int32_t> gangs;
-    std::vector<int> nf;
-    auto build = [&](int n, int n3) {
-        gangs.assign(must.begin(), must.end());
-        gangs.insert(gangs.end(), opt.begin(), opt.begin() + n);
-        std::stable_sort(gangs.begin(), gangs.end(), [&](int32_t x, int32_t y) { return gang_ns(x, 1) > gang_ns(y, 1); });
-        nf.assign(gangs.size(), 1);
-        for (size_t i = 0; i < gangs.size(); ++i)
-            if (states(gangs[i]) > 23) nf[i] = 2;                             // (one follower holds 16 long rings)
-        for (size_t i = 0; i < gangs.size() && n3 > 0; ++i)
-            if (states(gangs[i]) > 16 && nf[i] == 1) { nf[i] = 2; --n3; }
-    };
-    std::vector<double> cu(n_cu);
-    auto simulate = [&](int n) {                                             // list schedule in grid order
-        std::fill(cu.begin(), cu.end(), 0.0);
-        std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-        for (size_t i = 0; i < gangs.size(); ++i) {                           // the 2 or 3 earliest-free CUs
-            const int m = 1 + nf[i];
-            double t0 = 0.0;
-            for (int q = 0; q < m; ++q) {
-                std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-                t0 = std::max(t0, cu.back());
-                cu.pop_back();
-            }
-            for (int q = 0; q < m; ++q) {
-                cu.push_back(t0 + gang_ns(gangs[i], nf[i]));
-                std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-            }
-        }
-        auto run_single = [&](int32_t v) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            cu.back() += single_ns(v);
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-        };
-        for (size_t i = n; i < opt.size(); ++i) run_single(opt[i]);
-        for (int32_t v : rest) run_single(v);
-        return *std::max_element(cu.begin(), cu.end());
-    };
-    int best_n = 0, best_n3 = 0;
-    if (forced >= 0) {
-        best_n = std::min(std::min(forced, (int)opt.size()), SMM_MAX_PAIRS - (int)must.size());
-        best_n3 = forced3 >= 0 ? forced3 : 0;
-    } else {
-        double best_t = 1e300;
-        // (host time is on the caller's critical path: a handful of candidates, ~b heap operations each)
-        static const int n3s[] = {0, 1, 2, 4, 8, 16, 32, 64};
-        for (int n = 0; n <= eligible; n += (eligible <= 8 ? 1 : (n < 32 ? 8 : (n < 64 ? 16 : 32)))) {
-            for (int n3 : n3s) {
-                // triples only when every workgroup of the launch fits the GPU at once (a latency-bound launch: few
-                // videos, CUs to spare); on a full GPU their third CU costs the one-CU videos more than it gains
-                // (measured on cfg3: 32 pairs 5.0 ms, 32 triples 5.4 ms)
-                if (n3 > n + (int)must.size() || (n3 > 0 && b + n + (int)must.size() + n3 > n_cu)) continue;
-                build(n, n3);
-                const double t = simulate(n);
-                if (std::getenv("SMM_VERBOSE"))
-                    std::fprintf(stderr, "libsmmdp:   %d optional gangs, %d triples -> %.3f ms predicted\n", n, n3, t * 1e-6);
-                if (t < best_t * 0.98) { best_t = t; best_n = n; best_n3 = n3; }   // more gangs only for a clear gain
-            }
-        }
-    }
-    build(best_n, best_n3);
-    if (std::getenv("SMM_VERBOSE"))
-        std::fprintf(stderr, "libsmmdp: %d videos, %zu with > 21 states (always in a gang), %d optional gangs of %d eligible, %d triples, %d CUs\n",
-                     b, must.size(), best_n, eligible, best_n3, n_cu);
-    // new order: gangs (most expensive first), then the singles in their old relative order
-    std::vector<int32_t> singles;
-    {
-        std::vector<char> in_gang(b, 0);
-        for (size_t i = 0; i < gangs.size(); ++i) { in_gang[gangs[i]] = 1; hv[gangs[i]].nfol = nf[i]; }
-        for (int i = 0; i < b; ++i)
-            if (!in_gang[order[i]]) singles.push_back(order[i]);
-    }
-    std::copy(gangs.begin(), gangs.end(), order);
-    std::copy(singles.begin(), singles.end(), order + gangs.size());
-    *big_ok = true;
-    return (int)gangs.size();
-}
 
 static bool band_mode(int kp_max, int c_need);
 
 // Validates the metadata, builds SmmVideo[] (+ longest-first block order) and stages it into the workspace.
-// want_gangs: plan gangs for the Viterbi kernel (a list-schedule simulation, ~0.3 ms of host time at 360 videos: only
+// for_viterbi: the call launches the Viterbi kernel (part of a resident plan's key; rounds 1-3 planned gangs here: only
 // the entry points that launch that kernel ask for it)
 // Split of a decode (smm_decode_f32) into [critical videos | the rest].  The DP kernel's time is the time of the launch's
 // longest videos (one workgroup each, ~0.3 us per frame), while the emission scorer in front of it streams EVERY video's
@@ -324,19 +259,25 @@ static bool band_mode(int kp_max, int c_need);
 // is, i.e. its longest video has to be shorter than the launch's longest by the time the emission scorer takes.
 // Returns how many videos of `order` (reordered: critical ones first, both parts keep their order) form the first part;
 // 0: no split (few videos, a flat length distribution, or nothing to hide).
+static int device_cus()
+{
+    static std::mutex mu;
+    static int n_cu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!n_cu[dev] && hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu[dev] = 0;
+    return n_cu[dev] > 0 ? n_cu[dev] : 0;
+}
+
 static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_max, int64_t total_frames)
 {
-    if (b < 24 || std::getenv("SMM_NO_SPLIT")) return 0;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            n_cu = 0;
-        if (n_cu <= 0) { n_cu = 0; return 0; }
-    }
+    const SmmEnv &ev = env();
+    if (b < 24 || ev.no_split) return 0;
+    const int n_cu = device_cus();
+    if (n_cu <= 0) return 0;
     const double em_us = (double)total_frames * (4.0 * d + 8.0 * c_max) / 4.0e6;      // ~4 TB/s of algorithmic bytes
-    const char *mn = std::getenv("SMM_SPLIT_MIN_US");                                  // (test hook: split small launches too)
-    if (em_us < (mn ? std::atof(mn) : 100.0)) return 0;
+    if (em_us < ev.split_min_us) return 0;                                             // (SMM_SPLIT_MIN_US: test hook, split small launches too)
     int tmax = 0;
     for (int i = 0; i < b; ++i) tmax = std::max(tmax, hv[i].T);
     // a video of the second part starts em_us later than the critical ones and must not outlast them: the critical set is
@@ -344,9 +285,7 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
     // BAND kernel of round 3, ~250 ns per frame beside a full GPU): 230 / 250 ns 3.72-3.74 ms per step, 300 3.58-3.62,
     // 400 3.59-3.62, 600 3.65-3.71, 1000+ 3.68-3.70 -- the em_us estimate below (4 TB/s) is already on the long side.
     // SMM_SPLIT_NS / SMM_SPLIT_MARGIN: tuning aids
-    static const double split_ns = [] { const char *e = std::getenv("SMM_SPLIT_NS"); return e ? std::atof(e) : 330.0; }();
-    static const int split_margin = [] { const char *e = std::getenv("SMM_SPLIT_MARGIN"); return e ? std::atoi(e) : 400; }();
-    const int thr = tmax - (int)(em_us * 1000.0 / split_ns) - split_margin;
+    const int thr = tmax - (int)(em_us * 1000.0 / ev.split_ns) - ev.split_margin;
     int n1 = 0;
     for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
     if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16) return 0;
@@ -361,9 +300,13 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
 // the immutable part of the metadata (videos | order | n_states | emission block table) lives in a device buffer the
 // LIBRARY owns -- nobody else can write to it, so a later call with bit-identical inputs (compared in full, not by hash)
 // and the same planning environment points its kernels at that buffer and skips planning and upload.  The mutable
-// part (error words, gang counters) stays in the caller's workspace and is cleared per call as before.  Plans are never
-// freed (a captured graph may still point at one); past 64 MB of them, or with SMM_PLAN_CACHE=0, or when the first call
-// with some inputs happens under stream capture (no allocation there), a call is staged the old way, into its workspace.
+// part (the error words) stays in the caller's workspace and is cleared per call as before.
+// Lifetime: a plan is ADMITTED the second time its inputs are seen (a training loop that packs shuffled batches shows a new
+// key every step: those are staged the old way and leave nothing behind); plans live in slabs of the device they were
+// made on, 64 MB at most per process, and stay until smm_release_cached_plans() frees them (the caller's promise: no
+// call in flight and no captured graph that was captured from one of these calls still to be replayed).  With
+// SMM_PLAN_CACHE=0, past the cap, or when a call with new inputs happens under stream capture (no allocation, no event
+// query there), a call is staged into its workspace as before.
 namespace {
 struct PlanEntry {
     std::vector<char> key;
@@ -375,12 +318,17 @@ struct PlanEntry {
     hipStream_t stream = nullptr;
     bool settled = false;
 };
+struct PlanSlabs {                                                      // per device: metadata buffers are cut from 1 MB slabs
+    char *cur = nullptr;
+    size_t left = 0;
+    std::vector<char *> all;
+};
 struct PlanCache {
     std::mutex mu;
     std::unordered_map<uint64_t, std::vector<PlanEntry *>> entries;     // by FNV-1a of the key; compared in full on a hit
+    std::unordered_map<uint64_t, uint32_t> seen_once;                   // keys seen once (hash only): admitted at the second sighting
     size_t n = 0, bytes = 0, key_bytes = 0;                            // plans, device bytes, host bytes of their keys
-    char *slab = nullptr;                                               // metadata buffers are cut from 1 MB device slabs
-    size_t slab_left = 0;
+    PlanSlabs slabs[64];
 } g_plans;
 constexpr size_t SMM_PLAN_MAX_BYTES = (size_t)64 << 20, SMM_PLAN_MAX_ENTRIES = 8192, SMM_PLAN_SLAB = (size_t)1 << 20;
 
@@ -391,20 +339,23 @@ uint64_t plan_hash(const std::vector<char> &k)
     return h;
 }
 
-// (called with the cache locked)
-char *plan_alloc(size_t bytes)
+// (called with the cache locked; `dev` is the current device: a plan's buffer lives on the device its kernels run on)
+char *plan_alloc(size_t bytes, int dev)
 {
+    if (dev < 0 || dev >= 64) return nullptr;
+    PlanSlabs &sl = g_plans.slabs[dev];
     bytes = align_up(bytes, 256);
-    if (bytes > g_plans.slab_left) {
+    if (bytes > sl.left) {
         const size_t want = std::max(bytes, SMM_PLAN_SLAB);
         char *p = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&p), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        g_plans.slab = p;                  // (the rest of the previous slab is given up: plans are never freed)
-        g_plans.slab_left = want;
+        sl.all.push_back(p);               // (the rest of the previous slab is given up)
+        sl.cur = p;
+        sl.left = want;
     }
-    char *r = g_plans.slab;
-    g_plans.slab += bytes;
-    g_plans.slab_left -= bytes;
+    char *r = sl.cur;
+    sl.cur += bytes;
+    sl.left -= bytes;
     return r;
 }
 
@@ -415,7 +366,7 @@ void plan_key_append(std::vector<char> &k, const void *p, size_t n)
 }
 
 std::vector<char> plan_key(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
-                           const int32_t *kp, const int32_t *n_states, bool want_gangs, int cum_chunk, bool want_split)
+                           const int32_t *kp, const int32_t *n_states, bool for_viterbi, int cum_chunk, bool want_split)
 {
     std::vector<char> k;
     k.reserve(sizeof(*s) + (size_t)s->b * 24 + (size_t)s->n_groups * 4 + 128);
@@ -427,15 +378,11 @@ std::vector<char> plan_key(const smm_shape *s, const int64_t *lengths, const int
     if (group) plan_key_append(k, group, sizeof(int32_t) * s->b);
     if (kp) plan_key_append(k, kp, sizeof(int32_t) * s->b);
     plan_key_append(k, n_states, sizeof(int32_t) * s->n_groups);
-    const int32_t f[3] = {want_gangs, cum_chunk, want_split};
+    const int32_t f[3] = {for_viterbi, cum_chunk, want_split};
     plan_key_append(k, f, sizeof(f));
-    // the environment the planning functions read (tests and A/B runs flip these between calls)
-    for (const char *name : {"SMM_BAND", "SMM_PAIRS", "SMM_TRIPLES", "SMM_NW", "SMM_NO_SPLIT", "SMM_SPLIT_MIN_US"}) {
-        const char *e = std::getenv(name);
-        const char sep = e ? 1 : 0;
-        plan_key_append(k, &sep, 1);
-        if (e) plan_key_append(k, e, std::strlen(e) + 1);
-    }
+    // the switches the planning functions read (smm_env_reload() may change them between calls)
+    const std::string &ek = env().key;
+    plan_key_append(k, ek.data(), ek.size() + 1);
     return k;
 }
 
@@ -443,7 +390,6 @@ void plan_point(const SmmPlan &p, void *ws, Staged *out)
 {
     char *base = static_cast<char *>(ws);
     out->err = reinterpret_cast<int32_t *>(base + p.o_err);
-    out->pair_flags = reinterpret_cast<int32_t *>(base + p.o_pflags);
     out->hist = reinterpret_cast<double *>(base + p.meta_bytes);
     out->elp = out->hist + p.hist_doubles;
     out->tabs = out->elp + p.elp_doubles;
@@ -453,21 +399,20 @@ void plan_point(const SmmPlan &p, void *ws, Staged *out)
 
 static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                           const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                          bool want_gangs, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out);
+                          bool for_viterbi, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out);
 
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                  const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                 bool want_gangs = false, int cum_chunk = 0, bool want_split = false)
+                 bool for_viterbi = false, int cum_chunk = 0, bool want_split = false)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
-    static const bool enabled = [] { const char *e = std::getenv("SMM_PLAN_CACHE"); return !(e && std::atoi(e) == 0); }();
-    if (!enabled) return stage_uncached(s, lengths, frame_off, group, kp, n_states, ws, ws_bytes, stream, out, want_gangs, cum_chunk, want_split, nullptr, nullptr);
+    if (!env().plan_cache) return stage_uncached(s, lengths, frame_off, group, kp, n_states, ws, ws_bytes, stream, out, for_viterbi, cum_chunk, want_split, nullptr, nullptr);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     const bool capturing = cap != hipStreamCaptureStatusNone;
-    const std::vector<char> key = plan_key(s, lengths, frame_off, group, kp, n_states, want_gangs, cum_chunk, want_split);
+    const std::vector<char> key = plan_key(s, lengths, frame_off, group, kp, n_states, for_viterbi, cum_chunk, want_split);
     const uint64_t hk = plan_hash(key) ^ (uint64_t)dev;
     PlanEntry *hit = nullptr;
     {
@@ -477,11 +422,12 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
             for (PlanEntry *e : it->second)
                 if (e->device == dev && e->key.size() == key.size() && std::memcmp(e->key.data(), key.data(), key.size()) == 0) { hit = e; break; }
         if (hit && !hit->settled) {
-            // the upload was queued on another stream, maybe: usable once it is known to be through (or on that very stream)
-            if (hipEventQuery(hit->ready) == hipSuccess) hit->settled = true;
-            else if (hit->stream != stream) {
-                if (capturing || hipStreamWaitEvent(stream, hit->ready, 0) != hipSuccess) hit = nullptr;
-            }
+            // the upload was queued on another stream, maybe: usable once it is known to be through (or on that very
+            // stream).  Under capture nothing is queried or waited for (an event query can invalidate a global-mode capture):
+            // an unsettled plan is then simply not used.
+            if (capturing) { if (hit->stream != stream) hit = nullptr; }
+            else if (hipEventQuery(hit->ready) == hipSuccess) hit->settled = true;
+            else if (hit->stream != stream && hipStreamWaitEvent(stream, hit->ready, 0) != hipSuccess) hit = nullptr;
         }
     }
     if (hit) {
@@ -498,16 +444,23 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     bool keep = !capturing;
     if (keep) {
         std::lock_guard<std::mutex> lock(g_plans.mu);
-        keep = g_plans.bytes + p0.o_err <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES &&
+        // admitted at the second sighting: one-off batches (shuffled training steps) never take a slot
+        auto seen = g_plans.seen_once.find(hk);
+        if (seen == g_plans.seen_once.end()) {
+            if (g_plans.seen_once.size() >= 4 * SMM_PLAN_MAX_ENTRIES) g_plans.seen_once.clear();
+            g_plans.seen_once.emplace(hk, 1u);
+            keep = false;
+        }
+        keep = keep && g_plans.bytes + p0.o_err <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES &&
                g_plans.key_bytes + key.size() <= SMM_PLAN_MAX_BYTES;
         if (keep) {
-            dev_meta = plan_alloc(p0.o_err);
+            dev_meta = plan_alloc(p0.o_err, dev);
             keep = dev_meta != nullptr;
             if (keep) g_plans.bytes += align_up(p0.o_err, 256);
         }
     }
     SmmPlan plan{};
-    const int rc = stage_uncached(s, lengths, frame_off, group, kp, n_states, ws, ws_bytes, stream, out, want_gangs, cum_chunk, want_split,
+    const int rc = stage_uncached(s, lengths, frame_off, group, kp, n_states, ws, ws_bytes, stream, out, for_viterbi, cum_chunk, want_split,
                                   keep ? dev_meta : nullptr, &plan);
     if (rc != SMM_OK || !keep) return rc;          // (a buffer cut for a call that failed stays cut: 64 MB bound the total)
     PlanEntry *e = new PlanEntry;
@@ -525,14 +478,53 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     }
     std::lock_guard<std::mutex> lock(g_plans.mu);
     g_plans.entries[hk].push_back(e);
+    g_plans.seen_once.erase(hk);
     g_plans.n += 1;
     g_plans.key_bytes += key.size();
     return SMM_OK;
 }
 
+// Frees every resident plan and its device memory (all devices), the decode's second streams and the pooled events.
+// The caller's promise: no libsmmdp call is in flight on any stream, and no hipGraph captured from one of these calls will
+// be replayed again (a captured call points at its plan's buffer).  Returns the device bytes given back.
+static void release_aux();
+extern "C" size_t smm_release_cached_plans(void)
+{
+    release_aux();
+    std::lock_guard<std::mutex> lock(g_plans.mu);
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    size_t freed = 0;
+    for (auto &kv : g_plans.entries)
+        for (PlanEntry *e : kv.second) {
+            if (e->ready) (void)hipEventDestroy(e->ready);
+            delete e;
+        }
+    g_plans.entries.clear();
+    g_plans.seen_once.clear();
+    for (int d = 0; d < 64; ++d) {
+        PlanSlabs &sl = g_plans.slabs[d];
+        if (sl.all.empty()) continue;
+        (void)hipSetDevice(d);
+        for (char *p : sl.all) if (hipFree(p) == hipSuccess) freed += SMM_PLAN_SLAB;
+        sl = PlanSlabs{};
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    g_plans.n = g_plans.bytes = g_plans.key_bytes = 0;
+    return freed;
+}
+
+extern "C" size_t smm_cached_plan_bytes(void)
+{
+    std::lock_guard<std::mutex> lock(g_plans.mu);
+    size_t n = 0;
+    for (int d = 0; d < 64; ++d) n += g_plans.slabs[d].all.size() * SMM_PLAN_SLAB;
+    return n;
+}
+
 static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                           const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                          bool want_gangs, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out)
+                          bool for_viterbi, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
     if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
@@ -566,7 +558,7 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
         hv[i].T = (int32_t)t;                      // (no EOS: the DP kernels take T - 1, the emission kernel every frame)
         hv[i].group = g;
         hv[i].kp = k;
-        hv[i].nfol = 0;
+        hv[i].pad = 0;
         hoff += 8 * (size_t)s->c_max * (size_t)(t + 1);
         kp_max = std::max(kp_max, k);
     }
@@ -578,11 +570,8 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     // (chunk table for the emission chain rule: by group, so that a workgroup's run of chunks rarely changes group)
     if (cum_chunk > 0) std::stable_sort(ho, ho + s->b, [&](int a, int b) { return hv[a].group < hv[b].group; });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
-    out->n_pairs = 0;
-    out->pairs_cover_big = false;
-    out->band_mode = want_gangs && band_mode(kp_max, c_need);
-    if (want_gangs && !out->band_mode) out->n_pairs = choose_pairs(hv, ho, n_states, s->b, kp_max, c_need, &out->pairs_cover_big);
-    out->n_split = (want_split && out->n_pairs == 0) ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
+    out->band_mode = band_mode(kp_max, c_need);
+    out->n_split = want_split ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
     {
         // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
         int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
@@ -601,8 +590,8 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
 
     char *base = static_cast<char *>(ws);
     // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream) -- into
-    // the workspace, or into the resident plan's own buffer (meta_dst); the error word and the gang counters behind them
-    // (always in the workspace) start at zero
+    // the workspace, or into the resident plan's own buffer (meta_dst); the error words behind them (always in the
+    // workspace) start at zero
     char *meta = meta_dst ? meta_dst : base;
     SMM_HIP((hipError_t)smm_upload_meta(meta, host.data(), p.o_err, stream));
     SMM_HIP((hipError_t)smm_zero_async(base + p.o_err, p.meta_bytes - p.o_err, stream));
@@ -617,14 +606,11 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     return SMM_OK;
 }
 
-// Viterbi at K > 512: BAND mode (smm_viterbi.hip) for up to 28 states; SMM_BAND=0 brings the 1024-slot rings and the gangs
-// back (A/B measurements, and the shapes above 28 states)
+// Viterbi at K > 512: BAND mode (smm_viterbi.hip), up to SMM_MAX_STATES states on one CU
 static bool band_mode(int kp_max, int c_need)
 {
-    if (kp_max <= 512 || c_need > 28 || std::getenv("SMM_NW")) return false;
-    if (std::getenv("SMM_PAIRS") || std::getenv("SMM_TRIPLES")) return false;     // an explicit gang configuration is asked for
-    const char *e = std::getenv("SMM_BAND");
-    return !(e && std::atoi(e) == 0);
+    (void)c_need;
+    return kp_max > 512;
 }
 
 static int ring_regs(int kp_max)
@@ -658,6 +644,8 @@ struct DpTiming {
     std::mutex mu;
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> rec, pool;
+    std::vector<int> tag;          // per record: 0 the only DP launch of its call, 1 the critical videos of a split decode
+                                   // (caller's stream), 2 the rest of a split decode (second stream)
 } g_dp_timing;
 
 bool dp_timing_begin(hipStream_t stream, std::pair<hipEvent_t, hipEvent_t> &ev)
@@ -669,11 +657,12 @@ bool dp_timing_begin(hipStream_t stream, std::pair<hipEvent_t, hipEvent_t> &ev)
     return hipEventRecord(ev.first, stream) == hipSuccess;
 }
 
-void dp_timing_end(hipStream_t stream, const std::pair<hipEvent_t, hipEvent_t> &ev)
+void dp_timing_end(hipStream_t stream, const std::pair<hipEvent_t, hipEvent_t> &ev, int tag)
 {
     (void)hipEventRecord(ev.second, stream);
     std::lock_guard<std::mutex> lock(g_dp_timing.mu);
     g_dp_timing.rec.push_back(ev);
+    g_dp_timing.tag.push_back(tag);
 }
 }  // namespace
 
@@ -683,18 +672,22 @@ extern "C" void smm_dp_timing_enable(int on)
     g_dp_timing.on = on != 0;
 }
 
-extern "C" int smm_dp_timing_read(float *ms, int cap)
+extern "C" int smm_dp_timing_read_tagged(float *ms, int32_t *tags, int cap)
 {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> rec;
+    std::vector<int> tag;
     {
         std::lock_guard<std::mutex> lock(g_dp_timing.mu);
         rec.swap(g_dp_timing.rec);
+        tag.swap(g_dp_timing.tag);
     }
     int n = 0;
     for (auto &ev : rec) {
         float t = 0.f;
-        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess && ms && n < cap)
-            ms[n] = t;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess && n < cap) {
+            if (ms) ms[n] = t;
+            if (tags) tags[n] = tag[n];
+        }
         ++n;
     }
     std::lock_guard<std::mutex> lock(g_dp_timing.mu);
@@ -702,10 +695,12 @@ extern "C" int smm_dp_timing_read(float *ms, int cap)
     return n;
 }
 
+extern "C" int smm_dp_timing_read(float *ms, int cap) { return smm_dp_timing_read_tagged(ms, nullptr, cap); }
+
 static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, const double *trans, const double *init,
                        const double *len_scores, const double *endpen, const int64_t *class_map, int64_t *spans,
                        int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream, int first = 0, int count = -1,
-                       bool prep = true, bool launch = true)
+                       bool prep = true, bool launch = true, int timing_tag = 0)
 {
     if (!elp || !trans || !init || !len_scores) return SMM_ERR_ARG;
     SmmDpArgs a{};
@@ -715,15 +710,12 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
     a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
     if (count >= 0) { a.order = st.order + first; a.b = count; }
-    {
-        const char *dbg = std::getenv("SMM_DEBUG_FLAGS");   // profiling / test aid, see SmmDpArgs::flags
-        a.flags = dbg ? std::atoi(dbg) : 0;
-    }
+    a.flags = 0;
+#ifdef SMM_DEV
+    a.flags = env().debug_flags;                              // (SmmDpArgs::flags bit 0: profiling, outputs undefined)
+#endif
     if (no_eos) a.flags |= 8;
-    if (const char *e = std::getenv("SMM_SPEC")) { if (std::atoi(e) == 0) a.flags |= 256; }   // A/B aid: no speculative transition
-    a.n_pairs = st.n_pairs;
-    a.pair_flags = st.pair_flags;
-    if (st.pairs_cover_big) a.flags |= 4;
+    if (!env().spec) a.flags |= 256;                          // A/B aid: no speculative transition
     if (st.band_mode) {
         double *len_t = st.band, *band_tab = st.band + (size_t)s->n_groups * s->c_max * SMM_BAND_ROW;
         if (prep) smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, s->n_groups, s->c_max, s->k_rows, stream);
@@ -731,7 +723,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         a.band_tab = band_tab;
         a.flags |= 128;
     }
-    if (ring_regs(st.kp_max) == 1 && !std::getenv("SMM_NO_BT_WINDOW")) {
+    if (ring_regs(st.kp_max) == 1 && !env().no_bt_window) {
         // short segments: window back-trace (smm_viterbi.hip); W >= 2 kp keeps a window good for many segments
         // about 48 KB of window (three workgroups per CU stay possible), at least 2 kp positions, at most 512
         int w = (int)(48 * 1024 / (24 * (size_t)st.c_need)) & ~7;
@@ -743,12 +735,8 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     std::pair<hipEvent_t, hipEvent_t> tev;
     const bool timed = dp_timing_begin(stream, tev);
     const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
-    if (timed) dp_timing_end(stream, tev);
+    if (timed) dp_timing_end(stream, tev, timing_tag);
     if (rc != SMM_OK) return rc;
-    // Gangs depend on their workgroups being resident together, which HIP does not promise (another stream or tenant
-    // may hold the CUs): a gang that gives up flags itself and its video is decoded again here, on one CU, behind the
-    // main kernel on the same stream.  Without a time-out these launches cost two empty grids.
-    if (st.n_pairs > 0 && !(a.flags & 1)) smm_launch_viterbi_recovery(a, st.c_need, stream);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }
@@ -827,23 +815,63 @@ extern "C" int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_ho
 }
 
 // The second stream of a split decode: one per device, created on first use with the lowest priority (the critical videos'
-// DP on the caller's stream goes first), never destroyed.  It is the one piece of state the library keeps; every use is
-// bracketed by events on the caller's stream, so from the caller's point of view the call is still ordered on ITS stream
-// (and captures into a hipGraph like before: the event wait pulls the second stream into the capture).
-#include <mutex>
-static hipStream_t aux_stream()
+// DP on the caller's stream goes first); it lives until smm_release_cached_plans().  Every use is bracketed by a pooled
+// event pair on the caller's stream, so from the caller's point of view the call is still ordered on ITS stream.  A call
+// made under stream capture does NOT split (the one shared second stream would be pulled into the capture and a
+// concurrent call from another thread would then enqueue onto a capturing stream): it runs as one launch pair.
+namespace {
+struct AuxDev {                       // per device: the second stream of a split decode and the event pair that brackets it
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;     // idle (fork, join) pairs
+};
+std::mutex g_aux_mu;
+AuxDev g_aux[64];
+
+hipStream_t aux_stream(int dev)
 {
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!streams[dev]) {
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    AuxDev &d = g_aux[dev];
+    if (!d.stream) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least) != hipSuccess) streams[dev] = nullptr;
+        if (hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, least) != hipSuccess) d.stream = nullptr;
     }
-    return streams[dev];
+    return d.stream;
+}
+
+bool aux_events_get(int dev, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_aux_mu);
+        AuxDev &d = g_aux[dev];
+        if (!d.events.empty()) { ev = d.events.back(); d.events.pop_back(); return true; }
+    }
+    ev = {nullptr, nullptr};
+    if (hipEventCreateWithFlags(&ev.first, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&ev.second, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ev.first); return false; }
+    return true;
+}
+
+void aux_events_put(int dev, const std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    // (an event that is re-recorded while an earlier wait on it is still queued keeps that wait's meaning: a wait
+    // captures the record it follows)
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    g_aux[dev].events.push_back(ev);
+}
+}  // namespace
+
+static void release_aux()
+{
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    for (int d = 0; d < 64; ++d) {
+        for (auto &ev : g_aux[d].events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        g_aux[d].events.clear();
+        if (g_aux[d].stream) { (void)hipStreamDestroy(g_aux[d].stream); g_aux[d].stream = nullptr; }
+    }
+    std::lock_guard<std::mutex> lock2(g_dp_timing.mu);
+    for (auto &ev : g_dp_timing.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    g_dp_timing.pool.clear();
 }
 
 extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_host, const int64_t *frame_offset_host,
@@ -858,7 +886,14 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     int rc = stage(shape, lengths_host, frame_offset_host, group_host, kp_host, n_states_host, workspace, workspace_bytes,
                    hs, &st, true, 0, true);
     if (rc != SMM_OK) return rc;
-    hipStream_t aux = st.n_split > 0 ? aux_stream() : nullptr;
+    int dev = 0;
+    hipStream_t aux = nullptr;
+    if (st.n_split > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(hs, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) aux = aux_stream(dev);
+    }
+    std::pair<hipEvent_t, hipEvent_t> fj{nullptr, nullptr};
+    if (aux && !aux_events_get(dev, fj)) aux = nullptr;
     if (!aux) {
         rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs);
         if (rc != SMM_OK) return rc;
@@ -871,20 +906,21 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     if (rc != SMM_OK) return rc;
     rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs, 0, n1);
     if (rc != SMM_OK) return rc;
-    hipEvent_t fork = nullptr, join = nullptr;
-    SMM_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    SMM_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    const hipEvent_t fork = fj.first, join = fj.second;
     int rc2 = SMM_OK;
     if (hipEventRecord(fork, hs) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) rc2 = SMM_ERR_HIP;
-    static const int dbg_split = [] { const char *e = std::getenv("SMM_SPLIT_DEBUG"); return e ? std::atoi(e) : 0; }();   // (timing experiments: results INCOMPLETE)
+#ifdef SMM_DEV
+    const int dbg_split = env().split_debug;                  // (timing experiments: results INCOMPLETE)
+#else
+    const int dbg_split = 0;
+#endif
     if (rc2 == SMM_OK && !(dbg_split & 2)) rc2 = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, aux, n1, n2);
     if (rc2 == SMM_OK && !(dbg_split & 1))
-        rc2 = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, aux, n1, n2, false);
-    rc = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs, 0, n1, false);
+        rc2 = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, aux, n1, n2, false, true, 2);
+    rc = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs, 0, n1, false, true, 1);
     // the join is made even after an error on the way, so that the caller's stream never runs ahead of the second one
     if (hipEventRecord(join, aux) != hipSuccess || hipStreamWaitEvent(hs, join, 0) != hipSuccess) rc2 = SMM_ERR_HIP;
-    (void)hipEventDestroy(fork);
-    (void)hipEventDestroy(join);
+    aux_events_put(dev, fj);
     return rc != SMM_OK ? rc : rc2;
 }
 

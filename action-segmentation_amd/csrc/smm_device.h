@@ -20,7 +20,7 @@ struct SmmVideo {
     int32_t T;           // frames
     int32_t group;       // parameter group
     int32_t kp;          // usable segment lengths are 1..kp-1   (min(K, Tmax of the reference batch))
-    int32_t nfol;        // Viterbi gangs (smm_viterbi.hip, PAIR mode): follower workgroups of this video, 1 or 2 (0: none)
+    int32_t pad;         // (rounds 1-3: follower workgroups of a Viterbi gang)
 };
 
 struct SmmDpArgs {
@@ -33,24 +33,20 @@ struct SmmDpArgs {
     const double *len;         // [g][k_rows][c_max]
     const double *endpen;      // [b][c_max] or null
     const int64_t *class_map;  // [g][c_max+1] or null
-    double *hist;              // per video (Viterbi): cum[T+1][C], h[C][T+1], gamma[T+1][C], gangs: A'_long[T+1][c_max]; C = the video's states
+    double *hist;              // per video (Viterbi): cum[T+1][C], h[C][T+1], gamma[T+1][C]; C = the video's states
     int64_t *spans;            // [b][t_max+1] or null
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
-    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] gangs that timed out, [2] gangs repaired;
+    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1], [2] always 0 (rounds 1-3: gang time-outs / repairs);
                                // [3] Viterbi BAND mode, diagnostic: delayed band-blocks (the sources of one hand-over block, 8 or under SMM_BAND_B=4 4, x one band of one state) evaluated
     int32_t c_max, k_rows, t_max, b;
-    int32_t flags;             // bit 0: profiling only -- stop after the forward pass (outputs undefined); bit 1: logZ
-                               // backward; bit 2: every video with more than 21 states is in the paired prefix;
-                               // bit 3 (8): no EOS (add_eos=False; SmmVideo::T = frames - 1); bit 4 (16): recovery launch
-                               // behind a gang launch; bit 5 (32): test hook -- gang 0's followers never show up;
+    int32_t flags;             // bit 0: profiling only, -DSMM_DEV builds -- stop after the forward pass (outputs undefined);
+                               // bit 1: logZ backward; bit 3 (8): no EOS (add_eos=False; SmmVideo::T = frames - 1);
                                // bit 6 (64): logZ forward and time-reversed runs in one launch (2 workgroups per video);
                                // bit 7 (128): Viterbi BAND mode; bit 8 (256): Viterbi without the speculative transition (A/B aid)
-    int32_t n_pairs;           // the first n_pairs entries of order[] run as leader / follower pairs (smm_viterbi.hip)
     const double *trans_t;     // logZ, both directions in one launch (flags bit 6): transposed tables [g][c_max][c_max]
     double *logz_b;            // ... and where the reversed runs put their closing value [b]
-    int32_t *pair_flags;       // [4 * n_pairs] per gang: h rows / A' rows (follower 0, 1) published, failure word; zero at launch
     const double *len_t;       // Viterbi BAND mode (flags bit 7, 128): [g][c_max][k_rows] state-major length table ...
     const double *band_tab;    // ... and [g][c_max][16] bounds of the band skip test (smm_viterbi.hip: smm_band_tables_kernel)
     int32_t bt_window;         // Viterbi, kp <= 64: positions per LDS window of the back-trace (0: the general back-trace) ...

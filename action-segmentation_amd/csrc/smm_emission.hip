@@ -497,7 +497,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
     // v2 is opt-in (SMM_EMISSION_V2=1): measured on cfg3 (rocprofv3, profiles/round2_emission_v1_v2.txt) it takes 0.77 ms
     // against v1's 0.62 ms -- its LDS footprint (weights + 8 tile buffers = 157 KB) leaves ONE 8-wave workgroup per CU
     // where v1 runs two, and the kernel turned out not to be bound by the 64-byte row pieces of v1's loads.
-    const bool v2 = vec && nld <= 20 && lds_w2 + lds_x <= 160 * 1024 && std::getenv("SMM_EMISSION_V2");
+    const bool v2 = vec && nld <= 20 && lds_w2 + lds_x <= 160 * 1024 && smm_env_emission_v2();
     const int nsel = nld <= 4 ? 0 : (nld <= 8 ? 1 : (nld <= 13 ? 2 : 3));     // compiled load counts: 4, 8, 13, 20
     auto go1 = [&](auto kern) {
         if (lds_w > 48 * 1024)

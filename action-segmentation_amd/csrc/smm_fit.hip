@@ -304,7 +304,7 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
     // class sums: a persistent grid of 3 workgroups per CU (what the kernel's 167 VGPRs admit: one resident round, and
     // few flushes of the one sum-of-squares row)
     int g_sum = 768;
-    if (const char *e = std::getenv("SMM_FIT_GRID")) g_sum = std::atoi(e);     // (tuning aid)
+    if (smm_env_fit_grid() > 0) g_sum = smm_env_fit_grid();                    // (SMM_FIT_GRID: tuning aid)
     g_sum = (int)std::max<int64_t>(1, std::min<int64_t>(4 * n_chunks, g_sum));
     if ((d & 3) == 0) hipLaunchKernelGGL(smm_class_sums_kernel<true>, dim3(g_sum), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(smm_class_sums_kernel<false>, dim3(g_sum), dim3(256), 0, stream, a);

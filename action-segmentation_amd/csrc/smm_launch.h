@@ -51,8 +51,9 @@ int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream
 // Viterbi BAND mode: the state-major length table and the skip-test bounds of every (group, state) (smm_viterbi.hip)
 void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, int n_groups, int cm,
                             int k_rows, hipStream_t stream);
-// follow-up of a launch with gangs: decodes, on one CU each, the videos whose gang gave up (no-op kernels otherwise)
-void smm_launch_viterbi_recovery(const SmmDpArgs &a, int c_need, hipStream_t stream);
+// tuning switches other translation units read (smm_api.hip: SmmEnv; read once, see smm_env_reload)
+int smm_env_fit_grid();        // SMM_FIT_GRID (0: default)
+int smm_env_emission_v2();     // SMM_EMISSION_V2 (-DSMM_DEV builds only)
 // LogSemiring forward: logz[b]; same arguments as the Viterbi launch
 int smm_launch_logz(const SmmDpArgs &a, double *logz, int r, int c_need, hipStream_t stream);
 

@@ -37,9 +37,9 @@
 //
 // HBM traffic per frame (c states): read elp 8c, write history 24c (cumE and gamma frame-major, h state-major), label 8 B.
 //
-// K > 512 (up to 28 states): BAND mode below -- 128-slot rings shared by nine length bands, eight of them skipped by an
-// exact bound test, blocks of 8 positions.  29..32 states at K > 512, or SMM_BAND=0: the most expensive videos of a launch
-// run on TWO or THREE CUs (PAIR mode below: the lattice is cut along the segment length).
+// K > 512: BAND mode below -- 128-slot rings shared by nine length bands, eight of them skipped by an exact bound test,
+// blocks of 8 positions, up to 32 states on one CU.  (Rounds 1-3 also had 1024-slot rings and "gangs" of two or three
+// workgroups per video that exchanged rows through agent-scope atomics; BAND mode replaced both and round 4 removed them.)
 #include <type_traits>
 #include "smm_device.h"
 
@@ -239,214 +239,13 @@ __device__ __forceinline__ void smm_ring_init(double (&A)[R], double (&L)[R], co
     smm_ring_init_range<R>(A, L, len_col, cm, B + D, TRIB ? B + D + 1 : 2 * B + D, kp - 1, on, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// PAIR mode: a long video on TWO or THREE CUs (a "gang" of workgroups).  The time of a corpus is the time of its longest
-// videos, one CU each, while other CUs idle; a video cannot be cut along T, but its lattice can be cut along the segment
-// LENGTH:
-//   leader workgroup     chain wave + pushers for the SHORT range K0 < k <= 127 of every state (128-slot rings) and,
-//                        with one follower, for the LONG range 128 <= k <= kp-1 of the first cl states;
-//   follower workgroups  8 pusher waves each for the long range of the other states (one follower, or two that split
-//                        all states between them).
-// A long-range candidate for position n has a source <= n - 128, so a follower may lag the chain by ~100 positions:
-// it reads h rows from the history the leader writes anyway and returns A'_long rows through a fourth history array,
-// SMM_BF positions per exchange.  Progress counters in the workspace order them (pair_flags[4i] = h rows published,
-// [4i+1], [4i+2] = A'_long rows published by follower 0, 1).  Exchanged data and counters use agent-scope (sc1) loads
-// and stores -- the per-XCD L2s are not coherent with each other -- and each producer drains its own stores (vmcnt(0))
-// before it bumps the counter.  Every wait is bounded: a partner that never becomes resident (with in-order dispatch
-// of the grid at most one leader at a time waits for the CU its follower is about to get) sets error word 2 instead of
-// hanging.  max is exact and the candidates are the same expressions, so the result is bit-identical to one CU's.
-#define SMM_KS 127        // short range: K0 < k <= 127 (leader, 128-slot rings); long range: 128 <= k <= kp-1
-#define SMM_BF 16
-#define SMM_SPIN_LIMIT (1 << 22)
-
-// Who owns the long range of which states (SmmVideo::nfol followers, chosen by the host).  ONE follower (a pair) takes
-// states cl .. C-1; the leader, whose SIMDs are busy with the chain wave and the short range of every state, keeps a
-// few (cl) so that the follower's SIMDs hold at most 3 rings each where possible.  TWO followers (a triple) split all
-// states: above 16 states a pair leaves the leader's SIMDs the bottleneck (two long rings next to six short ones),
-// the triple is bound by the chain wave alone -- 1.2x faster for 1.25x the CU-time, so only the videos on the
-// launch's critical path get one.
-__device__ __forceinline__ int smm_pair_cl(int C, int nfol)
-{
-    if (nfol == 2) return 0;
-    // measured (T = 4096, 64 pairs): up to 16 states the follower's SIMDs should hold at most 3 rings each (cl = C - 12);
-    // above, the follower is full anyway and the leader -- two long rings on a SIMD already cost more than the chain
-    // wave's time -- keeps as few as the follower's capacity of 16 allows, at least 3 (one per SIMD)
-    int cl = C > 12 ? C - 12 : 0;
-    if (C > 16 && cl > 3) cl = 3;
-    if (C - cl > 16) cl = C - 16;                             // 20..23 states with one follower: 4..7
-    return cl;
-}
-// states c0 .. c0+nf-1 of follower f
-__device__ __forceinline__ void smm_follower_share(int C, int nfol, int f, int &c0, int &nf)
-{
-    if (nfol == 2) {
-        const int h = (C + 1) / 2;
-        c0 = f ? h : 0;
-        nf = f ? C - h : h;
-    } else {
-        c0 = smm_pair_cl(C, 1);
-        nf = f ? 0 : C - c0;
-    }
-}
-
 __device__ __forceinline__ double smm_ld_agent(const double *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void smm_st_agent(double *p, double v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One lane waits until a progress counter reaches `need` (bounded).  `seen` caches the last value read: the partner
-// usually runs ahead, and a poll is a round trip to memory.  Returns false once the partner is given up on: the gang's
-// failure word (pair_flags[4 gang + 3]) is set, every later wait of this workgroup returns at once, the loops run to
-// their counted end, and the recovery launch that follows the kernel on the stream decodes the video again without a
-// gang (smm_api.hip: run_viterbi).
-//
-// Memory ordering.  The hand-off is the form MI355X_MICROARCH.md lists as valid without an acquire/release pair: every
-// exchanged byte is stored sc1 (smm_st_agent) and loaded sc1 into registers (smm_ld_agent), the storing wave drains
-// its stores (s_waitcnt vmcnt(0)) before the counter store, and the counter is an agent-scope atomic polled with sc1
-// loads.  The signal fences pin the COMPILER's order (relaxed atomics to different addresses may otherwise be moved
-// across the poll); they emit no instruction.
-__device__ __forceinline__ bool smm_wait_progress(const int32_t *ctr, int need, int &seen, int32_t *gang_fail, bool alive,
-                                                  int spin_limit)
-{
-    if (!alive) return false;
-    if (seen >= need) return true;
-    for (int spin = 0; spin < spin_limit; ++spin) {
-        seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >= need) {
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);       // data loads stay behind the poll that matched
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __hip_atomic_store(gang_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-}
-
-// publish a progress counter: the caller has drained its stores (s_waitcnt vmcnt(0)) just before
-__device__ __forceinline__ void smm_publish(int32_t *ctr, int value)
-{
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);               // the counter store stays behind the data stores and their wait
-    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Follower workgroup of a pair: 8 pusher waves, wave w owns states cl + w and cl + w + 8 (long range only).
-// Blocks of SMM_BF sources.  Wave 0 fetches the h rows of the next block while the block is pushed (registers, then LDS);
-// wave 4 stores the block's A' rows and publishes the previous block's once its stores have drained.
-__device__ __forceinline__ void smm_follower(const SmmDpArgs &a, const SmmVideo &mv, int C, int pair, int fidx)
-{
-    constexpr int R = 16, RING = 1024, BF = SMM_BF, KL = SMM_KS + 1;
-    constexpr int NX = BF * 16 / 64;                          // row elements per lane of the moving waves (nf <= 16)
-    const int T = mv.T, cm = a.c_max, kp = mv.kp, g = mv.group;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int cl, nf;                                               // this follower's states cl .. cl+nf-1
-    smm_follower_share(C, mv.nfol, fidx, cl, nf);
-    if (nf <= 0) return;                                      // (the third workgroup of a gang whose video needs one follower)
-    const double *len = a.len + (size_t)g * a.k_rows * cm;
-    double *hh = a.hist + mv.hist_off + (size_t)C * (T + 1);            // history rows are C wide (see the kernel), A'_long rows cm
-    double *along = a.hist + mv.hist_off + (size_t)3 * C * (T + 1);
-    int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1 + fidx, *gang_fail = prog_h + 3;
-    const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
-    __shared__ __attribute__((aligned(16))) double f_h[2][BF][SMM_MAX_STATES_DEV];
-    __shared__ __attribute__((aligned(16))) double f_a[2][BF][SMM_MAX_STATES_DEV];
-
-    // positions 1..127 have no long-range candidate
-    const int n0 = (T < SMM_KS) ? T : SMM_KS;
-    for (int i = threadIdx.x; i < n0 * nf; i += blockDim.x) smm_st_agent(&along[(size_t)(1 + i / nf) * cm + cl + i % nf], SMM_NEG_INF);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    if (threadIdx.x == 0) smm_publish(prog_a, n0);
-    if (T <= SMM_KS) return;
-
-    double A[2][R], L[2][R];
-#pragma unroll
-    for (int js = 0; js < 2; ++js)
-        smm_ring_init_range<R>(A[js], L[js], len + cl + w + 8 * js, cm, KL, KL, kp - 1, w + 8 * js < nf, lane);
-    // element x of this lane in a block of rows.  A' rows are row-major like the other history arrays: (row, column) =
-    // ((lane + 64 x) / nf, cl + (lane + 64 x) % nf); the h history is state-major (see the kernel): (column, row) =
-    // (cl + (lane + 64 x) / BF, (lane + 64 x) % BF), BF consecutive lanes read 128 contiguous bytes.
-    int xr[NX], xc[NX], hr[NX], hc[NX];
-#pragma unroll
-    for (int x = 0; x < NX; ++x) {
-        const int e = lane + 64 * x;
-        xr[x] = (e < BF * nf) ? e / nf : -1;
-        xc[x] = cl + e % nf;
-        hr[x] = (e < BF * nf) ? e % BF : -1;
-        hc[x] = cl + e / BF;
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    const int QF = (T - KL) / BF + 1;                         // sources 0 .. T-128 are needed
-    bool alive = true;
-    int seen = 0;
-    double hreg[NX];
-    // h rows of block q (sources q BF ..), once the leader has published them; rows past T-1 do not exist
-    auto fetch = [&](int q) {
-        const int s0 = q * BF;
-        int ok = 1;
-        if (lane == 0) {
-            alive = smm_wait_progress(prog_h, (s0 + BF - 1 < T - 1) ? s0 + BF - 1 : T - 1, seen, gang_fail, alive, spin_limit);
-            ok = alive;
-        }
-        ok = __builtin_amdgcn_readfirstlane(ok);
-#pragma unroll
-        for (int x = 0; x < NX; ++x) {
-            const int row = hr[x] < 0 ? 0 : hr[x];
-            const int col = hr[x] < 0 ? cl : hc[x];
-            const int sr = (s0 + row <= T - 1) ? s0 + row : T - 1;
-            const double v = smm_ld_agent(&hh[(size_t)col * (T + 1) + sr]);
-            hreg[x] = (ok && hr[x] >= 0 && s0 + hr[x] <= T - 1) ? v : SMM_NEG_INF;
-        }
-    };
-    auto stage = [&](int q) {
-#pragma unroll
-        for (int x = 0; x < NX; ++x)
-            if (hr[x] >= 0) f_h[q & 1][hr[x]][hc[x]] = hreg[x];
-    };
-    if (w == 0) { fetch(0); stage(0); }
-    __syncthreads();
-    for (int q = 0; q < QF; ++q) {
-        const int s0 = q * BF;
-        if (w == 0 && q + 1 < QF) fetch(q + 1);               // in flight while this block is pushed
-        const bool hand = lane == (s0 & (RING - 1)) / R;
-#pragma unroll
-        for (int js = 0; js < 2; ++js) {
-            if (w + 8 * js >= nf) break;
-            const int c = cl + w + 8 * js;
-            double hv[BF];
-#pragma unroll
-            for (int i = 0; i < BF; ++i) hv[i] = f_h[q & 1][i][c];
-#pragma unroll
-            for (int i = 0; i < BF; ++i) smm_push<R>(A[js], L[js], hv[i], i);
-            if (hand) {
-#pragma unroll
-                for (int i = 0; i < BF; ++i) { f_a[q & 1][i][c] = A[js][i]; A[js][i] = SMM_NEG_INF; }
-            }
-        }
-        __syncthreads();
-        if (w == 0 && q + 1 < QF) stage(q + 1);
-        if (w == 4) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                // the previous block's rows are out
-            if (q >= 1 && lane == 0) smm_publish(prog_a, s0 - BF + KL + BF - 1);
-#pragma unroll
-            for (int x = 0; x < NX; ++x) {
-                const int n = s0 + KL + xr[x];
-                if (xr[x] >= 0 && n <= T) smm_st_agent(&along[(size_t)n * cm + xc[x]], f_a[q & 1][xr[x]][xc[x]]);
-            }
-        }
-        __syncthreads();
-    }
-    if (w == 4) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (lane == 0) smm_publish(prog_a, (QF - 1) * BF + KL + BF - 1);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
-// BAND mode (PAIR = 2): one workgroup per video at K > 512, the lattice cut along the segment length into BANDS that share
+// BAND mode (BAND = 1): one workgroup per video at K > 512, the lattice cut along the segment length into BANDS that share
 // ONE ring of 128 upcoming targets per state, and whole bands skipped -- exactly -- while they cannot matter.
 //   band 0     lengths up to 127 that the chain wave does not evaluate itself (see TRI in the kernel), sources
 //              undelayed: always evaluated (what a gang leader's short rings do);
@@ -511,25 +310,21 @@ __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double 
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
 // NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per lane group of the chain wave: 8, 12 or 16
-//     (two groups of 32 lanes) or 4 (launches of at most 16 states without gangs: FOUR groups of 16 lanes, merged by a
+//     (two groups of 32 lanes) or 4 (launches of at most 16 states: FOUR groups of 16 lanes, merged by a
 //     v_permlane16_swap on top of the v_permlane32_swap: 8 instructions fewer per position, same-box A/B: cfg2 DP -1 %,
 //     cfg4 DP -2.8 %)
 // One workgroup per CU is all that fits (and all that is wanted): tell the register allocator it may use the whole
 // architected VGPR budget of NW/4 waves per SIMD instead of spilling for an occupancy nobody asked for.
-// CP  1: the chain wave also owns the ring of state (NW-1)*SPW (the 12-wave configuration for 22..23 states)
 // B   positions per hand-over block; D = 1: pushers lag one more source (see smm_ring_block); the chain wave evaluates
 //     lengths 1..2B+D-1 itself
-// PAIR 1: the first 3*a.n_pairs workgroups are gangs of leader / follower 0 / follower 1 (R = 16, 8 waves only; see
-//         PAIR mode above; follower 1 returns at once when the video needs one follower)
-//      2: BAND mode (above): one workgroup per video, 128-slot rings, SPW = states per state-owning pusher wave (3..5)
-template <int R, int SPW, int NW, int HF, int CP, int B, int D = SMM_D, int PAIR = 0>
+// BAND  BAND mode (above): one workgroup per video at K > 512, 128-slot rings, SPW = states per state-owning pusher wave (3..6)
+template <int R, int SPW, int NW, int HF, int B, int D = SMM_D, bool BAND = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    static_assert(PAIR != 1 || (R == 16 && NW == 8 && CP == 0 && B == 4 && D == 1), "pair mode: K <= 1024, 8 waves");
-    static_assert(PAIR != 2 || (R == 16 && NW == 8 && CP == 0 && B == 8 && D == 0),
+    static_assert(!BAND || (R == 16 && NW == 8 && B == 8 && D == 0),
                   "band mode: K <= 1024, 8 waves, blocks of 8 positions, the pushers push the block's own sources");
-    constexpr bool GANG = PAIR == 1, BAND = PAIR == 2;
+    static_assert(BAND || R < 16, "rings of 1024 slots exist in BAND mode only");
 #ifndef SMM_TRI
 #define SMM_TRI 1
 #endif
@@ -540,47 +335,18 @@ smm_viterbi_kernel(SmmDpArgs a)
     // receiving those lengths for up to B - 1 pushes after its hand-over, addressed to a target that is gone: the slots
     // are cleared a second time one block later, before anything real reaches them (a ring's own lengths come back at
     // its far end, the delayed bands of BAND mode stay off ring indices < 16).
-    constexpr bool TRI = SMM_TRI && ((BAND && D == 0) || (PAIR == 0 && B == 8 && B % R == 0 && NW == 8 && CP == 0));
+    constexpr bool TRI = SMM_TRI && ((BAND && D == 0) || (!BAND && B == 8 && B % R == 0 && NW == 8));
     constexpr int K0 = 2 * B + D - 1;                      // segment lengths the chain wave evaluates itself
     constexpr int NP = NW - 1;
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
     constexpr int M = (D ? 4 : 2) * B;                     // chain wave: h[n] of the last M > K0 positions, slot n mod M
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
-    // role: 0 one workgroup per video, 1 leader, 2 follower of pair blockIdx.x / 2
-    int role = 0, vsel = blockIdx.x;
-    if (GANG) {
-        if ((int)blockIdx.x < 3 * a.n_pairs) { role = 1 + blockIdx.x % 3; vsel = blockIdx.x / 3; }   // gang: leader, follower 0, 1
-        else vsel = blockIdx.x - 2 * a.n_pairs;
-    }
-    const int pair = blockIdx.x / 3;
-    const bool recover = PAIR == 0 && (a.flags & 16);
-    if (recover) {
-        // RECOVERY launch (follows a gang launch on the stream; grid = number of gangs): workgroup p decodes the video of
-        // gang p again on ONE CU if that gang gave up waiting for a partner, and only if this configuration holds the
-        // video's states (the host launches the 8-wave and the 12-wave configuration; exactly one fits).
-        if (__hip_atomic_load(a.pair_flags + 4 * blockIdx.x + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    }
-    const int vid = a.order[vsel];
+    const int vid = a.order[blockIdx.x];
     SmmVideo mv = a.videos[vid];
     if (a.flags & 8) mv.T -= 1;               // no EOS: the DP covers the frames before the last one (smmdp.h)
     const int T = mv.T;
     const int g = mv.group;
     const int C = a.n_states[g];
-    if (recover) {
-        constexpr int cap = (NW - 1) * SPW + CP;
-        // (8 waves: <= 21 states; 12 waves: 22..23; 16 waves, spilling: 24..30 with 2 states per wave, 31..32 with 3 --
-        // those only ever ran as triples)
-        const bool mine = (NW == 8) ? C <= cap : ((NW == 12) ? (C > 21 && C <= cap) : ((SPW == 2) ? (C > 23 && C <= cap) : C > 30));
-        if (NW == 8 && threadIdx.x == 0) atomicAdd(a.err + 1, 1);          // gangs that timed out
-        if (!mine) return;
-    }
-    if (GANG && role >= 2) {
-        if ((a.flags & 32) && pair == 0) return;                           // (test hook: gang 0's followers never show up)
-        if (T > 0) smm_follower(a, mv, C, pair, role - 2);
-        return;
-    }
-    const bool lead = GANG && role == 1;
-    const int cl = lead ? smm_pair_cl(C, mv.nfol) : 0;        // leader: long-range states it keeps
     const int cm = a.c_max;
     const int kp = mv.kp;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: scalar branches
@@ -607,7 +373,6 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
-    __shared__ __attribute__((aligned(16))) double sh_along[GANG ? 2 : 1][GANG ? B : 1][SMM_MAX_STATES_DEV];   // pair mode: long-range A'[n][c]
     __shared__ double sh_hm[BAND ? SMM_MAX_STATES_DEV : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
@@ -633,17 +398,15 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
-            if (GANG) { sh_along[0][i][c] = SMM_NEG_INF; sh_along[GANG ? 1 : 0][i][c] = SMM_NEG_INF; }
         }
         sh_gam[c] = SMM_NEG_INF;
         sh_gfin[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
             hcum[c] = 0.0;
-            if (lead) smm_st_agent(&hh[(size_t)c * (T + 1)], init[c]);             // (a pair's follower reads h rows)
-            else hh[(size_t)c * (T + 1)] = init[c];
+            hh[(size_t)c * (T + 1)] = init[c];
         }
     }
-    constexpr bool SPEC = SMM_SPEC && !GANG && (R < 16 || BAND);   // (the kernels whose chain wave computes whole blocks: TAILFREE below)
+    constexpr bool SPEC = SMM_SPEC != 0;
     if constexpr (SPEC) {
         for (int e = threadIdx.x; e < SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV; e += blockDim.x) {
             const int to = e / SMM_MAX_STATES_DEV, f = e % SMM_MAX_STATES_DEV;
@@ -690,8 +453,6 @@ smm_viterbi_kernel(SmmDpArgs a)
 #define SMM_BAND_GAMROW 0   // (same-box A/B at B = 8: the history row as broadcast row, one LDS store less per position, -2 %)
 #endif
         constexpr bool GAMROW = BAND ? bool(SMM_BAND_GAMROW) : ((B > 4) || (R < 4));   // a separate gamma broadcast row (see the position loop)
-        constexpr bool TAILFREE = R < 16 || BAND;          // no bounds tests inside a block (see the position loop; BAND:
-                                                           // the chain wave alone bounds the frame, whatever the state count)
         // The transition's fold is compiled for the launch's largest class set (HF source states per lane group) AND,
         // in BAND launches of more than 16 states, for <= 16 states (four lane groups of 16, four sources each): a
         // corpus mixes tasks of 11..23 states in one launch, and a video of 11 states need not fold 24 sources.
@@ -718,17 +479,10 @@ smm_viterbi_kernel(SmmDpArgs a)
             // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
             // s_and_saveexec / branch / s_or groups per position) on the serial path.
             double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
-            double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
             double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
             double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
             double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
-            // own ring (CP): state cx, same code as a pusher with one state
-            constexpr int cx = NP * SPW;
-            const bool has1 = CP && cx < C;
-            double A1[CP ? R : 1], L1[CP ? R : 1], hd1 = SMM_NEG_INF;
-            if constexpr (CP) smm_ring_init<R, B, D>(A1, L1, len + cx, cm, kp, has1, lane);
-            constexpr int UM = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even,
-            constexpr int UC = (CP && UB > UM) ? UB : UM;     // and a multiple of UB when the wave owns a ring
+            constexpr int UC = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even
             SMM_PROF_DECL;
             // SPEC: the transition SPECULATED on one source.  beta[to] = max_c (gamma[c] + trans[to][c]) is the largest piece of
             // a position (12 adds, 12 maxes, 6 LDS reads behind an LDS round trip at 17..24 states), and on real data its
@@ -760,7 +514,6 @@ smm_viterbi_kernel(SmmDpArgs a)
     #pragma unroll
                     for (int i = 0; i < B; ++i) {
                         ap[i] = sh_apart[jj & 1][i][to];
-                        if (GANG) ap[i] = smm_fmax(ap[i], sh_along[GANG ? (jj & 1) : 0][i][to]);   // (-inf unless this is a leader)
                         ev[i] = sh_e[jj & 1][i][to];
                     }
                     // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
@@ -813,14 +566,10 @@ smm_viterbi_kernel(SmmDpArgs a)
                         constexpr int MODE = decltype(mode_c)::value;
     #pragma unroll
                         for (int i = 0; i < B; ++i) {
-                            // Rings below 1024 slots (the chain wave bounds the frame): every position of a block is computed,
-                            // also those past T in the tail of the last block (their rows are never stored, published or read):
-                            // no bounds test on the serial path -- every instruction of this wave, scalar compare and branch
-                            // included, is a slot of the position's time (same-box A/B: cfg2 DP -1.2 %).  At 1024 slots the same
-                            // change made cfg1 1.3 % faster and cfg3 1 % slower (its one-CU videos are bound by the pusher that
-                            // shares the chain wave's SIMD): those keep the tests.
-                            const int n = j * B + 1 + i;           // position; n mod M == (jj*B + 1 + i) mod M
-                            if constexpr (!TAILFREE) { if (n > T) break; }
+                            // Every position of a block is computed, also those past T in the tail of the last block (their
+                            // rows are never stored, published or read): no bounds test on the serial path -- every instruction
+                            // of this wave, scalar compare and branch included, is a slot of the position's time (same-box A/B:
+                            // cfg2 DP -1.2 %).  Position n = jB + 1 + i; n mod M == (jj*B + 1 + i) mod M.
                             const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
                             cum = cumn;
                             const double gm = cum + acc;
@@ -830,9 +579,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                             if constexpr (GAMROW) st_gam[0] = gm;
                             if constexpr (!(SMM_ABLATE & 256)) st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
                             if constexpr (!(SMM_ABLATE & (2 | 256))) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
-                            // (TAILFREE: gamma[T] is read back from the block's rows behind the loop -- no test per position)
-                            if constexpr (!TAILFREE) { if (n == T) st_fin[0] = gm; }      // (wave-uniform, once per video)
-                            if (TAILFREE || n < T) {
+                            // (gamma[T] is read back from the block's rows behind the loop -- no test per position)
+                            {
                                 double hcur;
                                 if constexpr (MODE == 1) {
                                     // (while no leader holds -- after a failed check earlier in this block -- dlt is -inf and lane cs
@@ -903,17 +651,12 @@ smm_viterbi_kernel(SmmDpArgs a)
                             else { dlt = SMM_NEG_INF; spec_wait = spec_back; spec_back = spec_back < 32 ? 2 * spec_back : 32; }
                         }
                     }
-                    if constexpr (CP) {
-                        if (has1) smm_ring_block<R, B, D>(A1, L1, hd1, &sh_h[(jj + 1) & 1][0][cx], &sh_apart[(jj + 1) & 1][0][cx], j, jj % UB, lane, ninf);
-                    }
-                    if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j (LDS-only: see smm_lds_barrier)
+                    SMM_LDS_BARRIER();                           // end of block j (LDS-only: see smm_lds_barrier)
                 }
             }
-            if constexpr (TAILFREE) {
-                // gamma[T] for the closing step: the row of position T in the last block's staging rows (written by lane
-                // group 0; every wave reads sh_gfin behind the __syncthreads() that follows the loops)
-                if (half == 0) sh_gfin[to] = sh_g[(J - 1) & 1][(T - 1) % B][to];
-            }
+            // gamma[T] for the closing step: the row of position T in the last block's staging rows (written by lane
+            // group 0; every wave reads sh_gfin behind the __syncthreads() that follows the loops)
+            if (half == 0) sh_gfin[to] = sh_g[(J - 1) & 1][(T - 1) % B][to];
 #ifdef SMM_PROFILE
             p_ph[2] = p_fastn;                                // (slot 34 of the stamps: wave 0 has no blocks with j mod 4 = 2)
 #endif
@@ -925,146 +668,6 @@ smm_viterbi_kernel(SmmDpArgs a)
         } else {
             chain(std::integral_constant<int, HF>{});
         }
-    } else if (GANG && lead) {
-        // ============================================================================ pusher waves of a pair's leader
-        // every pusher: short range (K0 < k <= 127, 128-slot rings) of states rank, rank+7, rank+14, rank+21, rank+28 and long range
-        // (128 <= k <= kp-1, 1024-slot rings) of states rank, rank+7 below cl.  The follower's long-range A' rows come
-        // back through HBM; four pusher waves move the HBM traffic (below).
-        constexpr int SPS = 5, SPL = 2, RS = 2;               // (5 x 7 short rings: up to 32 states; 2 long rings per pusher)
-        const int rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);
-        const int kshort = (kp - 1 < SMM_KS) ? kp - 1 : SMM_KS;
-        double As[SPS][RS], Ls[SPS][RS], hds[SPS];
-#pragma unroll
-        for (int js = 0; js < SPS; ++js) {
-            const int c = js * NP + rank;
-            smm_ring_init_range<RS>(As[js], Ls[js], len + c, cm, B + D, 2 * B + D, kshort, c < C, lane);
-            hds[js] = SMM_NEG_INF;
-        }
-        double Al[SPL][R], Ll[SPL][R], hdl[SPL];
-#pragma unroll
-        for (int js = 0; js < SPL; ++js) {
-            const int c = js * NP + rank;
-            smm_ring_init_range<R>(Al[js], Ll[js], len + c, cm, B + D, SMM_KS + 1, kp - 1, c < cl, lane);
-            hdl[js] = SMM_NEG_INF;
-        }
-        int lo[NE], row[NE];
-        bool mine[NE];                                                     // element belongs to a follower-owned column
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            row[q] = e / cm;
-            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
-            mine[q] = lo[q] >= 0 && e % cm >= cl && e % cm < C;
-        }
-        double *along = hgam + (size_t)C * (T + 1);                        // fourth history array: A'_long rows of the follower ([T+1][cm])
-        int slo[NE], srw[NE];                                              // history block element e (rows C wide) -> LDS offset, row
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            srw[q] = e / C;
-            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
-        }
-        int32_t *prog_h = a.pair_flags + 4 * pair, *prog_a = prog_h + 1;  // [1], [2]: follower 0, follower 1
-        int32_t *gang_fail = prog_h + 3;
-        const int spin_limit = (a.flags & 32) ? (1 << 10) : SMM_SPIN_LIMIT;
-        const bool two = mv.nfol == 2;
-        const int64_t e_last = (int64_t)T * cm - 1, a_last = (int64_t)(T + 1) * cm - 1;
-        // Movers: every wave waits only for what it issued TWO blocks ago (nothing younger of its own is in flight),
-        // so the hipcc-inserted vmcnt(0) costs nothing.  Loaders: wave 4 on even blocks, wave 7 on odd blocks -- at
-        // block j write block j+1 (fetched at block j-2) to LDS, then fetch block j+3.  Storers: wave 5 on even
-        // blocks, wave 6 on odd blocks -- at block j publish the rows up to (j-2)B (its own stores of block j-2 have
-        // drained, the other storer's older ones drained before the last barrier), then store history block j-1.
-        const int ldpar = (w == 4) ? 0 : ((w == 7) ? 1 : -1);
-        const int stpar = (w == 5) ? 0 : ((w == 6) ? 1 : -1);
-        double pre[NE], pal[NE];
-        bool alive = true;
-        int seen = 0, seen1 = 0;
-        if (ldpar >= 0) {
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                const int64_t e = (int64_t)(1 + ldpar) * B * cm + lane + 64 * q;   // block 1 (even loader) / block 2 (odd)
-                pre[q] = elp[e < e_last ? e : e_last];
-                pal[q] = SMM_NEG_INF;                                              // positions <= 3B < 128: nothing long-range
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0), see the single-workgroup pushers
-        auto store_block = [&](const double *src, double *dst, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x;
-                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
-            }
-        };
-        // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes), with
-        // agent-scope stores: the follower reads them
-        auto store_h_block = [&](const double *src, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x, c = e / B, i = e % B;
-                if (c < C && q * B + 1 + i <= T)
-                    smm_st_agent(&hh[(size_t)c * (T + 1) + q * B + 1 + i], src[i * SMM_MAX_STATES_DEV + c]);
-            }
-        };
-        SMM_PROF_DECL;
-        for (int j0 = 0; j0 < J; j0 += UB) {
-#pragma unroll
-            for (int jj = 0; jj < UB; ++jj) {
-                const int j = j0 + jj;
-                if (j >= J) break;
-                if (ldpar == (jj & 1)) {
-                    // block j+1 (fetched two blocks ago) -> LDS
-                    double *dst = &sh_e[(jj + 1) & 1][0][0];
-                    double *dsa = &sh_along[(jj + 1) & 1][0][0];
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
-                        if (mine[q]) dsa[lo[q]] = pal[q];
-                    }
-                    // fetch block j+3: elp rows, and the follower's A' rows once it has published them
-                    if (lane == 0) {
-                        const int need = ((j + 4) * B < T) ? (j + 4) * B : T;
-                        alive = smm_wait_progress(prog_a, need, seen, gang_fail, alive, spin_limit);
-                        if (two) alive = smm_wait_progress(prog_a + 1, need, seen1, gang_fail, alive, spin_limit);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        const int64_t e = (int64_t)(j + 3) * B * cm + lane + 64 * q;
-                        pre[q] = elp[e < e_last ? e : e_last];
-                        const int64_t ea = e + cm;                                 // position = frame + 1
-                        pal[q] = smm_ld_agent(&along[ea < a_last ? ea : a_last]);
-                    }
-                } else if (stpar == (jj & 1)) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (j >= 3 && lane == 0) smm_publish(prog_h, (j - 2) * B);
-                    if (j >= 1) {
-                        store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
-                        store_h_block(&sh_h[(jj + 1) & 1][0][0], j - 1);
-                        store_block(&sh_g[(jj + 1) & 1][0][0], hgam, j - 1);
-                    }
-                }
-#pragma unroll
-                for (int js = 0; js < SPS; ++js) {
-                    const int c = js * NP + rank;
-                    if (c >= C) break;
-                    smm_ring_block<RS, B, D>(As[js], Ls[js], hds[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
-                }
-#pragma unroll
-                for (int js = 0; js < SPL; ++js) {
-                    const int c = js * NP + rank;
-                    if (c >= cl) break;
-                    smm_ring_block<R, B, D>(Al[js], Ll[js], hdl[js], &sh_h[(jj + 1) & 1][0][c], &sh_along[(jj + 1) & 1][0][c], j, jj, lane, ninf);
-                }
-                SMM_BLOCK_BARRIER();                             // end of block j
-            }
-        }
-        SMM_PROF_OUT();
-        // the last block's history; every h row is out once both storers have drained
-        if (stpar == (J & 1)) {
-            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
-            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
-            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
-        }
-        if (stpar >= 0) __builtin_amdgcn_s_waitcnt(0x0F70);                 // (published after the barrier below)
     } else if (BAND) {
       if constexpr (BAND) {
         // ============================================================================ pusher waves, BAND mode (see above)
@@ -1406,7 +1009,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         // the lower priority -- owns NO states and only moves data (as in BAND mode).  With two states it was the wave the
         // block barrier waited for (stamps on cfg2's shape: busy 3720 cycles per block of 8, the chain wave 3470, the
         // other pushers <= 2600).
-        const bool stateless = NW == 8 && !GANG && C <= (NP - 1) * SPW && !(SMM_MOVER_STATES);
+        const bool stateless = NW == 8 && C <= (NP - 1) * SPW && !(SMM_MOVER_STATES);
         const int NPd = stateless ? NP - 1 : NP;                           // state-owning pushers
         if (NW == 8) {
             if (stateless) {
@@ -1418,7 +1021,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if (swap >= 0) rank = (rank == swap) ? NP - 1 : ((rank == NP - 1) ? swap : rank);
             }
         }
-        // (12 waves: every pusher owns SPW states, nothing to rebalance)
         const int nv_all = (C - rank + NPd - 1) / NPd;                     // states rank, rank+NPd, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
         double A[SPW][R], L[SPW][R], hd[SPW];
@@ -1522,7 +1124,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                     const int c = js * NPd + rank;
                     smm_ring_block<R, B, D, TRI>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
-                if constexpr (!GANG) SMM_LDS_BARRIER(); else SMM_BLOCK_BARRIER();   // end of block j
+                SMM_LDS_BARRIER();                               // end of block j
             }
         }
         SMM_PROF_OUT();
@@ -1537,8 +1139,6 @@ smm_viterbi_kernel(SmmDpArgs a)
     // -------------------------------------------------------------------------------- last position
     // sh_gfin holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
-    if (GANG && lead && threadIdx.x == 5 * 64)                             // both storer waves have drained: every h row is out
-        smm_publish(a.pair_flags + 4 * pair, T);
     const bool no_eos = (a.flags & 8) != 0;    // add_eos=False: T counts the frames before the last one (see smmdp.h)
     if (w == 0) {
         double f = SMM_NEG_INF;
@@ -1565,12 +1165,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     __syncthreads();
 
     // -------------------------------------------------------------------------------- back-trace
-    if (a.flags & 1) return;
-    if (GANG && lead) {
-        // a gang that gave up (this workgroup or a follower) has garbage in its lattice: leave the outputs to the recovery
-        // launch.  (A follower only ever gives up when this leader was not making progress, i.e. before this point.)
-        if (__hip_atomic_load(a.pair_flags + 4 * pair + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    }
+#ifdef SMM_DEV
+    if (a.flags & 1) return;                   // (profiling builds: stop after the forward pass, outputs undefined)
+#endif
     // At a span start (n, to) the predecessor is the FIRST (k ascending, then from ascending) whose
     //   (cumE[n][from] + (h[n-k][from] + len[k][from])) + w(to, from)  equals the maximum.
     // Adding is monotone, so a hit needs gamma[n][from] + w(to, from) == maximum: phase A (every wave, redundantly,
@@ -1659,7 +1256,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                 }
             }
             if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg + (no_eos ? 1 : 0);
-            if (recover && threadIdx.x == 0) atomicAdd(a.err + 2, 1);
             return;
         }
     }
@@ -1767,7 +1363,6 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
 #endif
     if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg + (no_eos ? 1 : 0);
-    if (recover && threadIdx.x == 0) atomicAdd(a.err + 2, 1);                   // repaired
 #ifdef SMM_PROFILE_END   // diagnostic build: when did each video's (leader) workgroup finish?  (100 MHz wall clock into best[])
     if (a.best && threadIdx.x == 0) a.best[vid] = (double)wall_clock64();
 #endif
@@ -1817,60 +1412,55 @@ void smm_launch_band_tables(const double *len, const int32_t *n_states, double *
 #include "../../include/smmdp.h"
 #include "smm_launch.h"
 
-// Configuration: 1 chain wave + NP pusher waves x SPW states, NP * SPW >= states.  VALU code can only address the
-// 256 architected VGPRs (the other half of the unified file are AGPRs) and a pusher needs ~4*R*SPW + 40 of them, so
-// R*SPW <= 52.  Fewer, fatter pushers are preferred (fewer waves per barrier), but at least one pusher per SIMD.
+// Configuration: 1 chain wave + NP pusher waves x SPW states.  VALU code can only address the 256 architected VGPRs (the
+// other half of the unified file are AGPRs) and a pusher needs ~4*R*SPW + 40 of them.  Fewer, fatter pushers are
+// preferred (fewer waves per barrier), but at least one pusher per SIMD.  K <= 512 (R <= 8): up to 32 states on 8 waves.
 template <int R, int SPW, int NW>
 static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_t stream)
 {
     if (spw != SPW || nw != NW) return 0;
-    // 16 waves leave 128 VGPRs per wave: the chain wave then keeps a shorter window (B = 2)
-    constexpr int B = (NW == 16 && R >= 8) ? 2 : ((R == SMM_B8_R && NW == 8) ? 8 : SMM_B);
-    if constexpr (R == 16 && NW == 8 && B == 4 && SMM_D == 1) {
-        if (a.n_pairs > 0) {                                     // gangs of 3 workgroups first: a.b + 2 n_pairs workgroups
-            const dim3 grid(a.b + 2 * a.n_pairs);
-            if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 8, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
-            else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 12, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
-            else hipLaunchKernelGGL((smm_viterbi_kernel<R, SPW, NW, 16, 0, B, SMM_D, 1>), grid, dim3(NW * 64), 0, stream, a);
-            return 1;
-        }
-    }
-    if (a.n_pairs > 0) return 0;                                 // (the host only pairs for the configuration above)
+    constexpr int B = (R == SMM_B8_R && NW == 8) ? 8 : SMM_B;
     // R = 1 (kp <= 64): the window back-trace stages history and tables in dynamic LDS (a.bt_dyn_bytes, up to ~125 KB:
-    // the 64 KB default limit of dynamic LDS is lifted once per kernel)
+    // the 64 KB default limit of dynamic LDS is lifted once per kernel and device)
     const size_t dyn = (R == 1 && a.bt_window > 0) ? (size_t)a.bt_dyn_bytes : 0;
     auto go = [&](auto kernel) {
         if constexpr (R == 1) {
-            static bool raised = false;
-            if (!raised) {
+            static bool raised[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+            if (!raised[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                raised = true;
+                raised[dev] = true;
             }
         }
         hipLaunchKernelGGL(kernel, dim3(a.b), dim3(NW * 64), dyn, stream, a);
     };
-    // HF: source states per half of the chain wave (2 HF >= states)
-    if (c_need <= 16) go(smm_viterbi_kernel<R, SPW, NW, 4, 0, B>);
-    else if (c_need <= 24) go(smm_viterbi_kernel<R, SPW, NW, 12, 0, B>);
-    else go(smm_viterbi_kernel<R, SPW, NW, 16, 0, B>);
+    // HF: source states per lane group of the chain wave (4: four groups of 16 lanes; else two groups, 2 HF >= states)
+    if (c_need <= 16) go(smm_viterbi_kernel<R, SPW, NW, 4, B>);
+    else if (c_need <= 24) go(smm_viterbi_kernel<R, SPW, NW, 12, B>);
+    else go(smm_viterbi_kernel<R, SPW, NW, 16, B>);
     return 1;
 }
 
-// BAND mode (the host asks for it with flags bit 7): 8 waves, up to 21 states with 3 per pusher wave, up to 28 with 4
+// BAND mode (K > 512): 8 waves, six state-owning pusher waves with 3 states each up to 18 states, 4 up to 24, 5 up to 30,
+// 6 up to 32; HF = source states per lane group of the chain wave
 static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
-    // six state-owning pusher waves: up to 18 states with 3 each, 24 with 4, 28 (30) with 5; HF = source states per lane
-    // group of the chain wave (4: four groups of 16 lanes)
     const dim3 grid(a.b), block(512);
 #ifdef SMM_DEV_BAND_ONE   // development builds: one instantiation
     (void)c_need;
-    hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
+#ifndef SMM_DEV_BAND_SPW
+#define SMM_DEV_BAND_SPW 4
+#define SMM_DEV_BAND_HF 12
+#endif
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, SMM_DEV_BAND_SPW, 8, SMM_DEV_BAND_HF, 8, 0, true>), grid, block, 0, stream, a);
     return SMM_OK;
 #else
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 0, 8, 0, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 0, 8, 0, 2>), grid, block, 0, stream, a);
-    else if (c_need <= 28) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 0, 8, 0, 2>), grid, block, 0, stream, a);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 8, 0, true>), grid, block, 0, stream, a);
+    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 8, 0, true>), grid, block, 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 8, 0, true>), grid, block, 0, stream, a);
+    else if (c_need <= 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 8, 0, true>), grid, block, 0, stream, a);
+    else if (c_need <= 32) hipLaunchKernelGGL((smm_viterbi_kernel<16, 6, 8, 16, 8, 0, true>), grid, block, 0, stream, a);
     else return SMM_ERR_UNSUPPORTED;
     return SMM_OK;
 #endif
@@ -1879,77 +1469,20 @@ static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 template <int R>
 static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
-    // 8 waves: 256 VGPRs per wave -> R*SPW <= 52;  16 waves: 128 VGPRs per wave -> R*SPW <= 22.
-    // K > 512 with more than 21 states fits neither (the rings of 22+ states x 1024 slots x fp64 (A, len) exceed the
-    // CU's register file); that shape still runs -- 16 waves x 2 states, spilling to scratch -- but slowly.
-    constexpr int SPW8 = (52 / R) > 5 ? 5 : (52 / R);
-    constexpr int SPW16 = (22 / R) > 3 ? 3 : ((22 / R) < 1 ? 1 : (22 / R));
-    int nw = 8;
-    if (const char *e = std::getenv("SMM_NW")) nw = std::atoi(e);   // tuning aid: minimum wave count
-    if (nw != 4 && nw != 8 && nw != 16) nw = 8;
-    if constexpr (R == 16) {
-        if (a.flags & 128) return launch_band(a, c_need, stream);
-    }
-    if constexpr (R == 16) {
-        // 22..32 states, every such video in a gang (a.flags bit 2; 24..32: a triple): the 8-wave kernel, whose gang leaders
-        // hold 35 short-range states and whose single workgroups only ever see <= 21
-        if ((a.flags & 4) && a.n_pairs > 0 && c_need <= 32 && nw == 8)
-            return launch_if<16, 3, 8>(a, 3, 8, c_need, stream) ? SMM_OK : SMM_ERR_UNSUPPORTED;
-    }
-    if (nw == 8 && (c_need + 6) / 7 > SPW8) nw = 16;
-    (void)SPW16;
-    if constexpr (R == 16) {
-        // 22..23 states at K > 512: 12 waves (170 VGPRs each) = 11 pushers x 2 states + the chain wave's own ring
-        if (nw == 16 && c_need <= 23) {
-            hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), dim3(a.b), dim3(12 * 64), 0, stream, a);
-            return SMM_OK;
-        }
-    }
+    // 8 waves (256 VGPRs per wave): 7 pushers x up to 5 states; 4 waves for the short rings of small launches
+    const int nw = 8;
     const int spw = (c_need + nw - 2) / (nw - 1);
     int hit = 0;
     if constexpr (R <= 4) {
-        hit = launch_if<R, 1, 4>(a, spw, nw, c_need, stream) || launch_if<R, 2, 4>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 4>(a, spw, nw, c_need, stream) || launch_if<R, 4, 4>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 6, 4>(a, spw, nw, c_need, stream) || launch_if<R, 8, 4>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
+        hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
               launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 5, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
+              launch_if<R, 5, 8>(a, spw, nw, c_need, stream);
     } else if constexpr (R == 8) {
         hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
               launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 5, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
-    } else if constexpr (R == 16) {
-        hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 1, 16>(a, spw, nw, c_need, stream) || launch_if<R, 2, 16>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 16>(a, spw, nw, c_need, stream);
+              launch_if<R, 5, 8>(a, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
-}
-
-// Recovery launches behind a gang launch (see the kernel: `recover`): one workgroup per gang, which returns at once
-// unless its gang's failure word is set.  1024-slot rings only (gangs exist for nothing else).
-void smm_launch_viterbi_recovery(const SmmDpArgs &a0, int c_need, hipStream_t stream)
-{
-#ifdef SMM_DEV_BAND_ONLY
-    (void)a0; (void)c_need; (void)stream;
-#else
-    SmmDpArgs a = a0;
-    a.flags = (a0.flags & ~4) | 16;
-    const dim3 grid(a0.n_pairs);
-    a.n_pairs = 0;
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 8, 0, SMM_B>), grid, dim3(512), 0, stream, a);
-    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 0, SMM_B>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 16, 0, SMM_B>), grid, dim3(512), 0, stream, a);
-    if (c_need > 21) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 12, 12, 1, 2>), grid, dim3(12 * 64), 0, stream, a);
-    if (c_need > 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
-    if (c_need > 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 16, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
-    else if (c_need > 23) hipLaunchKernelGGL((smm_viterbi_kernel<16, 2, 16, 12, 0, 2>), grid, dim3(16 * 64), 0, stream, a);
-#endif
 }
 
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)
@@ -1968,7 +1501,7 @@ int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream
     SMM_CASE_R(2)
     SMM_CASE_R(4)
     SMM_CASE_R(8)
-    SMM_CASE_R(16)
+    case 16: if constexpr (SMM_DEV_R == 0 || SMM_DEV_R == 16) return launch_band(a, c_need, stream); else break;
     default: break;
     }
 #undef SMM_CASE_R

@@ -337,7 +337,7 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 16].view(torch.int32)      # [error, gangs timed out, gangs repaired, band-blocks evaluated]
+    return ws[off:off + 16].view(torch.int32)      # [error, 0, 0, band-blocks evaluated]
 
 
 def _err_copy(batch, ws):
@@ -356,12 +356,9 @@ def error_flag(batch, out=None, ws=None):
     return error_words(batch, out, ws)[0]
 
 
-gang_timeouts_repaired = 0     # how often a decode had gangs repaired by the recovery launch (diagnostic counter)
-
-
 def error_words(batch, out=None, ws=None):
-    """[error word, gangs that timed out, gangs repaired by the recovery launch, delayed band-blocks evaluated (a
-    diagnostic of the Viterbi kernel's BAND mode: smm_viterbi.hip)] of a decode (synchronises)."""
+    """[error word, 0, 0, delayed band-blocks evaluated (a diagnostic of the Viterbi kernel's BAND mode:
+    smm_viterbi.hip)] of a decode (synchronises).  (Words 1 and 2 counted gang time-outs in rounds 1-3.)"""
     if out is not None and out.get('_err') is not None:
         return [int(v) for v in out['_err'].tolist()]
     if ws is None:
@@ -371,15 +368,8 @@ def error_words(batch, out=None, ws=None):
 
 def check_decoded(batch, out=None):
     """Call after the decode's outputs have reached the host (the stream is idle then): raises SmmError when the DP
-    kernel flagged the run.  1: a NaN / inf - inf reached the DP; 2: a two-CU gang (smm_viterbi.hip, PAIR mode) gave
-    up waiting for its partner workgroup -- the outputs are invalid (the library relaunches such a batch without
-    gangs by itself, so this only surfaces when that was switched off)."""
-    global gang_timeouts_repaired
-    flag, timed_out, repaired = error_words(batch, out)[:3]
-    gang_timeouts_repaired += repaired
-    if timed_out > repaired:
-        raise _lib.SmmError("libsmmdp: %d gang(s) of workgroups timed out waiting for a partner and %d were repaired by "
-                            "the recovery launch; outputs invalid (SMM_PAIRS=0 disables gangs)" % (timed_out, repaired))
+    kernel flagged the run: a NaN / inf - inf reached the DP of some video and its decode stopped early."""
+    flag = error_words(batch, out)[0]
     if flag != 0:
         raise _lib.SmmError("libsmmdp: NaN (or inf - inf) in the DP inputs; decode stopped early (error word %d)" % flag)
 
@@ -489,8 +479,29 @@ def dp_timing(on):
     _lib.load().smm_dp_timing_enable(1 if on else 0)
 
 
-def dp_timing_read(cap=4096):
-    """Durations (ms, launch order) of the DP kernel launches recorded since the last read; waits for them."""
+def dp_timing_read(cap=4096, tagged=False):
+    """Durations (ms, launch order) of the DP kernel launches recorded since the last read; waits for them.
+    ``tagged``: (ms, tag) pairs -- tag 0: the only DP launch of its call, 1: the critical videos of a split decode
+    (caller's stream), 2: the rest of a split decode (the library's second stream)."""
     buf = (ctypes.c_float * cap)()
-    n = _lib.load().smm_dp_timing_read(buf, cap)
+    tags = (ctypes.c_int32 * cap)()
+    n = _lib.load().smm_dp_timing_read_tagged(buf, tags, cap)
+    if tagged:
+        return [(float(buf[i]), int(tags[i])) for i in range(min(n, cap))]
     return [float(buf[i]) for i in range(min(n, cap))]
+
+
+def reload_env():
+    """Make the library read its SMM_* tuning switches again (it reads them once, at first use)."""
+    _lib.reload_env()
+
+
+def release_cached_plans():
+    """smm_release_cached_plans(): frees the library's resident plans, second streams and pooled events; returns the
+    device bytes given back.  Only when no call is in flight and no captured graph of a call will be replayed."""
+    torch.cuda.synchronize()
+    return int(_lib.load().smm_release_cached_plans())
+
+
+def cached_plan_bytes():
+    return int(_lib.load().smm_cached_plan_bytes())

@@ -22,7 +22,8 @@
  *   - Plain C, no exceptions; every function returns SMM_OK (0) or a negative smm_status.
  *   - "dev" pointers are HIP device pointers owned by the caller; "host" pointers are small per-video /
  *     per-group metadata arrays in ordinary host memory (the library stages them itself; they may be reused
- *     as soon as the call returns).  The library allocates nothing and keeps no state between calls.
+ *     as soon as the call returns).  Results never depend on earlier calls.  What the library keeps between calls is
+ *     listed under "State" below; nothing else is allocated or retained.
  *   - All work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream); no call
  *     synchronises.  Distinct streams may be used from distinct threads.
  *   - A "group" is a parameter set (one CrossTask task: its valid classes, transition/init/length tables).
@@ -35,6 +36,13 @@
  *     class_map[g][c_max + 1] int64: local state -> global class id, entry n_states[g] = EOS id (n_classes).
  *   - Per-video kp[i] = min(K, Tmax of the video's reference batch) reproduces modules:450-452 (NULL: min(k_rows, t_max)).
  *   - endpen[i][c_max] fp64 (dev, nullable): 0 for allowed end states, -1e9 otherwise (modules:462-471).
+ *
+ * State (all of it released by smm_release_cached_plans(); none of it changes a result)
+ *   - resident plans: the staged, immutable metadata of a call whose inputs have been seen twice, in library-owned device
+ *     memory (at most 64 MB per process; the entry points that take lengths_host / frame_offset_host stage through it);
+ *   - one low-priority stream per device for smm_decode_f32's split decode, and pooled events around it;
+ *   - the SMM_* tuning switches, read from the environment once, at first use (smm_env_reload() reads them again);
+ *   - smm_dp_timing_*: the event pairs of the measurement aid while it is enabled.
  */
 #ifndef SMMDP_H
 #define SMMDP_H
@@ -92,13 +100,9 @@ int smm_device_count(void);
 size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 
 /* Byte offset, inside the workspace, of the int32 error word the kernels set.  1: a NaN / inf-inf reached the DP of
- * some video and its decode stopped early.  (Gangs -- videos decoded by two or three workgroups on as many CUs, long
- * videos at K > 512; environment SMM_PAIRS=0 disables them -- that give up waiting for a partner workgroup are
- * counted in the next word, see below.)
- * It is cleared at the start of every call.  Returns 0 on invalid shape.
- * The two int32 words behind it count gang time-outs and gang time-outs REPAIRED: a video whose gang gave up is decoded
- * again without a gang by a follow-up kernel of the same call (same stream, no host involvement), so the outputs are
- * invalid only if word[1] > word[2]. */
+ * some video and its decode stopped early.  It is cleared at the start of every call.  Returns 0 on invalid shape.
+ * (The two int32 words behind it are always 0: rounds 1-3 counted the time-outs of multi-workgroup "gangs" there, which
+ * no longer exist; the fourth word is a diagnostic of the Viterbi kernel's BAND mode.) */
 size_t smm_error_word_offset(const smm_shape *shape);
 
 /*
@@ -111,6 +115,23 @@ size_t smm_error_word_offset(const smm_shape *shape);
  */
 void smm_dp_timing_enable(int on);
 int smm_dp_timing_read(float *ms, int cap);
+/* as smm_dp_timing_read, plus which launch each one was: tags[i] = 0 the only DP launch of its call, 1 the launch of the
+ * critical (longest) videos of a split smm_decode_f32 on the caller's stream, 2 the rest of that call on the library's
+ * second stream (either array may be NULL) */
+int smm_dp_timing_read_tagged(float *ms, int32_t *tags, int cap);
+
+/*
+ * Library state (see "State" above).  smm_release_cached_plans frees every resident plan (all devices), the split
+ * decode's second streams and all pooled events, and returns the device bytes it gave back.  The caller's promise: no
+ * libsmmdp call is in flight on any stream, and no hipGraph captured from a call will be replayed afterwards (a captured
+ * call points at its plan's buffer).  smm_cached_plan_bytes: device bytes currently held by resident plans.
+ * smm_env_reload: read the SMM_* tuning switches from the environment again (they are read once, at first use:
+ * SMM_SPEC, SMM_NO_SPLIT, SMM_SPLIT_MIN_US / _NS / _MARGIN, SMM_PLAN_CACHE, SMM_NO_BT_WINDOW, SMM_FIT_GRID, SMM_VERBOSE --
+ * none of them changes a result; switches that do exist only in -DSMM_DEV builds of the library).
+ */
+size_t smm_release_cached_plans(void);
+size_t smm_cached_plan_bytes(void);
+void smm_env_reload(void);
 
 /*
  * Emission scorer.  elp[t][c] = cst[g][c] + sum_d x[t][d]*w[g][c][d] - 0.5*sum_d x[t][d]^2*inv_var[d] (+ cons[t][c])

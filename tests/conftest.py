@@ -36,3 +36,25 @@ def golden():
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _smm_switches_follow_the_environment(monkeypatch):
+    """libsmmdp reads its SMM_* tuning switches once, at first use (include/smmdp.h: smm_env_reload); tests flip them
+    inside one process with monkeypatch.setenv / delenv, so every change is followed by a reload -- and every test
+    starts from the environment as it is (the previous test's changes have been undone by then)."""
+    from action_segmentation_amd import _lib
+    _lib.reload_env()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith('SMM_'):
+            _lib.reload_env()
+
+    def delenv_and_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith('SMM_'):
+            _lib.reload_env()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload
+    yield

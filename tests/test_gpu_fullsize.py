@@ -87,7 +87,7 @@ def check_equivalent(cp, out, spans, v, elp, lengths, off):
 
 
 def test_cfg1_one_long_video():
-    """BASELINE configs[0]: one video, T = 10 000, 20 states, K = 1024, D = 200 (a gang of three CUs)."""
+    """BASELINE configs[0]: one video, T = 10 000, 20 states, K = 1024, D = 200 (one workgroup, BAND mode)."""
     cp = make_corpus(1, [10000], 20, 1024)
     res = decode_both(cp)
     check_equivalent(cp, *res)
@@ -104,19 +104,20 @@ def test_cfg2_batch_of_64():
 
 @pytest.mark.parametrize('c', [23, 21, 15])
 def test_cfg3_longest_videos(c):
-    """BASELINE configs[2] at its extremes: T = 14 000 (cumE ~ 4e6), K = 1024, 23 states (always a gang), 21 (the most one
-    workgroup holds) and 15, next to shorter videos of the same task in one ragged launch."""
+    """BASELINE configs[2] at its extremes: T = 14 000 (cumE ~ 4e6), K = 1024, 23 states (CrossTask's largest task), 21
+    and 15, next to shorter videos of the same task in one ragged launch."""
     cp = make_corpus(30 + c, [14000, 9000, 14000, 600, 3000], c, 1024)
     res = decode_both(cp)
     check_equivalent(cp, *res)
 
 
-def test_cfg3_gangs_and_singles_agree(monkeypatch):
-    """The same ragged launch with gangs switched off decodes to the same bits."""
+def test_cfg3_with_and_without_the_speculative_transition_agree(monkeypatch):
+    """The same ragged launch with the chain wave's speculative transition switched off decodes to the same bits."""
     from action_segmentation_amd import ops
     cp = make_corpus(77, [14000, 12000, 5000], 19, 1024)
+    monkeypatch.delenv('SMM_SPEC', raising=False)
     a = decode_both(cp)
-    monkeypatch.setenv('SMM_PAIRS', '0')
+    monkeypatch.setenv('SMM_SPEC', '0')
     b = decode_both(cp)
     np.testing.assert_array_equal(a[0]['spans'].cpu().numpy(), b[0]['spans'].cpu().numpy())
     np.testing.assert_array_equal(a[0]['best'].cpu().numpy(), b[0]['best'].cpu().numpy())
@@ -248,7 +249,7 @@ def test_cfg3_shape_log_partition_and_gradients(c):
 
 def test_cfg3_whole_corpus_one_ragged_launch_equals_the_twin():
     """BASELINE configs[2] as bench.py decodes it: the cfg3 seed-2 corpus (18 tasks x 20 videos, 11..23 states, T up to
-    14 000, K = 1024) in ONE ragged launch -- gangs, singles and all -- against the C twin, every frame of every video."""
+    14 000, K = 1024) in ONE ragged launch against the C twin, every frame of every video."""
     import bench
     from action_segmentation_amd import synth
     from action_segmentation_amd.semimarkov import SemiMarkovModel

@@ -1,5 +1,5 @@
 """The decode path enqueues on the caller's stream and never waits for it (metadata travels in kernel arguments): a
-whole decode -- metadata uploads, emission kernel, DP kernel with gangs, recovery launches -- must capture into a
+whole decode -- metadata uploads, band tables, emission kernel, DP kernel -- must capture into a
 hipGraph and replay bit-identically, also after the features changed in place (include/smmdp.h: stream-async,
 caller-owned buffers)."""
 import numpy as np
@@ -17,9 +17,9 @@ def test_decode_captures_into_a_hip_graph_and_replays_bit_exactly(shape, monkeyp
     from action_segmentation_amd import ops
     lengths, c, k = shape
     if len(lengths) > 24:
-        # a SPLIT decode (smm_api.hip: choose_split): the two longest videos on the caller's stream, the other thirty
-        # scored and decoded on the library's second stream beside them -- forked and joined with events, which the
-        # capture has to follow
+        # eager: a SPLIT decode (smm_api.hip: choose_split): the two longest videos on the caller's stream, the other thirty
+        # scored and decoded on the library's second stream beside them.  Under capture the same call does NOT split (the
+        # shared second stream must not be pulled into somebody's capture): one launch pair, same bits
         monkeypatch.setenv('SMM_SPLIT_MIN_US', '0')
     cp = make_corpus(31, lengths, c, k, d=64, rate=(10, 120))
     dev = torch.device('cuda:0')

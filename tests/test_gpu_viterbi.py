@@ -92,36 +92,31 @@ def test_viterbi_bit_exact_vs_factored_oracle(shape, ends):
     check(p, out, spans, v)
 
 
-PAIR_SHAPES = [
-    # b, tmax, c, k: 1024-slot rings (kp > 512); every video forced onto two CUs (leader + follower workgroups)
+LONG_SHAPES = [
+    # b, tmax, c, k: kp > 512 (BAND mode: 128-slot rings shared by nine length bands, one workgroup per video)
     (2, 1500, 21, 1024), (3, 1100, 11, 1024), (2, 700, 16, 600), (2, 2100, 5, 1024), (1, 3000, 20, 1024),
     (4, 640, 4, 1024), (2, 1300, 17, 520), (2, 1200, 23, 1024), (3, 900, 22, 700),
 ]
 
 
-@pytest.mark.parametrize('shape', PAIR_SHAPES)
+@pytest.mark.parametrize('shape', LONG_SHAPES)
 @pytest.mark.parametrize('ends', [False, True])
-def test_viterbi_pair_mode_bit_exact(shape, ends, monkeypatch):
-    """The two-CU split of a video (short / long segment-length ranges, progress counters through HBM) must not
-    change a bit: same oracle, same checks as the one-workgroup path."""
+def test_viterbi_long_segment_lengths_bit_exact(shape, ends):
+    """K > 512 on random (unstructured) lattices, where hardly a band can be skipped and no leader ever holds: same oracle,
+    same checks as the short rings."""
     b, tmax, c, k = shape
-    monkeypatch.setenv('SMM_PAIRS', str(b))
     p = make_problem(hash(shape) % 1000 + 3, b, tmax, c, k, ends=ends)
     out = run_gpu(p)
     spans, v = run_oracle(p)
     check(p, out, spans, v)
 
 
-def test_viterbi_pair_mode_mixed_grid(monkeypatch):
-    """Pairs in front of the grid, single workgroups behind them, one launch; a paired video shorter than 64 frames."""
-    shape = (5, 1400, 13, 1024)
-    b, tmax, c, k = shape
-    monkeypatch.setenv('SMM_PAIRS', '2')
-    p = make_problem(77, b, tmax, c, k, ends=True)
+def test_viterbi_long_segment_lengths_ragged_grid():
+    """K > 512, ragged: long videos next to one shorter than a ring, and one shorter than 64 frames."""
+    p = make_problem(77, 5, 1400, 13, 1024, ends=True)
     out = run_gpu(p)
     spans, v = run_oracle(p)
     check(p, out, spans, v)
-    monkeypatch.setenv('SMM_PAIRS', '2')
     p = make_problem(78, 2, 1200, 9, 1024, ends=False, min_len=1)
     p['lengths'][1] = 40
     out = run_gpu(p)
@@ -144,16 +139,14 @@ def _rescore(p, i, spans_row):
     return total
 
 
-@pytest.mark.parametrize('shape,pairs', [((2, 10000, 20, 1024), None), ((2, 10000, 20, 1024), '0'), ((3, 14000, 21, 1024), None),
-                                         ((64, 2048, 16, 256), None)])
-def test_full_size_bit_exact_and_properties(shape, pairs, monkeypatch):
+@pytest.mark.parametrize('shape', [(2, 10000, 20, 1024), (3, 14000, 21, 1024), (64, 2048, 16, 256)])
+def test_full_size_bit_exact_and_properties(shape, monkeypatch):
     """BASELINE.json's shapes at full size (cfg1: T = 10 000, 20 states, L = 1024; cfg3's longest: T = 14 000, 21 states;
     cfg2: 64 x 2048, 16 states, L = 256): bit-exact against the C twin (a fraction of a second per video), plus
     properties that do not need an oracle -- the decoded path re-scores to the reported optimum, labels and spans
-    agree, a second run and the one-CU / two-CU splits give identical bits."""
+    agree, a second run and a run without the speculative transition (SMM_SPEC=0) give identical bits."""
     b, tmax, c, k = shape
-    if pairs is not None:
-        monkeypatch.setenv('SMM_PAIRS', pairs)
+    monkeypatch.delenv('SMM_SPEC', raising=False)
     p = make_problem(hash(shape) % 1000 + 17, b, tmax, c, k, ends=True, scale=1.5)
     out = run_gpu(p)
     spans, v = run_oracle(p)
@@ -163,16 +156,15 @@ def test_full_size_bit_exact_and_properties(shape, pairs, monkeypatch):
     again = run_gpu(p)
     for key in ('best', 'spans', 'labels', 'n_segs'):
         np.testing.assert_array_equal(out[key], again[key])
-    if k > 512:
-        monkeypatch.setenv('SMM_PAIRS', '0' if pairs is None else str(b))
-        other = run_gpu(p)
-        for key in ('best', 'spans', 'labels', 'n_segs'):
-            np.testing.assert_array_equal(out[key], other[key])
+    monkeypatch.setenv('SMM_SPEC', '0')
+    other = run_gpu(p)
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], other[key])
 
 
-def test_viterbi_22_23_states_ride_in_pairs():
-    """More than 21 states at K > 512 do not fit one 8-wave workgroup's registers: such videos are always decoded by a
-    leader / follower pair, next to single workgroups for the other tasks of the same launch (two parameter groups)."""
+def test_viterbi_22_23_states_next_to_smaller_tasks():
+    """CrossTask's largest tasks (22..23 states) at K > 512 next to a 13-state task in one launch (three parameter
+    groups): the kernel is chosen for the launch's largest class set, every video is checked against its own twin."""
     ops = _ops()
     dev = torch.device('cuda:0')
     k, cm = 1024, 23
@@ -525,11 +517,12 @@ def test_no_eos_needs_two_frames():
         ops.viterbi(ops.Batch([1, 5], [3], 4, t_max=5, total_frames=10, no_eos=True), z(10, 3), z(1, 3, 3), z(1, 3), z(1, 4, 3))
 
 
-@pytest.mark.parametrize('c', [24, 26, 28, 29, 31, 32])
-def test_viterbi_24_to_32_states_ride_in_triples(c, monkeypatch):
-    """24..32 states at K > 512 used to fall to the spilling 16-wave configuration (12-16x slower): a gang leader's short
-    rings hold every state and two followers split the long rings, so such videos are always triples now.  Bit-exact
-    against the C twin, next to a 13-state task on single workgroups, and identical to the spilling path (gangs off)."""
+@pytest.mark.parametrize('c', [24, 26, 28, 29, 30, 31, 32])
+def test_viterbi_24_to_32_states_in_band_mode(c, monkeypatch):
+    """24..32 states at K > 512: BAND mode with five (up to 30 states) or six states per pusher wave, on one CU like
+    everything else (rounds 2-3 ran them as gangs of three workgroups).  Bit-exact against the C twin, next to a 13-state
+    task of the same launch, and identical without the speculative transition."""
+    monkeypatch.delenv('SMM_SPEC', raising=False)
     ops = _ops()
     dev = torch.device('cuda:0')
     k, cm = 1024, c
@@ -556,7 +549,8 @@ def test_viterbi_24_to_32_states_ride_in_triples(c, monkeypatch):
         spans, v = F.viterbi(elp[i:i + 1, :, :cc], lengths[i:i + 1], tabs[g]['trans'][:cc, :cc], tabs[g]['init'][:cc],
                              tabs[g]['lens'][:, :cc], endpen[i:i + 1, :cc])
         assert got['best'][i] == v[0]
-    monkeypatch.setenv('SMM_PAIRS', '0')                            # gangs off: the spilling configuration
+        np.testing.assert_array_equal(got['spans'][i], spans[0])
+    monkeypatch.setenv('SMM_SPEC', '0')
     slow = ops.viterbi(batch, *args)
     torch.cuda.synchronize()
     for key in ('best', 'spans', 'labels', 'n_segs'):
@@ -621,15 +615,14 @@ BAND_SHAPES = [
 @pytest.mark.parametrize('shape', BAND_SHAPES)
 @pytest.mark.parametrize('kind', ['random', 'structured', 'integer', 'flat'])
 def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
-    """K > 512, up to 28 states: the BAND kernel (128-slot rings shared by nine length bands, delayed bands skipped by an
-    exact bound test) against the C twin AND against the 1024-slot ring kernels (SMM_BAND=0), bit for bit -- on random
+    """K > 512: the BAND kernel (128-slot rings shared by nine length bands, delayed bands skipped by an exact bound test)
+    against the C twin, with and without the chain wave's speculative transition (SMM_SPEC=0), bit for bit -- on random
     lattices, on CrossTask-like lattices (nearly every delayed band is skipped), on integer lattices full of exact ties
     (a skipped candidate may TIE with the maximum, never beat it) and on FLAT lattices (every state emits the same, so no
     state ever falls behind and hardly a band can be skipped: the worst case of the test's cost, not of its result)."""
     lengths, c, k = shape
     ops = _ops()
-    monkeypatch.delenv('SMM_PAIRS', raising=False)
-    monkeypatch.delenv('SMM_BAND', raising=False)
+    monkeypatch.delenv('SMM_SPEC', raising=False)
     if kind == 'structured':
         p = structured_problem(hash((tuple(lengths), c)) % 1000, lengths, c, k)
     else:
@@ -659,11 +652,10 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         assert frac < 0.12, frac                       # (long videos: ~1-3 %; the first 1000 frames of a video cost the most)
     elif kind == 'flat':
         assert frac > 0.5, frac
-    monkeypatch.setenv('SMM_BAND', '0')
-    ring = run_gpu(p)
-    assert ring['_err'][3] == 0
+    monkeypatch.setenv('SMM_SPEC', '0')
+    full = run_gpu(p)
     for key in ('best', 'spans', 'labels', 'n_segs'):
-        np.testing.assert_array_equal(out[key], ring[key])
+        np.testing.assert_array_equal(out[key], full[key])
 
 
 def masked_problem(seed, lengths, c, k, neg_inf=False):
@@ -727,12 +719,12 @@ MASKED_BAND_SHAPES = [
 def test_viterbi_band_mode_masked_lattices(shape, neg_inf, monkeypatch):
     """BAND mode on the lattices of the reference's constrained path: transitions / initial scores / ends masked at -1e9
     before the softmax (or at true -inf), -1e4 narration penalties in the emissions.  The band skip test compares bounds
-    built from maxima of h, and h now jumps by 1e4..1e9 between neighbouring sources: bit-exact against the C twin and
-    against the 1024-slot rings (SMM_BAND=0), with the best path's score finite (the chain explains every video, through
-    penalties where it must)."""
+    built from maxima of h, and h now jumps by 1e4..1e9 between neighbouring sources; the speculative transition's check
+    (every other source loses against the leader at EVERY target) can hardly ever hold on a masked table: bit-exact
+    against the C twin, with and without it (SMM_SPEC=0), with the best path's score finite (the chain explains every
+    video, through penalties where it must)."""
     lengths, c, k = shape
-    monkeypatch.delenv('SMM_PAIRS', raising=False)
-    monkeypatch.delenv('SMM_BAND', raising=False)
+    monkeypatch.delenv('SMM_SPEC', raising=False)
     p = masked_problem(hash((tuple(lengths), c, k)) % 1000 + 11, lengths, c, k, neg_inf=neg_inf)
     out = run_gpu(p)
     spans, v = run_oracle(p)
@@ -741,11 +733,11 @@ def test_viterbi_band_mode_masked_lattices(shape, neg_inf, monkeypatch):
         assert np.all(v[::2] > -400.0 * np.asarray(lengths[::2]))   # one pass through the chain: no penalty is paid (~ -290 per frame)
     check(p, out, spans, v)
     assert out['_err'][0] == 0
-    monkeypatch.setenv('SMM_BAND', '0')
-    ring = run_gpu(p)
-    assert ring['_err'][3] == 0
+    monkeypatch.setenv('SMM_SPEC', '0')
+    full = run_gpu(p)
     for key in ('best', 'spans', 'labels', 'n_segs'):
-        np.testing.assert_array_equal(out[key], ring[key])
+        np.testing.assert_array_equal(out[key], full[key])
+    assert full['_err'][3] == out['_err'][3]            # (the band decisions do not depend on how the transition is folded)
 
 
 @pytest.mark.parametrize('first', [127, 128, 129, 239, 240, 241, 600, 1023])
@@ -755,8 +747,6 @@ def test_viterbi_band_mode_first_segment_from_position_zero(first, monkeypatch):
     decided on the initial scores alone.  One long first segment of exactly `first` frames on either side of every band
     boundary (128 = band 1's first length, 240 = band 2's), then ordinary segments."""
     ops = _ops()
-    monkeypatch.delenv('SMM_PAIRS', raising=False)
-    monkeypatch.delenv('SMM_BAND', raising=False)
     from scipy.special import gammaln
     g = np.random.default_rng(first)
     c, k, t = 7, 1024, 1400
@@ -813,7 +803,6 @@ def test_dp_timing_diagnostic():
 def test_viterbi_band_mode_no_eos_and_end_penalties(monkeypatch):
     """The two closing variants on the BAND kernel: add_eos=False, and per-video allowed ends."""
     ops = _ops()
-    monkeypatch.delenv('SMM_PAIRS', raising=False)
     p = structured_problem(7, [2200, 1300], 19, 1024)
     dev = torch.device('cuda:0')
     b, tmax, c = p['elp'].shape
@@ -834,31 +823,42 @@ def test_viterbi_band_mode_no_eos_and_end_penalties(monkeypatch):
     check(p, got, spans, v)
 
 
-# ---------------------------------------------------------------------------------------------------- gang recovery
-@pytest.mark.parametrize('c', [13, 23, 26, 31])
-def test_gang_timeout_is_repaired_in_the_same_call(c, monkeypatch):
-    """A gang whose follower workgroups never become resident (test hook: SmmDpArgs::flags bit 5 -- gang 0's followers
-    return at once and the leader's waits are short) gives up, flags itself, and the recovery launch behind the main
-    kernel decodes its video again on one CU: bit-exact output, no exception, the repair is counted."""
-    ops = _ops()
-    shape = (4, 1500, c, 1024)
-    b, tmax, _, k = shape
-    p = make_problem(91 + c, b, tmax, c, k, ends=True)
-    monkeypatch.setenv('SMM_PAIRS', '3')
-    monkeypatch.setenv('SMM_DEBUG_FLAGS', '32')
-    before = ops.gang_timeouts_repaired
-    dev = torch.device('cuda:0')
-    batch = ops.Batch(p['lengths'], [c], k, c_max=c, t_max=tmax, total_frames=b * tmax)
-    t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
-    out = ops.viterbi(batch, t(p['elp'].reshape(b * tmax, c)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]),
-                      t(p['endpen']))
-    torch.cuda.synchronize()
-    words = ops.error_words(batch, out)
-    assert words[0] == 0 and words[1] >= 1 and words[1] == words[2], words
-    ops.check_decoded(batch, out)                                   # does not raise
-    assert ops.gang_timeouts_repaired == before + words[2]
+# ---------------------------------------------------------------------------------------------------- library state
+def test_result_changing_debug_switches_do_not_exist_in_the_product_build(monkeypatch):
+    """SMM_DEBUG_FLAGS (bit 0: stop after the forward pass, outputs undefined), SMM_SPLIT_DEBUG (parts of a split decode
+    left out) and SMM_UPLOAD_MEMCPY are development aids of -DSMM_DEV builds; the shipped library does not know them:
+    with all of them set, a decode is still the twin's."""
+    p = make_problem(5, 3, 400, 7, 40, ends=True)
+    for name, val in (('SMM_DEBUG_FLAGS', '1'), ('SMM_SPLIT_DEBUG', '3'), ('SMM_UPLOAD_MEMCPY', '1'), ('SMM_EMISSION_V2', '1')):
+        monkeypatch.setenv(name, val)
+    out = run_gpu(p)
     spans, v = run_oracle(p)
-    check(p, {k_: v_.cpu().numpy() for k_, v_ in out.items() if k_ in ('best', 'spans', 'labels', 'n_segs')}, spans, v)
+    check(p, out, spans, v)
+    p = structured_problem(9, [1500, 900], 12, 1024)
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+
+
+def test_release_cached_plans_gives_the_device_memory_back():
+    """The library keeps staged calls resident (admitted at the second sighting of their inputs) until
+    smm_release_cached_plans(): bytes held go up with a repeated call, back to zero on release, and the next decode is
+    staged afresh and still right."""
+    ops = _ops()
+    ops.release_cached_plans()
+    assert ops.cached_plan_bytes() == 0
+    p = make_problem(31, 3, 200, 6, 30)
+    spans, v = run_oracle(p)
+    check(p, run_gpu(p), spans, v)
+    assert ops.cached_plan_bytes() == 0                    # seen once: not admitted
+    check(p, run_gpu(p), spans, v)
+    held = ops.cached_plan_bytes()
+    assert held > 0                                         # seen twice: resident
+    check(p, run_gpu(p), spans, v)
+    assert ops.cached_plan_bytes() == held
+    assert ops.release_cached_plans() == held               # (bytes whose hipFree succeeded)
+    assert ops.cached_plan_bytes() == 0
+    check(p, run_gpu(p), spans, v)
 
 
 @pytest.mark.parametrize('shape', [(3, 40, 6, 8), (2, 300, 17, 130), (4, 70, 5, 20), (2, 1030, 21, 1024)])

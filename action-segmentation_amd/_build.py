@@ -68,3 +68,41 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+def kernel_resources(lib=LIB):
+    """{kernel name: {'private_segment_fixed_size', 'vgpr_count', 'vgpr_spill_count', 'group_segment_fixed_size'}} of every gfx950
+    kernel inside the shared library: the code objects are cut out of the clang offload bundles of its .hip_fatbin section
+    and their metadata notes read with llvm-readelf.  Used by the no-scratch check (tests/test_module_host.py): a DP kernel
+    with a private segment -- a single spilled register -- is dispatched measurably slower beside another kernel
+    (round 4: +0.3 ms on the critical launch of a split decode), so none may have one."""
+    import re
+    import struct
+    import tempfile
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    blob = open(lib, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = {}
+    pos = blob.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", blob, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "amdgcn" not in triple or size == 0:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(blob[pos + off:pos + off + size])
+                f.flush()
+                notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+            for block in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block)
+                if not name:
+                    continue
+                out[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                                      for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "group_segment_fixed_size")
+                                      if re.search(r"\.%s:\s+(\d+)" % k, block)}
+        pos = blob.find(magic, pos + len(magic))
+    return out

@@ -288,7 +288,10 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
     const int thr = tmax - (int)(em_us * 1000.0 / ev.split_ns) - ev.split_margin;
     int n1 = 0;
     for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
-    if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16) return 0;
+    // ... and only a launch that is bound by its longest videos: with more than two rounds of workgroups the DP is bound by
+    // CU-time and the split only adds a second launch (scripts/sweep_split.py, round 4: 1000 videos of ~2000 frames lost
+    // 3.8 % with it; every latency-bound distribution won 5..10 % or stayed level)
+    if (thr <= 0 || n1 < 1 || n1 > b / 3 || n1 > n_cu / 2 || b - n1 < 16 || b > 2 * n_cu) return 0;
     std::stable_partition(order, order + b, [&](int32_t v) { return hv[v].T >= thr; });
     return n1;
 }
@@ -606,11 +609,11 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     return SMM_OK;
 }
 
-// Viterbi at K > 512: BAND mode (smm_viterbi.hip), up to SMM_MAX_STATES states on one CU
+// Viterbi at K > 512: BAND mode (smm_viterbi.hip), up to SMM_MAX_STATES states on one CU; also 29..32 states at K > 256
+// (the 512-slot rings of five states per pusher wave do not fit the registers)
 static bool band_mode(int kp_max, int c_need)
 {
-    (void)c_need;
-    return kp_max > 512;
+    return kp_max > 512 || (kp_max > 256 && c_need > 28);
 }
 
 static int ring_regs(int kp_max)
@@ -734,7 +737,7 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     if (!launch) { SMM_HIP(hipGetLastError()); return SMM_OK; }      // (prep only)
     std::pair<hipEvent_t, hipEvent_t> tev;
     const bool timed = dp_timing_begin(stream, tev);
-    const int rc = smm_launch_viterbi(a, ring_regs(st.kp_max), st.c_need, stream);
+    const int rc = smm_launch_viterbi(a, st.band_mode ? 16 : ring_regs(st.kp_max), st.c_need, stream);
     if (timed) dp_timing_end(stream, tev, timing_tag);
     if (rc != SMM_OK) return rc;
     SMM_HIP(hipGetLastError());

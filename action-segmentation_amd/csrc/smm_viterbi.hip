@@ -84,8 +84,11 @@
 // release + barrier + acquire, i.e. s_waitcnt vmcnt(0) in front of every s_barrier: the mover wave then stalls once per
 // block until the elp rows it has just asked for (two blocks ahead, on purpose) have arrived from HBM, and seven waves
 // wait for it.  Global data that does change hands inside the workgroup is ordered otherwise: the history rows the
-// delayed bands read were stored >= 27 blocks earlier by a wave that has since waited for YOUNGER loads (vmcnt counts in
-// issue order), and the back-trace starts behind real __syncthreads().
+// delayed bands read (agent-scope loads, two blocks ahead of their pushes) were stored by the mover wave at least
+// (SMM_BAND_DELAY - 2B) / B - 1 = 11 block steps earlier (blocks of B = 8 positions, delay 112: see the static_assert in
+// the kernel), and the mover has since waited, in EVERY one of those steps, for the elp loads it issued a step before --
+// loads YOUNGER than the stores, and vmcnt retires a wave's vector-memory operations in issue order: the stores of step s
+// are through before the mover leaves step s + 2.  The back-trace starts behind real __syncthreads().
 __device__ __forceinline__ void smm_lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -110,6 +113,9 @@ __device__ __forceinline__ void smm_lds_barrier()
 #endif
 #ifndef SMM_SPEC
 #define SMM_SPEC 1       // the chain wave's speculative transition (see SPEC in the kernel); 0: compiled out (A/B aid)
+#endif
+#ifndef SMM_PIPE0_ALWAYS
+#define SMM_PIPE0_ALWAYS 0
 #endif
 #ifndef SMM_B8_R
 #define SMM_B8_R 4       // blocks of 8 positions for the 256-slot rings (round 3, same box: cfg2 DP 0.481 -> 0.456 ms; the 64-slot
@@ -166,7 +172,7 @@ __device__ __forceinline__ void smm_ring_block(double (&A)[R], double (&L)[R], d
     constexpr int RING = 64 * R;
     double hv[B];
 #pragma unroll
-    for (int i = 0; i < B; ++i) hv[i] = h_blk[i * SMM_MAX_STATES_DEV];
+    for (int i = 0; i < B; ++i) hv[i] = h_blk[i * 2 * SMM_MAX_STATES_DEV];      // (h_blk: the h half of sh_gh's (gamma, h) pairs)
     if constexpr (D == 1) {
         smm_push<R>(A, L, hd, (jj * B) % R);
 #pragma unroll
@@ -341,6 +347,17 @@ smm_viterbi_kernel(SmmDpArgs a)
     constexpr int UB = (R / B) > 2 ? (R / B) : 2;          // blocks per unrolled pusher iteration (UB*B % R == 0, UB even)
     constexpr int M = (D ? 4 : 2) * B;                     // chain wave: h[n] of the last M > K0 positions, slot n mod M
     constexpr int MW = (NW >= 8) ? 4 : 1;                  // the wave that moves HBM traffic (shares the chain wave's SIMD)
+    constexpr int SN = (HF == 4) ? 16 : 2 * HF;            // states the kernel's launches hold at most
+#ifdef SMM_DIAG_V255
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");      // (diagnostic: the kernel allocates all 256 VGPRs)
+#endif
+#ifdef SMM_DIAG_SCRATCH
+    {   // (diagnostic: the kernel needs a private segment)
+        volatile int junk_[8];
+        junk_[threadIdx.x & 7] = (int)threadIdx.x;
+        if (junk_[(threadIdx.x + 1) & 7] == 123456789) a.err[5] = 1;
+    }
+#endif
     const int vid = a.order[blockIdx.x];
     SmmVideo mv = a.videos[vid];
     if (a.flags & 8) mv.T -= 1;               // no EOS: the DP covers the frames before the last one (smmdp.h)
@@ -369,18 +386,21 @@ smm_viterbi_kernel(SmmDpArgs a)
 
     // block q = positions qB+1 .. (q+1)B, buffer q & 1
     __shared__ __attribute__((aligned(16))) double sh_apart[2][B][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
-    __shared__ __attribute__((aligned(16))) double sh_h[2][B][SMM_MAX_STATES_DEV];       // h[n][c]    chain -> pushers, HBM
-    __shared__ __attribute__((aligned(16))) double sh_cum[2][B][SMM_MAX_STATES_DEV];     // cumE[n][c] chain -> HBM
-    __shared__ __attribute__((aligned(16))) double sh_g[2][B][SMM_MAX_STATES_DEV];       // gamma[n][c] chain -> HBM
+    // (gamma[n][c], h[n][c]) pairs: ONE 16-byte store per position by the chain wave (LDS instructions are what its fast
+    // positions are made of: round 4 measured ~40 cycles of the wave's time per ds_write_b64 on a CU whose other seven waves
+    // use the LDS too); h -> pushers and HBM, gamma -> HBM.  cumE never goes through LDS: the mover wave adds up the elp
+    // rows it staged itself -- the same additions in the same order, hence the same bits.
+    __shared__ __attribute__((aligned(16))) double sh_gh[2][B][SMM_MAX_STATES_DEV][2];
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
-    __shared__ double sh_hm[BAND ? SMM_MAX_STATES_DEV : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
+    __shared__ double sh_hm[BAND ? SN : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
-    __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV];    // where the chain wave's upper half stores
+    __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV][2]; // where the chain wave's other lane groups store
     // speculative transition (see SPEC in the chain wave): the video's transition table and, per (leader cs, source c),
     // how far gamma[c] must lie below gamma[cs] for source c to lose against cs at EVERY target
-    __shared__ double sh_tr[SMM_SPEC ? SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV : 1];     // [to][from]
-    __shared__ double sh_dl[SMM_SPEC ? SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV : 1];     // [cs][c]
+    // (as small as the kernel's class sets allow)
+    __shared__ double sh_tr[SMM_SPEC ? SN * SN : 1];                                     // [to][from]
+    __shared__ double sh_dl[SMM_SPEC ? SN * SN : 1];                                     // [cs][c]
     __shared__ unsigned sh_kmin[3];
     __shared__ int sh_c;
     __shared__ int sh_guess[SMM_MAX_STATES_DEV + 1];   // back-trace: the predecessor state last seen / expected for each state
@@ -394,8 +414,9 @@ smm_viterbi_kernel(SmmDpArgs a)
         for (int i = 0; i < B; ++i) {
             sh_apart[0][i][c] = SMM_NEG_INF;              // block 0 needs no pusher source
             sh_apart[1][i][c] = SMM_NEG_INF;
-            sh_h[0][i][c] = SMM_NEG_INF;
-            sh_h[1][i][c] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
+            sh_gh[0][i][c][0] = SMM_NEG_INF; sh_gh[0][i][c][1] = SMM_NEG_INF;
+            sh_gh[1][i][c][0] = SMM_NEG_INF;
+            sh_gh[1][i][c][1] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
         }
@@ -408,8 +429,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
     constexpr bool SPEC = SMM_SPEC != 0;
     if constexpr (SPEC) {
-        for (int e = threadIdx.x; e < SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV; e += blockDim.x) {
-            const int to = e / SMM_MAX_STATES_DEV, f = e % SMM_MAX_STATES_DEV;
+        for (int e = threadIdx.x; e < SN * SN; e += blockDim.x) {
+            const int to = e / SN, f = e % SN;
             sh_tr[e] = (to < C && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
         }
     }
@@ -420,12 +441,12 @@ smm_viterbi_kernel(SmmDpArgs a)
         // gamma[cs] + trans[to][cs] in real arithmetic for every target, hence -- rounding is monotone -- for the rounded
         // sums the fold compares.  A target that source c cannot reach (-inf) asks for nothing; one that only cs cannot
         // reach can never be granted (-inf).
-        for (int e = threadIdx.x; e < SMM_MAX_STATES_DEV * SMM_MAX_STATES_DEV; e += blockDim.x) {
-            const int cs = e / SMM_MAX_STATES_DEV, c = e % SMM_MAX_STATES_DEV;
+        for (int e = threadIdx.x; e < SN * SN; e += blockDim.x) {
+            const int cs = e / SN, c = e % SN;
             double d = 0.0;
             if (cs < C && c < C) {
                 for (int to = 0; to < C; ++to) {
-                    const double x = sh_tr[to * SMM_MAX_STATES_DEV + cs], y = sh_tr[to * SMM_MAX_STATES_DEV + c];
+                    const double x = sh_tr[to * SN + cs], y = sh_tr[to * SN + c];
                     if (y == SMM_NEG_INF) continue;
                     d = fmin(d, x - y);
                 }
@@ -433,8 +454,8 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
             sh_dl[e] = d;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     // The chain wave touches LDS only (a wave that waits for a load waits for its older stores as well: vmcnt is one
     // in-order counter).  HBM traffic is moved block-wise by pusher wave MW: it fetches the elp rows two blocks ahead
@@ -444,15 +465,87 @@ smm_viterbi_kernel(SmmDpArgs a)
     double ninf = SMM_NEG_INF;                             // kept in a register pair (smm_ring_block)
     asm volatile("" : "+v"(ninf));
     const int J = (T + B - 1) / B;                         // blocks; one barrier each, in every wave
+    // ---------------------------------------------------------------------------------------------- the mover's block step
+    // Wave MW (the chain wave's SIMD partner) moves the HBM traffic, block-wise.  In block j it
+    //   * reads the staged elp rows and the (gamma, h) rows of block j-1 from LDS: lane = (half, state), each half of the
+    //     wave takes half of the block's positions (B/2 16-byte reads + B 8-byte reads per lane, conflict-free);
+    //   * writes the elp rows of block j+1 (fetched a block ago) to LDS and fetches those of block j+2 -- unconditional
+    //     loads from clamped addresses (rows >= T are never used): a predicated load waits for the previous one into the
+    //     same register;
+    //   * adds the elp rows up (cumE[n] = cumE[n-1] + elp[n-1]: the chain wave's own additions, repeated) and stores
+    //     cumE, gamma (rows of C in HBM) and h (state-major in HBM: B/2 consecutive positions per lane);
+    //   * BAND mode: returns max h over the block's sources per state (lane = state, both halves), for the skip test.
+    constexpr int PB = B / 2;                              // positions per half of the mover wave
+    int mv_lo[NE];                                         // elp block element e = lane + 64 q  ->  LDS offset (row e / cm, column e % cm), -1: none
+    double mv_pre[NE], mv_cum = 0.0;
+    const int64_t e_last = (int64_t)T * cm - 1;
+    if (w == MW) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = lane + 64 * q;
+            mv_lo[q] = (e < B * cm) ? (e / cm) * SMM_MAX_STATES_DEV + e % cm : -1;
+            const int64_t eg = (int64_t)B * cm + e;                                // block 1
+            mv_pre[q] = elp[eg < e_last ? eg : e_last];
+        }
+    }
+    auto mover_step = [&](int j, int jj, bool prefetch) -> double {
+        const int mc = lane & (SMM_MAX_STATES_DEV - 1), mh = lane >> 5;
+        double ev[B];
+        double2 gh[PB];
+#pragma unroll
+        for (int i = 0; i < B; ++i) ev[i] = sh_e[(jj + 1) & 1][i][mc];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) gh[i] = *reinterpret_cast<const double2 *>(&sh_gh[(jj + 1) & 1][mh * PB + i][mc][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch) {
+            double *dst = &sh_e[(jj + 1) & 1][0][0];
+#pragma unroll
+            for (int q = 0; q < NE; ++q)
+                if (mv_lo[q] >= 0) dst[mv_lo[q]] = mv_pre[q];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
+                mv_pre[q] = elp[e < e_last ? e : e_last];
+            }
+        }
+        double cv[PB];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            mv_cum = mv_cum + ev[i];
+            if (i / PB == 0) { if (mh == 0) cv[i % PB] = mv_cum; }
+            else { if (mh == 1) cv[i % PB] = mv_cum; }
+        }
+        double hmax = gh[0].y;
+#pragma unroll
+        for (int i = 1; i < PB; ++i) hmax = smm_fmax(hmax, gh[i].y);
+        if (j >= 1 && mc < C) {
+            const int n0 = (j - 1) * B + 1 + mh * PB;                               // this lane's positions n0 .. n0 + PB - 1
+            double *hrow = hh + (size_t)mc * (T + 1) + n0;
+            if (n0 + PB - 1 <= T) {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    hcum[(size_t)(n0 + i) * C + mc] = cv[i];
+                    hgam[(size_t)(n0 + i) * C + mc] = gh[i].x;
+                    hrow[i] = gh[i].y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    if (n0 + i <= T) {
+                        hcum[(size_t)(n0 + i) * C + mc] = cv[i];
+                        hgam[(size_t)(n0 + i) * C + mc] = gh[i].x;
+                        hrow[i] = gh[i].y;
+                    }
+                }
+            }
+        }
+        return smm_max_halves(hmax);
+    };
     if (w == 0) {
         // ============================================================================ chain wave
         // The serial chain is the critical path of a block; its SIMD partner is a pusher wave with an endless
         // supply of independent fp64 work, so the chain wave takes priority in the issue arbitration.
         __builtin_amdgcn_s_setprio(3);
-#ifndef SMM_BAND_GAMROW
-#define SMM_BAND_GAMROW 0   // (same-box A/B at B = 8: the history row as broadcast row, one LDS store less per position, -2 %)
-#endif
-        constexpr bool GAMROW = BAND ? bool(SMM_BAND_GAMROW) : ((B > 4) || (R < 4));   // a separate gamma broadcast row (see the position loop)
         // The transition's fold is compiled for the launch's largest class set (HF source states per lane group) AND,
         // in BAND launches of more than 16 states, for <= 16 states (four lane groups of 16, four sources each): a
         // corpus mixes tasks of 11..23 states in one launch, and a video of 11 states need not fold 24 sources.
@@ -475,13 +568,11 @@ smm_viterbi_kernel(SmmDpArgs a)
             for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
             hq[0] = live ? init[to] : SMM_NEG_INF;
             double cum = 0.0;
-            // Both halves of the wave compute every position; only the lower half's results are wanted in LDS.  The upper
-            // half stores to a junk array of the same shape instead of being masked off: no exec juggling (three
-            // s_and_saveexec / branch / s_or groups per position) on the serial path.
-            double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
-            double *const st_g = half ? &sh_junk[0][0][to] : &sh_g[0][0][to];
-            double *const st_cum = half ? &sh_junk[0][0][to] : &sh_cum[0][0][to];
-            double *const st_h = half ? &sh_junk[0][0][to] : &sh_h[0][0][to];
+            // every lane group computes every position; only group 0's results are wanted in LDS.  The other groups store
+            // to a junk array of the same shape instead of being masked off: no exec juggling on the serial path (masking
+            // measured slower: round 4, +8 % of the wave's busy time)
+            double *const st_gam = half ? &sh_junk[0][0][to][0] : &sh_gam[to];
+            double *const st_gh = half ? &sh_junk[0][0][to][0] : &sh_gh[0][0][to][0];
             constexpr int UC = M / B;                         // blocks per unrolled chain iteration: UC*B % M == 0, UC even
             SMM_PROF_DECL;
             // SPEC: the transition SPECULATED on one source.  beta[to] = max_c (gamma[c] + trans[to][c]) is the largest piece of
@@ -510,26 +601,41 @@ smm_viterbi_kernel(SmmDpArgs a)
                 for (int jj = 0; jj < UC; ++jj) {
                     const int j = j0 + jj;
                     if (j >= J) break;
+                    // A'[n][to] and elp[n-1][to] of the block's positions: read TWO positions ahead of their use (all sixteen at the
+                    // block's start cost 28 registers of a wave that has none to spare)
+                    // ... in the kernels that are short of registers (TIGHT: blocks of 8 positions, two lane groups, the
+                    // speculative transition compiled in); the others read the whole block at its start, one wait for all
+                    constexpr bool TIGHT = SPEC && B == 8 && HFC != 4;
                     double ap[B], ev[B];
+                    auto stage = [&](int i) {
+                        if (i < B) { ap[i] = sh_apart[jj & 1][i][to]; ev[i] = sh_e[jj & 1][i][to]; }
+                    };
+                    if constexpr (TIGHT) { stage(0); stage(1); stage(2); }
+                    else {
     #pragma unroll
-                    for (int i = 0; i < B; ++i) {
-                        ap[i] = sh_apart[jj & 1][i][to];
-                        ev[i] = sh_e[jj & 1][i][to];
+                        for (int i = 0; i < B; ++i) stage(i);
                     }
                     // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
                     // candidates k = 2..K0, A'[n+1], cumE[n+1] -- is evaluated in the shadow of position n's LDS round trip
                     // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
                     auto partial = [&](int i) {                  // max(A'[n], max_{k=2..K0} h[n-k] + len[k]), n = jB+1+i
-                        double sq[K0 + 1];
                         double acc = ap[i];
                         if constexpr (SMM_ABLATE & 1) return acc;
                         const int kmax = TRI ? B + D + i : K0;     // (i is a constant at every call site)
+                        // groups of four candidates, fenced: all fourteen sums ahead of the first max (what the scheduler
+                        // makes of a free hand) are 28 live registers in a wave that spills past 256 -- and a kernel with
+                        // a private segment pays for it at dispatch (round 4: +0.3 ms on a launch beside another kernel)
     #pragma unroll
-                        for (int k = 2; k <= K0; ++k)
-                            if (k <= kmax) sq[k] = hq[(jj * B + 1 + i - k + 4 * M) % M] + lk[k];
+                        for (int k0 = K0; k0 >= 2; k0 -= 4) {
+                            double sq[4];
     #pragma unroll
-                        for (int k = K0; k >= 2; --k)
-                            if (k <= kmax) acc = smm_fmax(acc, sq[k]);
+                            for (int q = 0; q < 4; ++q)
+                                if (k0 - q >= 2 && k0 - q <= kmax) sq[q] = hq[(jj * B + 1 + i - (k0 - q) + 4 * M) % M] + lk[k0 - q];
+    #pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (k0 - q >= 2 && k0 - q <= kmax) acc = smm_fmax(acc, sq[q]);
+                            if constexpr (TIGHT) { if (k0 - 4 >= 2) __builtin_amdgcn_sched_barrier(0); }
+                        }
                         return acc;
                     };
                     double pacc = partial(0);
@@ -539,7 +645,8 @@ smm_viterbi_kernel(SmmDpArgs a)
                     // the full transition of position i of the block: beta[to] = max_from (gamma[from] + trans[to][from]); this
                     // lane group folds sources half*HFC ..  (gamma comes back from LDS: the row the chain wave has just written)
                     auto fold_read = [&](int i, double2 (&gv)[HFC / 2]) {
-                        const double2 *gp = reinterpret_cast<const double2 *>(GAMROW ? &sh_gam[half * HFC] : &sh_g[jj & 1][i][half * HFC]);
+                        (void)i;
+                        const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HFC]);
     #pragma unroll
                         for (int q = 0; q < HFC / 2; ++q) gv[q] = gp[(SMM_ABLATE & 16) ? q % 2 : q];
                     };
@@ -562,6 +669,11 @@ smm_viterbi_kernel(SmmDpArgs a)
                     // MODE 0: every position takes the full fold (no leader holds; kernels without SPEC): the next position's
                     // candidates are evaluated in the shadow of the fold's LDS round trip.  MODE 1: a leader holds at the
                     // block's start: the fast transition, checked per position, the full fold (unshadowed: rare) where it fails.
+                    // PIPE0: a full position evaluates the next position's candidates in the shadow of its fold's LDS round trip.
+                    // With the speculative transition compiled in, the kernels with blocks of 8 positions and two lane groups
+                    // cannot afford the registers (fold operands + candidate sums at once: a few spilled registers, i.e. a
+                    // private segment, i.e. a slower DISPATCH of every launch): there the candidates follow the fold.
+                    constexpr bool PIPE0 = !TIGHT || SMM_PIPE0_ALWAYS;
                     auto run_block = [&](auto mode_c) {
                         constexpr int MODE = decltype(mode_c)::value;
     #pragma unroll
@@ -570,15 +682,10 @@ smm_viterbi_kernel(SmmDpArgs a)
                             // rows are never stored, published or read): no bounds test on the serial path -- every instruction
                             // of this wave, scalar compare and branch included, is a slot of the position's time (same-box A/B:
                             // cfg2 DP -1.2 %).  Position n = jB + 1 + i; n mod M == (jj*B + 1 + i) mod M.
+                            if constexpr (TIGHT) stage(i + 3);
                             const double acc = smm_fmax(pacc, hq[(jj * B + i + 4 * M) % M] + lk[1]);
                             cum = cumn;
                             const double gm = cum + acc;
-                            // The transition reads gamma back from its history staging row (one LDS store less per position:
-                            // cfg3 DP -1.4 % in a same-box A/B); with the 8-position blocks of the short-ring configurations that
-                            // and with rings of <= 128 slots (cfg4) that measured 1.5-2 % slower: those keep the separate broadcast row.
-                            if constexpr (GAMROW) st_gam[0] = gm;
-                            if constexpr (!(SMM_ABLATE & 256)) st_g[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = gm;
-                            if constexpr (!(SMM_ABLATE & (2 | 256))) st_cum[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = cum;
                             // (gamma[T] is read back from the block's rows behind the loop -- no test per position)
                             {
                                 double hcur;
@@ -600,9 +707,19 @@ smm_viterbi_kernel(SmmDpArgs a)
                                     double hfast_p = hfast;
                                     asm volatile("" : "+v"(hfast_p));
                                     if (__builtin_expect(bad, 0)) {
-                                        double2 gv[HFC / 2];
-                                        fold_read(i, gv);
-                                        hcur = fold_reduce(gv) - cum;
+                                        st_gam[0] = gm;                          // (the fold reads gamma back from its broadcast row)
+                                        // the full fold in pieces of two sources, fenced (rare: registers matter here, time does not --
+                                        // a spill anywhere in the kernel is a private segment, and that costs every launch)
+                                        const double2 *gp = reinterpret_cast<const double2 *>(&sh_gam[half * HFC]);
+                                        double bm = SMM_NEG_INF;
+    #pragma unroll
+                                        for (int q = 0; q < HFC / 2; ++q) {
+                                            const double2 g2 = gp[q];
+                                            bm = smm_fmax(bm, smm_fmax(g2.x + tr[2 * q], g2.y + tr[2 * q + 1]));
+                                            __builtin_amdgcn_sched_barrier(0);
+                                        }
+                                        if constexpr (HFC == 4) bm = smm_max_rows16(bm);
+                                        hcur = smm_max_halves(bm) - cum;
                                         if (spec) { spec = false; dlt = SMM_NEG_INF; }   // the leader lost its lead: the next one is looked for behind this block
                                         if (i == B - 1) gm_last = gm;
                                     } else {
@@ -613,18 +730,28 @@ smm_viterbi_kernel(SmmDpArgs a)
                                     }
                                 } else {
                                     double2 gv[HFC / 2];
+                                    st_gam[0] = gm;
                                     fold_read(i, gv);
                                     __builtin_amdgcn_sched_barrier(0);
-                                    if (i + 1 < B) {
-                                        pacc = partial(i + 1 < B ? i + 1 : 0);
-                                        cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
+                                    if constexpr (PIPE0) {
+                                        if (i + 1 < B) {
+                                            pacc = partial(i + 1 < B ? i + 1 : 0);
+                                            cumn = (SMM_ABLATE & 2) ? ev[i + 1 < B ? i + 1 : 0] : cum + ev[i + 1 < B ? i + 1 : 0];
+                                        }
+                                        __builtin_amdgcn_sched_barrier(0);
                                     }
-                                    __builtin_amdgcn_sched_barrier(0);
                                     hcur = fold_reduce(gv) - cum;
+                                    if constexpr (!PIPE0) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        if (i + 1 < B) {
+                                            pacc = partial(i + 1 < B ? i + 1 : 0);
+                                            cumn = cum + ev[i + 1 < B ? i + 1 : 0];
+                                        }
+                                    }
                                     if (i == B - 1) gm_last = gm;
                                 }
                                 hq[(jj * B + 1 + i) % M] = hcur;
-                                if constexpr (!(SMM_ABLATE & 1024)) st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
+                                *reinterpret_cast<double2 *>(st_gh + ((jj & 1) * B + i) * 2 * SMM_MAX_STATES_DEV) = make_double2(gm, hcur);
                             }
                         }
                     };
@@ -643,8 +770,10 @@ smm_viterbi_kernel(SmmDpArgs a)
                             bool ok = false;
                             if (lead_m) {
                                 cs = __builtin_amdgcn_readfirstlane(__ffsll(lead_m) - 1);
-                                trS = sh_tr[to * SMM_MAX_STATES_DEV + cs];
-                                dlt = sh_dl[cs * SMM_MAX_STATES_DEV + to];
+                                int to_i = to < SN ? to : 0;
+                                asm volatile("" : "+v"(to_i));       // (addresses made here, once per segment: hoisted out of the loop they were spilled)
+                                trS = sh_tr[to_i * SN + cs];
+                                dlt = sh_dl[cs * SN + to_i];
                                 ok = __ballot(gm_last - best > dlt) == 0;
                             }
                             if (ok) { spec = true; spec_back = 1; }
@@ -656,7 +785,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
             // gamma[T] for the closing step: the row of position T in the last block's staging rows (written by lane
             // group 0; every wave reads sh_gfin behind the __syncthreads() that follows the loops)
-            if (half == 0) sh_gfin[to] = sh_g[(J - 1) & 1][(T - 1) % B][to];
+            if (half == 0) sh_gfin[to] = sh_gh[(J - 1) & 1][(T - 1) % B][to][0];
 #ifdef SMM_PROFILE
             p_ph[2] = p_fastn;                                // (slot 34 of the stamps: wave 0 has no blocks with j mod 4 = 2)
 #endif
@@ -699,17 +828,18 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
         for (int r = 0; r < NHR; ++r) {
             const int e = 16 * r + (lane & 15), ejs = e / B, ec = ejs * NPS + rank;
-            hoff[r] = (e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0);
+            hoff[r] = ((e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0)) * 2 + 1;   // (the h half of the (gamma, h) pairs)
             hvp[r] = SMM_NEG_INF;
         }
-        uint32_t act[SPS];                                                   // bit m-1: band m is switched on for the current group
+        unsigned long long mcur = 0, mnext = 0;          // bit 8 js + m - 1: band m of the wave's js-th state is switched on for the
+                                                         // current group / for the next one, once decided
+        const int nvw = (rank < C) ? ((C - 1 - rank) / NPS + 1 < SPS ? (C - 1 - rank) / NPS + 1 : SPS) : 0;   // states of this wave
         uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
 #pragma unroll
         for (int js = 0; js < SPS; ++js) {
             const int c = js * NPS + rank;
             const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
             smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, TRI ? B + 1 : 2 * B + D, kshort, c < C, lane);
-            act[js] = 0;
         }
         // The skip test.  The mover wave keeps max h over every group of 16 sources, one lane per state (ring sh_hm);
         // every pusher decides the bands of its own states, lane q = 8 js + (m - 1) for (state js, band m), in the block
@@ -718,6 +848,10 @@ smm_viterbi_kernel(SmmDpArgs a)
         // decision is due), so the test reads
         //     hm[G - 7m] + max_{band m} len  >  hm[G - 2] + min_{33 <= k <= 174} len      <=>  band m on for group G.
         static_assert(!BAND || BPG == 2, "a group is two blocks: decided in the second block of the previous group");
+        // the delayed sources are read from the history TWO blocks ahead of their pushes; the mover stores a block's rows
+        // one step after the block and is known to have drained them two steps later (smm_lds_barrier): the newest row a
+        // delayed band reads must be older than that by a margin
+        static_assert(!BAND || (SMM_BAND_DELAY - 2 * B) / B - 1 >= 4 + 4, "delayed-band reads of the history: at least 4 block steps of slack behind the mover's drained stores");
         double hmx = SMM_NEG_INF;                                            // mover, lane = state: running max of the group
         // lane q = 8 js + (m - 1) decides (state js, band m) and fetches its delayed sources, two blocks ahead
         const int qjs = lane >> 3, qm = (lane & 7) + 1;
@@ -730,56 +864,13 @@ smm_viterbi_kernel(SmmDpArgs a)
         double hq[2][B];                                                     // by parity of the block that pushes them
 #pragma unroll
         for (int i = 0; i < B; ++i) { hq[0][i] = SMM_NEG_INF; hq[1][i] = SMM_NEG_INF; }
-        uint32_t actp[SPS];                                                  // the next group's bands, once decided
-#pragma unroll
-        for (int js = 0; js < SPS; ++js) actp[js] = 0;
         constexpr int NPRE = 2;                   // rings fetched a block ahead: the wave's first NPRE (state, band) pairs
                                                   // (six measured 7 % SLOWER than two: registers and code for a case that is rare)
         double Lp[NPRE][RS];                      // in ascending 8 js + (m - 1), the order the push loop meets them in
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) { Lp[k][0] = SMM_NEG_INF; Lp[k][1] = SMM_NEG_INF; }
         int npre = 0, pk = 0;                     // pairs fetched for this block; pairs met so far in this block
-        // mover role (wave MW), as in the plain configuration below
-        int lo[NE], row[NE];
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            row[q] = e / cm;
-            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
-        }
-        int slo[NE], srw[NE], sloc[NE], hloc[NE];                           // (sloc, hloc: the mover's unconditional reads)
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            srw[q] = e / C;
-            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
-            sloc[q] = slo[q] >= 0 ? slo[q] : 0;
-            hloc[q] = (e / B < C) ? (e % B) * SMM_MAX_STATES_DEV + e / B : 0;
-        }
-        const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE];
-        if (w == MW) {
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
-                pre[q] = elp[e < e_last ? e : e_last];
-            }
-        }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): tables and rings have arrived
-        auto store_block = [&](const double *src, double *dst, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x;
-                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
-            }
-        };
-        auto store_h_block = [&](const double *src, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x, c = e / B, i = e % B;
-                if (c < C && q * B + 1 + i <= T) hh[(size_t)c * (T + 1) + q * B + 1 + i] = src[i * SMM_MAX_STATES_DEV + c];
-            }
-        };
         SMM_PROF_DECL;
         for (int j0 = 0; j0 < J; j0 += UBB) {
 #pragma unroll
@@ -788,57 +879,19 @@ smm_viterbi_kernel(SmmDpArgs a)
                 if (j >= J) break;
                 const int ph = jj % BPG;                                   // block of its group
                 if (w == MW) {
-                    // Every LDS read of the block is issued first, unconditionally (clamped offsets), as ONE batch: the
-                    // history rows of block j-1, the rows the pushers push in this block (group maxima), the two group
-                    // maxima of this block's decision pass.  (Reads inside the `if (row <= T)` of each store were
-                    // ds_read / wait / store ten times over: ten LDS round trips, 2200 busy cycles for 80 instructions.)
-                    double hist[3][NE];
-#pragma unroll
-                    for (int x = 0; x < NE; ++x) {
-                        hist[0][x] = (&sh_cum[(jj + 1) & 1][0][0])[sloc[x]];
-                        hist[1][x] = (&sh_h[(jj + 1) & 1][0][0])[hloc[x]];
-                        hist[2][x] = (&sh_g[(jj + 1) & 1][0][0])[sloc[x]];
-                    }
-                    const double *h_blk = &sh_h[(jj + 1) & 1][0][lane & (SMM_MAX_STATES_DEV - 1)];
-                    double hrow[B];
-#pragma unroll
-                    for (int i = 0; i < B; ++i) hrow[i] = h_blk[i * SMM_MAX_STATES_DEV];
-                    __builtin_amdgcn_sched_barrier(0);
-                    double *dst = &sh_e[(jj + 1) & 1][0][0];
-#pragma unroll
-                    for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                        pre[q] = elp[e < e_last ? e : e_last];
-                    }
-                    if (j >= 1) {
-                        const int q = j - 1;
-#pragma unroll
-                        for (int x = 0; x < NE; ++x) {
-                            const int e = lane + 64 * x;
-                            if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) {
-                                hcum[(size_t)(q * B + 1) * C + e] = hist[0][x];
-                                hgam[(size_t)(q * B + 1) * C + e] = hist[2][x];
-                            }
-                            const int hc = e / B, hi = e % B;
-                            if (hc < C && q * B + 1 + hi <= T) hh[(size_t)hc * (T + 1) + q * B + 1 + hi] = hist[1][x];
-                        }
-                    }
-                    // the sources the pushers push in this block (positions (j-1)B + 1 .. jB), lane = state
+                    // (the mover's block step: see mover_step) ... and the maxima of the skip test: the sources the pushers
+                    // push in this block (positions (j-1)B + 1 .. jB), lane = state
+                    const double gm = mover_step(j, jj, true);
                     if constexpr (!(SMM_ABLATE & 8)) {
-                        double gm = hrow[B - 1];
-#pragma unroll
-                        for (int i = 0; i < B - 1; ++i) gm = smm_fmax(gm, hrow[i]);
                         hmx = smm_fmax(hmx, gm);
                         if (ph == 0) {                                         // group j/BPG - 1 is complete
                             // (j = 0: "group -1", slot 63: position 0, the start of every first segment, is its one real source)
-                            if (lane < SMM_MAX_STATES_DEV) sh_hm[BAND ? lane : 0][BAND ? ((j / BPG - 1) & 63) : 0] = hmx;
+                            if (lane < SN) sh_hm[BAND ? lane : 0][BAND ? ((j / BPG - 1) & 63) : 0] = hmx;
                             hmx = SMM_NEG_INF;
                         }
                     }
                 }
+                if (w != MW) {           // (the mover owns no states: none of what follows -- least of all the eight loads -- is for it)
                 // this block pushes sources (j-1)B .. jB-1 (push steps jB ..): band 0 from LDS, the bands that are switched
                 // on from the rows fetched during the previous block.  (Reading the rows of all states first and
                 // interleaving the states' pushes step by step measured 3 % SLOWER: the wave is not bound by the latency
@@ -849,7 +902,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 double dsrc = SMM_NEG_INF, dwit = SMM_NEG_INF;               // decision of group (j+1)/2, due in its block 2G - 1
                 const int dG = (j + 1) / BPG;
 #pragma unroll
-                for (int r = 0; r < NHR; ++r) hvl[r] = (&sh_h[(jj + 1) & 1][0][0])[hoff[r]];
+                for (int r = 0; r < NHR; ++r) hvl[r] = (&sh_gh[(jj + 1) & 1][0][0][0])[hoff[r]];
                 auto src_row = [&](int js, int i) {          // h[(j-1)B + 1 + i] of the wave's js-th state
                     return smm_row_bcast(hvl[(B * js + i) / 16], (B * js + i) % 16);
                 };
@@ -868,13 +921,14 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                 for (int js = 0; js < SPS; ++js) {
                     const int c = js * NPS + rank;
-                    if (c >= C) break;
+                    if (js >= nvw) break;
                     if constexpr (!(SMM_ABLATE & 4)) {
 #pragma unroll
                         for (int i = D; i < B; ++i)
                             smm_push<RS>(As[js], L0[js], src_row(js, i - D), (jj * B + i) % RS);
                     }
-                    if (act[js]) {
+                    const uint32_t act_js = (uint32_t)(mcur >> (8 * js)) & 0xffu;
+                    if (__builtin_expect(act_js != 0, 0)) {
                         // the bands that are switched on (rarely any): their rings at this block's phase come from the table
                         // -- the first two of the wave were fetched during the previous block (below), like their sources:
                         // a table row costs an L2 round trip, and a pusher that waits for one makes the whole block wait
@@ -890,7 +944,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                             }
                             ++pk;
                         };
-                        uint32_t mm = act[js];
+                        uint32_t mm = act_js;
                         nact += __builtin_popcount(mm);
                         int m = __builtin_ctz(mm) + 1;
                         double Lm[RS];
@@ -909,14 +963,21 @@ smm_viterbi_kernel(SmmDpArgs a)
                             m = mn;
                         }
                     }
-                    // hand A' of block j+1 to the chain wave and clear those slots (the B slots are all registers of B/RS lanes)
+                }
+                // hand A' of block j+1 to the chain wave and clear those slots (the B slots are all registers of B/RS lanes) --
+                // for all of the wave's states under ONE exec mask (a masked region per state was two branches per state)
+                {
                     const int d = lane - (((j + 1) * B) & 127) / RS;
                     if (d >= 0 && d < B / RS) {
-                        double *a_blk = &sh_apart[(jj + 1) & 1][0][c];
 #pragma unroll
-                        for (int r = 0; r < RS; ++r) {
-                            a_blk[(d * RS + r) * SMM_MAX_STATES_DEV] = As[js][r];
-                            As[js][r] = ninf;
+                        for (int js = 0; js < SPS; ++js) {
+                            if (js >= nvw) break;
+                            double *a_blk = &sh_apart[(jj + 1) & 1][0][js * NPS + rank];
+#pragma unroll
+                            for (int r = 0; r < RS; ++r) {
+                                a_blk[(d * RS + r) * SMM_MAX_STATES_DEV] = As[js][r];
+                                As[js][r] = ninf;
+                            }
                         }
                     }
                     if constexpr (TRI) {
@@ -924,30 +985,23 @@ smm_viterbi_kernel(SmmDpArgs a)
                         const int dp = (d + 64) & 63;
                         if (dp >= 64 - B / RS) {
 #pragma unroll
-                            for (int r = 0; r < RS; ++r) As[js][r] = ninf;
+                            for (int js = 0; js < SPS; ++js) {
+#pragma unroll
+                                for (int r = 0; r < RS; ++r) As[js][r] = ninf;
+                            }
                         }
                     }
                 }
                 if (ph == 1 && !(SMM_ABLATE & 32)) {
                     // group dG = (j+1)/2 (pushed in blocks j+2, j+3): which of this wave's (state, band) pairs are on
                     const bool on = qok && dG - 7 * qm >= -1 && dsrc + qlmx > dwit + qlbm;
-                    const unsigned long long mask = __ballot(on);
-#pragma unroll
-                    for (int js = 0; js < SPS; ++js) actp[js] = (uint32_t)(mask >> (8 * js)) & 0xffu;
+                    mnext = __ballot(on);                         // (bit 8 js + m - 1: lane q = 8 js + (m - 1) decides (state js, band m))
                 }
-                unsigned long long lanes2 = 0;                    // group (j+1)/2 (`actp` in either block of a group)
-#pragma unroll
-                for (int js = 0; js < SPS; ++js) lanes2 |= (unsigned long long)actp[js] << (8 * js);
-                if (ph == 0) {
-                    // the next block starts group j/2
-#pragma unroll
-                    for (int js = 0; js < SPS; ++js) act[js] = actp[js];
-                }
+                const unsigned long long lanes2 = mnext;          // group (j+1)/2 (decided in either block of a group)
+                if (ph == 0) mcur = mnext;                        // the next block starts group j/2
                 // the rings of the next block's first NPRE (state, band) pairs at that block's phase (the tables stay in L2)
                 {
-                    unsigned long long lanes = 0;
-#pragma unroll
-                    for (int js = 0; js < SPS; ++js) lanes |= (unsigned long long)act[js] << (8 * js);
+                    const unsigned long long lanes = mcur;
                     npre = 0; pk = 0;
                     if (lanes) {                                  // (nearly always nothing is switched on)
                         const int offn = (B + D - (j + 1) * B) & 127;
@@ -986,15 +1040,12 @@ smm_viterbi_kernel(SmmDpArgs a)
                 }
 #pragma unroll
                 for (int r = 0; r < NHR; ++r) hvp[r] = hvl[r];
+                }
                 SMM_LDS_BARRIER();                               // end of block j
             }
         }
         SMM_PROF_OUT();
-        if (w == MW) {
-            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
-            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
-            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
-        }
+        if (w == MW) (void)mover_step(J, J & 1, false);                       // the last block's history
         if (lane == 0 && nact) atomicAdd(a.err + 3, (int)nact);             // error block word 3: see ops.error_words
 #ifdef SMM_PROFILE
         if (lane == 0 && blockIdx.x == 0 && w != MW && w < 7) reinterpret_cast<unsigned long long *>(a.err)[w < MW ? w + 1 : w] = nact;   // slots 2..6: workgroup 0's waves 1, 2, 3, 5, 6
@@ -1029,111 +1080,28 @@ smm_viterbi_kernel(SmmDpArgs a)
             smm_ring_init<R, B, D, TRI>(A[js], L[js], len + (js < nv ? js * NPd + rank : 0), cm, kp, js < nv, lane);
             hd[js] = SMM_NEG_INF;
         }
-        // mover role of this wave: block-relative element e = lane + 64 q  <->  HBM offset e, LDS offset (e / cm, e % cm)
-        int lo[NE], row[NE];
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            row[q] = e / cm;
-            lo[q] = (e < B * cm) ? row[q] * SMM_MAX_STATES_DEV + e % cm : -1;
-        }
-        int slo[NE], srw[NE], sloc[NE], hloc[NE];                          // history block element e (rows C wide) -> LDS offset, row
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + 64 * q;
-            srw[q] = e / C;
-            slo[q] = (e < B * C) ? srw[q] * SMM_MAX_STATES_DEV + e % C : -1;
-            sloc[q] = slo[q] >= 0 ? slo[q] : 0;                            // (the mover's unconditional reads)
-            hloc[q] = (e / B < C) ? (e % B) * SMM_MAX_STATES_DEV + e / B : 0;
-        }
-        // wave MW: elp of the block after next.  Unconditional loads from clamped addresses (rows >= T are never used):
-        // a predicated load has to wait for the previous one into the same register.
-        const int64_t e_last = (int64_t)T * cm - 1;
-        double pre[NE];
-        if (w == MW) {
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                const int64_t e = (int64_t)B * cm + lane + 64 * q;                 // block 1
-                pre[q] = elp[e < e_last ? e : e_last];
-            }
-        }
         // Everything loaded so far (tables, rings) has to have arrived before the loop: the compiler's wait-count
         // bookkeeping would otherwise carry "maybe pending" into every iteration and make the waves that store the
         // history wait for their own stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
-        // history block q (positions qB+1 .. (q+1)B, rows <= T) from LDS to HBM
-        auto store_block = [&](const double *src, double *dst, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x;
-                if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) dst[(size_t)(q * B + 1) * C + e] = src[slo[x]];
-            }
-        };
-        // h rows, state-major in HBM (element e = c B + i: B consecutive lanes write 8 B contiguous bytes)
-        auto store_h_block = [&](const double *src, int q) {
-#pragma unroll
-            for (int x = 0; x < NE; ++x) {
-                const int e = lane + 64 * x, c = e / B, i = e % B;
-                if (c < C && q * B + 1 + i <= T) hh[(size_t)c * (T + 1) + q * B + 1 + i] = src[i * SMM_MAX_STATES_DEV + c];
-            }
-        };
         SMM_PROF_DECL;
         for (int j0 = 0; j0 < J; j0 += UB) {
 #pragma unroll
             for (int jj = 0; jj < UB; ++jj) {
                 const int j = j0 + jj;
                 if (j >= J) break;
-                if (w == MW) {
-                    // the history rows of block j-1: every LDS read first, unconditionally (clamped offsets), as ONE batch
-                    // (a read inside the `if (row <= T)` of each store is a round trip of its own: see the BAND mover)
-                    double hist[3][NE];
-#pragma unroll
-                    for (int x = 0; x < NE; ++x) {
-                        hist[0][x] = (&sh_cum[(jj + 1) & 1][0][0])[sloc[x]];
-                        hist[1][x] = (&sh_h[(jj + 1) & 1][0][0])[hloc[x]];
-                        hist[2][x] = (&sh_g[(jj + 1) & 1][0][0])[sloc[x]];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // block j+1 (fetched a block ago) -> LDS, then fetch block j+2
-                    double *dst = &sh_e[(jj + 1) & 1][0][0];
-#pragma unroll
-                    for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        const int64_t e = (int64_t)(j + 2) * B * cm + lane + 64 * q;
-                        pre[q] = elp[e < e_last ? e : e_last];
-                    }
-                    if (j >= 1) {
-                        const int q = j - 1;
-#pragma unroll
-                        for (int x = 0; x < NE; ++x) {
-                            const int e = lane + 64 * x;
-                            if (slo[x] >= 0 && q * B + 1 + srw[x] <= T) {
-                                hcum[(size_t)(q * B + 1) * C + e] = hist[0][x];
-                                hgam[(size_t)(q * B + 1) * C + e] = hist[2][x];
-                            }
-                            const int hc = e / B, hi = e % B;
-                            if (hc < C && q * B + 1 + hi <= T) hh[(size_t)hc * (T + 1) + q * B + 1 + hi] = hist[1][x];
-                        }
-                    }
-                }
+                if (w == MW) (void)mover_step(j, jj, true);                 // (see mover_step)
 #pragma unroll
                 for (int js = 0; js < SPW; ++js) {
                     if (js >= nv) break;
                     const int c = js * NPd + rank;
-                    smm_ring_block<R, B, D, TRI>(A[js], L[js], hd[js], &sh_h[(jj + 1) & 1][0][c], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
+                    smm_ring_block<R, B, D, TRI>(A[js], L[js], hd[js], &sh_gh[(jj + 1) & 1][0][c][1], &sh_apart[(jj + 1) & 1][0][c], j, jj, lane, ninf);
                 }
                 SMM_LDS_BARRIER();                               // end of block j
             }
         }
         SMM_PROF_OUT();
-        // the last block's history
-        if (w == MW) {
-            store_block(&sh_cum[(J - 1) & 1][0][0], hcum, J - 1);
-            store_h_block(&sh_h[(J - 1) & 1][0][0], J - 1);
-            store_block(&sh_g[(J - 1) & 1][0][0], hgam, J - 1);
-        }
+        if (w == MW) (void)mover_step(J, J & 1, false);                       // the last block's history
     }
 
     // -------------------------------------------------------------------------------- last position
@@ -1436,9 +1404,12 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
         hipLaunchKernelGGL(kernel, dim3(a.b), dim3(NW * 64), dyn, stream, a);
     };
     // HF: source states per lane group of the chain wave (4: four groups of 16 lanes; else two groups, 2 HF >= states)
-    if (c_need <= 16) go(smm_viterbi_kernel<R, SPW, NW, 4, B>);
-    else if (c_need <= 24) go(smm_viterbi_kernel<R, SPW, NW, 12, B>);
-    else go(smm_viterbi_kernel<R, SPW, NW, 16, B>);
+    // blocks of 8: the pushers push the block's own sources (D = 0, as in BAND mode): with D = 1 the chain wave keeps 32
+    // positions of h instead of 16, and with the speculative transition on top it spills
+    constexpr int DD = (B == 8) ? 0 : SMM_D;
+    if (c_need <= 16) go(smm_viterbi_kernel<R, SPW, NW, 4, B, DD>);
+    else if (c_need <= 24) go(smm_viterbi_kernel<R, SPW, NW, 12, B, DD>);
+    else go(smm_viterbi_kernel<R, SPW, NW, 16, B, DD>);
     return 1;
 }
 
@@ -1478,9 +1449,10 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
               launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
               launch_if<R, 5, 8>(a, spw, nw, c_need, stream);
     } else if constexpr (R == 8) {
+        // (five states per pusher with 512-slot rings do not fit the registers: 29..32 states at K > 256 run in BAND mode,
+        // smm_api.hip: band_mode)
         hit = launch_if<R, 1, 8>(a, spw, nw, c_need, stream) || launch_if<R, 2, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream) ||
-              launch_if<R, 5, 8>(a, spw, nw, c_need, stream);
+              launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
 }

@@ -285,12 +285,7 @@ class SemiMarkovModel(object):
         (multi-GPU decode: videos are independent, every rank decodes its own; batching.make_data_loader)."""
         # everything baked into the cached PackedCorpus (constraints scaled by the narration weight, K clipped per batch,
         # end penalties from the allowed-ends tables) is part of the key
-        order = self.ordered_indices_by_task
-        key = (id(test_data), len(test_data), shard, tuple(self.args.sm_constrain_with_narration),
-               float(getattr(self.args, 'sm_constrain_narration_weight', 0.0)), self.model.max_k,
-               None if self.model.allowed_ends is None else tuple(sorted(self.model.allowed_ends)),
-               None if order is None else tuple((t, tuple(v)) for t, v in sorted(order.items())),
-               self.args.batch_size, str(self.device))
+        key = self._prepared_key(test_data, shard)
         cache = self.__dict__.setdefault('_prepared', {})
         hit = cache.get(key)
         if hit is not None and hit[0]() is test_data:
@@ -311,6 +306,17 @@ class SemiMarkovModel(object):
             except TypeError:                               # (a datasplit type that cannot be weakly referenced)
                 pass
         return self.model.prepare_packed(pc)
+
+    def _prepared_key(self, test_data, shard, *extra):
+        """Everything baked into a cached PackedCorpus: the datasplit (by identity -- the cache holds a weak reference and
+        checks it), the shard, the narration constraints and their weight, K (clipped per batch), the allowed-ends
+        tables, the task orderings, the batching and the device."""
+        order = self.ordered_indices_by_task
+        return (id(test_data), len(test_data), shard, tuple(self.args.sm_constrain_with_narration),
+                float(getattr(self.args, 'sm_constrain_narration_weight', 0.0)), self.model.max_k,
+                None if self.model.allowed_ends is None else tuple(sorted(self.model.allowed_ends)),
+                None if order is None else tuple((t, tuple(v)) for t, v in sorted(order.items())),
+                self.args.batch_size, str(self.device)) + tuple(extra)
 
     def clear_prepared(self):
         """Drop every datasplit kept resident by ``prepare`` (frees the HBM they hold)."""
@@ -353,9 +359,13 @@ class SemiMarkovModel(object):
         loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
                                   shard=shard)
         batches = list(loader)
+        # longest videos first: a slab's decode lasts as long as its longest video (the DP is one serial chain per video),
+        # and the pass ends with the decode of the LAST slab, which no upload overlaps -- so the last slab gets the
+        # batches whose longest video is shortest (round 3 kept the loader's order: a 14 000-frame video in the last
+        # slab left 3 ms of a 40 ms pass uncovered)
+        batches.sort(key=lambda b: -int(b['lengths'].max()))
         frames = [int(b['lengths'].sum()) for b in batches]
-        # equal shares, except that the last two slabs split one share 3 : 1 -- the pass ends with the decode of the last
-        # slab, which nothing overlaps: keep it short
+        # equal shares, except that the last two slabs split one share 3 : 1: keep the uncovered decode short
         shares = [1.0] * n_slabs if n_slabs < 3 else [1.0] * (n_slabs - 2) + [0.75, 0.25]
         bounds = np.cumsum(shares) / np.sum(shares)
         total, slabs, cur, acc = sum(frames), [], [], 0
@@ -380,6 +390,9 @@ class SemiMarkovModel(object):
         import torch
         from . import ops
         dev = self.device
+        slabs = [pc for pc in slabs if pc.n_videos > 0]
+        if not slabs:                                          # (more ranks than batches: nothing to decode on this one)
+            return torch.empty(0, dtype=torch.int64), []
         n_max = max(pc.x.size(0) for pc in slabs)
         d = slabs[0].x.size(1)
         st = self.__dict__.setdefault('_host_stream_state', {})
@@ -415,14 +428,21 @@ class SemiMarkovModel(object):
 
     def predict_host(self, test_data, n_slabs=6, shard=None):
         """``predict`` for a datasplit whose features stay in host memory: ``{video: int64[T]}``."""
+        import weakref
         cache = self.__dict__.setdefault('_prepared_host', {})
-        key = (id(test_data), len(test_data), n_slabs, shard, tuple(self.args.sm_constrain_with_narration), self.args.batch_size)
-        slabs = cache.get(key)
-        if slabs is None:
-            cache.clear()
-            slabs = cache[key] = self.prepare_host(test_data, n_slabs, shard)
+        key = self._prepared_key(test_data, shard, n_slabs)
+        hit = cache.get(key)
+        if hit is not None and hit[0]() is test_data:
+            slabs = [self.model.prepare_packed(pc) for pc in hit[1]]     # (tables follow the current parameters)
         else:
-            slabs = [self.model.prepare_packed(pc) for pc in slabs]      # (tables follow the current parameters)
+            cache.clear()
+            slabs = self.prepare_host(test_data, n_slabs, shard)
+            try:
+                cache[key] = (weakref.ref(test_data), slabs)
+            except TypeError:                               # (a datasplit type that cannot be weakly referenced)
+                pass
+        if not slabs or all(pc.n_videos == 0 for pc in slabs):
+            return {}                                       # this rank's shard is empty
         labels, _ = self.decode_host(slabs)
         lab = labels.clone().numpy()
         out, off = {}, 0

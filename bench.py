@@ -65,7 +65,7 @@ def parse(argv=None):
     p.add_argument('--no-predict-e2e', action='store_true', help='skip the SemiMarkovModel.predict wall-time figures')
     p.add_argument('--second-seed', type=int, default=1000,
                    help='N = 1, cfg3 only: also time the decode of the corpus of this seed (round 1\'s default draw, 11..21 '
-                        'states: no forced gangs) and report it beside the headline; negative: skip')
+                        'states) and report it beside the headline; negative: skip')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help="collectives: 'nccl' = RCCL (required for a measurement); 'gloo' only for rehearsals")
     p.add_argument('--share-gpus', action='store_true',
@@ -333,10 +333,16 @@ def timed_decode(a, pc, world, want_events=True):
     dp = None
     if timing:
         ops.dp_timing(False)
-        ms = ops.dp_timing_read()
-        if ms:
+        rec = ops.dp_timing_read(tagged=True)
+        if rec:
+            ms = [m for m, _ in rec]
+            # tag 1: the launch of the launch's critical (longest) videos on the caller's stream, tag 2: the rest of a split
+            # decode on the library's second stream, tag 0: the only DP launch of an unsplit call
+            crit = [m for m, t in rec if t in (0, 1)]
+            rest = [m for m, t in rec if t == 2]
             dp = {"launch_ms": float(np.mean(ms)), "launches_per_step": len(ms) / a.steps, "per_step_sum_ms": float(np.sum(ms)) / a.steps,
-                  "max_launch_ms": float(np.max(ms))}
+                  "max_launch_ms": float(np.max(ms)), "critical_launch_ms": float(np.mean(crit)) if crit else None,
+                  "rest_launch_ms": float(np.mean(rest)) if rest else None}
     if not empty:
         ops.check_decoded(pc.batch, last.get('out'))
         labels = labels.clone()       # (the pinned staging buffer is reused by the next decode)
@@ -822,12 +828,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "smm_viterbi_kernel", "kernel_ms": dp["launch_ms"], "launches_per_step": dp["launches_per_step"],
                          "kernel_ms_per_step": dp_ms, "kernel_ms_longest_launch": dp["max_launch_ms"],
+                         "critical_launch_ms": dp["critical_launch_ms"], "rest_launch_ms": dp["rest_launch_ms"],
+                         "frac_wall": dp_bytes / (weak["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_source": "HIP events recorded by the library (smm_dp_timing_*) around every DP kernel launch "
                                              "of the K timed steps, on the stream each launch runs on: smm_decode_f32 launches "
                                              "the kernel twice per step on a corpus whose longest videos set the DP's time (those "
                                              "videos first, the others on a second stream beside them: smm_api.hip choose_split); "
                                              "kernel_ms is the mean launch (what rocprofv3 --stats averages), achieved = the "
-                                             "step's algorithmic bytes / the step's summed launch time",
+                                             "step's algorithmic bytes / the step's summed launch time; critical_launch_ms / "
+                                             "rest_launch_ms: the means per stream (the critical launch is what must fit into "
+                                             "ms_per_step, and bench.py asserts that it does); frac_wall = the same bytes / the "
+                                             "step's wall time / peak",
                          "algorithmic_bytes_per_launch": dp_bytes / dp["launches_per_step"],
                          "note": "the DP is latency-bound, not HBM-bound: one serial chain per video (a few hundred cycles per "
                                  "position), and the launch lasts as long as its longest video; %.3g lattice cells per step, "
@@ -846,6 +857,9 @@ def main():
                                        "algorithmic_bytes_per_launch": fit_bytes},
                           "what": "smm_fit_stats_f64 (class sums + span statistics) over every frame of the workload"},
         }
+        # the launches of a split decode overlap: their sum may exceed the step, the critical one may not
+        assert dp["critical_launch_ms"] is None or dp["critical_launch_ms"] <= weak["ms_per_step"] * 1.001, \
+            (dp["critical_launch_ms"], weak["ms_per_step"])
         if strong is not None:
             res["strong_scaling"] = strong
             if head is strong and strong.get("roofline_rank0"):

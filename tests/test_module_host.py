@@ -141,3 +141,19 @@ def test_batched_group_tables_equal_per_group_tables(constrain):
     for n, p in m.named_parameters():
         if p.grad is not None:
             torch.testing.assert_close(gb[n], p.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_no_viterbi_kernel_has_a_private_segment():
+    """A spilled register gives a kernel a private segment (scratch), and a kernel with one is dispatched slower beside
+    another kernel: round 4 measured +0.3 ms on the critical launch of a split decode for twelve bytes of it.  Every
+    instantiation of the decode path's DP kernel must fit its registers (the code objects inside libsmmdp.so are read with
+    llvm-readelf; no GPU needed)."""
+    import shutil
+    from action_segmentation_amd import _build
+    if not (shutil.which("llvm-readelf") or os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")):
+        pytest.skip("llvm-readelf not available")
+    res = _build.kernel_resources()
+    vit = {k: v for k, v in res.items() if 'smm_viterbi_kernel' in k}
+    assert len(vit) >= 40, sorted(res)[:5]
+    bad = {k: v for k, v in vit.items() if v.get('private_segment_fixed_size', 0) != 0 or v.get('vgpr_spill_count', 0) != 0}
+    assert not bad, bad

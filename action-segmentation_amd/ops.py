@@ -60,7 +60,7 @@ class Batch:
 def _dev(t, dtype, name):
     if t is None:
         return None
-    if not t.is_cuda and not (name == 'labels' and t.is_pinned()):
+    if not t.is_cuda and not (name in ('labels', 'spans') and t.is_pinned()):
         raise _lib.SmmError("libsmmdp: %s must be a CUDA/HIP tensor (there is no CPU path)" % name)
     if t.dtype != dtype:
         raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
@@ -103,8 +103,26 @@ def _labels_on_host(batch, device):
     return out
 
 
-def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None):
-    spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
+_host_small = {}
+
+
+def _pinned_small(kind, device, numel, dtype):
+    """Small pinned host buffers the kernels (spans) or an async copy (error words) write into: the reference's call
+    pattern -- one viterbi() per batch of five videos -- is host latency, and every blocking device -> host copy is ~50 us
+    of it.  Valid after the stream has been synchronised, until the next call."""
+    key = (kind, device.index, dtype)
+    buf = _host_small.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(int(numel * 1.5) + 16, dtype=dtype, pin_memory=True)
+        _host_small[key] = buf
+    return buf[:numel]
+
+
+def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None, spans_on_host=False):
+    if want_spans and spans_on_host:
+        spans = _pinned_small('spans', device, batch.b * (batch.t_max + 1), torch.int64).view(batch.b, batch.t_max + 1)
+    else:
+        spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
     if labels_out is not None:
         labels = labels_out
     elif want_labels and labels_on_host:
@@ -244,12 +262,14 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
-           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False, labels_out=None):
+           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False, labels_out=None, spans_on_host=False):
     """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream.
-    ``labels_on_host`` / ``labels_out``: see ``viterbi``."""
+    ``labels_on_host`` / ``labels_out``: see ``viterbi``.  ``spans_on_host``: the kernel writes the span encoding into
+    pinned host memory and the error words follow by an asynchronous copy (small batches: the reference's per-batch call
+    pattern); both are valid once the stream has been synchronised, until the next such call."""
     lib = _lib.load()
     dev = x.device
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out, spans_on_host)
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want_elp else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
@@ -262,7 +282,12 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(class_map, torch.int64, 'class_map'), _dev(spans, torch.int64, 'spans'),
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
-    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=_err_copy(batch, ws))
+    if spans_on_host:
+        err = _pinned_small('err', dev, 4, torch.int32)
+        err.copy_(_err_view(batch, ws), non_blocking=True)
+    else:
+        err = _err_copy(batch, ws)
+    return dict(spans=spans, labels=labels, best=best, n_segs=n_segs, elp=elp32, _err=err)
 
 
 def _shape_with(batch, extra_flags):

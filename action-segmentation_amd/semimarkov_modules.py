@@ -389,9 +389,13 @@ class SemiMarkovModule(nn.Module):
     def _check_valid_classes(self, valid_classes_per_instance):
         if valid_classes_per_instance is None:
             return None
-        assert all_equal(set(int(v) for v in vc) for vc in valid_classes_per_instance), \
-            "must have same valid_classes for all instances in the batch"
-        return valid_classes_per_instance[0].detach().cpu().long()
+        first = valid_classes_per_instance[0]
+        # (the collate hands over the task's ONE index tensor b times: identity first -- the element-wise comparison of the
+        # reference, :600-601, walks every tensor in Python, 80 us of a 240 us call)
+        if not all(vc is first for vc in valid_classes_per_instance):
+            assert all_equal(set(int(v) for v in vc) for vc in valid_classes_per_instance), \
+                "must have same valid_classes for all instances in the batch"
+        return first.detach().cpu().long()
 
     def factor_tables(self, valid_classes, device=None):
         """fp64 factors of the potentials for one class set (no EOS row: the kernels handle EOS in closed form).
@@ -490,19 +494,37 @@ class SemiMarkovModule(nn.Module):
         or None.  Returns pred_spans: CPU int64 b x (Tmax+1) -- global class id at every span start, -1 for a
         continuation, ``n_classes`` (EOS) at position lengths[i], -1 after it [, elp b x Tmax x C fp32 on device].
         """
+        return self.viterbi_launch(features, lengths, valid_classes_per_instance, add_eos, use_mean_z,
+                                   additional_allowed_ends_per_instance, constraints, predict_single, return_elp)()
+
+    def viterbi_launch(self, features, lengths, valid_classes_per_instance, add_eos=True, use_mean_z=False,
+                       additional_allowed_ends_per_instance=None, constraints=None, predict_single=False, return_elp=False):
+        """``viterbi`` in two halves: this one enqueues the decode and returns at once; calling the returned function waits
+        for it and hands out what ``viterbi`` returns.  ONE launch may be outstanding per device (the spans land in a
+        pinned host buffer that the next launch reuses): a caller can collate its next batch in between
+        (``SemiMarkovModel.predict(fused=False)`` does)."""
         self._require_device(features, 'viterbi')
         valid_classes = self._check_valid_classes(valid_classes_per_instance)
         self.set_z(features, lengths, use_mean=use_mean_z)
+        # (the spans land in pinned host memory, the error words follow by an asynchronous copy: ONE synchronisation, no
+        # blocking device -> host copy -- this call is host latency at the reference's batch size)
         out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                           want_elp=return_elp, want_labels=False, no_eos=not add_eos)
-        pred_spans = out['spans'].cpu()
-        if not add_eos:
-            pred_spans = pred_spans[:, :features.size(1)].contiguous()   # b x Tmax: no EOS position (reference :679)
-        ops.check_decoded(out['_batch'], out)
-        if return_elp:
-            b, tmax = features.shape[:2]
-            return pred_spans, out['elp'].view(b, tmax, -1)
-        return pred_spans
+                           want_elp=return_elp, want_labels=False, no_eos=not add_eos, spans_on_host=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(features.device))
+        tmax = features.size(1)
+        b = features.size(0)
+
+        def result():
+            done.synchronize()
+            pred_spans = out['spans'].clone()                  # (the pinned buffer is reused by the next launch)
+            if not add_eos:
+                pred_spans = pred_spans[:, :tmax].contiguous()  # b x Tmax: no EOS position (reference :679)
+            ops.check_decoded(out['_batch'], out)
+            if return_elp:
+                return pred_spans, out['elp'].view(b, tmax, -1)
+            return pred_spans
+        return result
 
     viterbi_decode = viterbi   # name used by BASELINE.json's north star
 
@@ -513,7 +535,7 @@ class SemiMarkovModule(nn.Module):
                              "in the reference's lattice)")
 
     def _decode(self, features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                want_elp=False, want_labels=True, want_spans=True, no_eos=False):
+                want_elp=False, want_labels=True, want_spans=True, no_eos=False, spans_on_host=False):
         b, tmax, d = features.shape
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
@@ -532,7 +554,7 @@ class SemiMarkovModule(nn.Module):
                          tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
                          tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
                          class_map=tab['class_map'].view(1, -1), want_spans=want_spans, want_labels=want_labels,
-                         want_elp=want_elp)
+                         want_elp=want_elp, spans_on_host=spans_on_host)
         out['_batch'] = batch
         return out
 

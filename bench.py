@@ -449,7 +449,7 @@ def predict_end_to_end(model, data):
     return out
 
 
-def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=6):
+def host_features_leg(a, cfg, model, data, labels_ref, pc_ref, n_slabs=6):
     """The same decode with the features in HOST memory (the reference's flow: features loaded from disk
     into host memory, crosstask.py:95-112, every batch moved to the device, semimarkov.py:349-354): the corpus packed
     into pinned slabs once (untimed, the loader's job), then K timed passes of SemiMarkovModel.decode_host -- upload on a
@@ -462,7 +462,17 @@ def host_features_leg(a, cfg, model, data, labels_ref, n_slabs=6):
     frames = sum(pc.n_frames for pc in slabs)
     nbytes = sum(pc.x.numel() * 4 for pc in slabs)
     labels, _ = model.decode_host(slabs)                     # warm-up (buffers, workspaces)
-    same = bool(np.array_equal(labels.numpy(), labels_ref))
+    # per video: the slabs hold the batches longest-first (prepare_host), the resident corpus in the loader's order
+    ref_of = {(t, n): labels_ref[o:o + ln] for t, n, o, ln in zip(pc_ref.task_names, pc_ref.video_names, pc_ref.frame_offset,
+                                                                  pc_ref.lengths)}
+    got, off, n_vid = labels.numpy(), 0, 0
+    same = True
+    for s in slabs:
+        for t, n, o, ln in zip(s.task_names, s.video_names, s.frame_offset, s.lengths):
+            same = same and bool(np.array_equal(got[off + o:off + o + ln], ref_of[(t, n)]))
+            n_vid += 1
+        off += s.x.size(0)
+    same = same and n_vid == len(ref_of)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -871,7 +881,7 @@ def main():
         if world == 1 and not a.no_predict_e2e:
             res["predict_end_to_end"] = predict_end_to_end(model, data)
             try:
-                res["host_features"] = host_features_leg(a, cfg, model, data, lab)
+                res["host_features"] = host_features_leg(a, cfg, model, data, lab, pc)
             except Exception as e:
                 res["host_features"] = {"error": repr(e)}
             if a.workload == 'cfg3':

@@ -11,6 +11,7 @@
 #define SMM_BAND_LO 16
 #define SMM_BAND_N 8          // delayed bands
 #define SMM_BAND_ROW 1026      // doubles per state of the shifted state-major length table (row[k + 1] = len[k], k <= 1024)
+#define SMM_L0_ROW 130         // doubles per state of band 0's length table in LDS (ring distances 0..128 + padding)
 #define SMM_BAND_TAB 16       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 33..174, [m] max len over band m
 
 // One entry per video, built on the host by smm_plan() and staged into the workspace.
@@ -85,6 +86,7 @@ __device__ __forceinline__ double smm_dpp(double x)
 }
 
 #define SMM_DPP_ROW_SHR(n) (0x110 + (n))
+#define SMM_DPP_ROW_SHL(n) (0x100 + (n))   // lane i <- lane i + n of its row of 16
 #define SMM_DPP_WAVE_ROR1 0x13C
 #define SMM_DPP_ROW_BCAST15 0x142
 #define SMM_DPP_ROW_BCAST31 0x143

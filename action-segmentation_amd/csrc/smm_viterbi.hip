@@ -117,6 +117,12 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_PIPE0_ALWAYS
 #define SMM_PIPE0_ALWAYS 0
 #endif
+#ifndef SMM_DOM_SPARSE
+#define SMM_DOM_SPARSE 3   // BAND pushers (DOM): fewer unbeaten sources than this (besides the last) are pushed one by one from the LDS table
+#endif
+#ifndef SMM_HQ_ALWAYS
+#define SMM_HQ_ALWAYS 0    // 1 (A/B aid): the delayed sources are fetched in every block, as in round 3, whether a band is on or not
+#endif
 #ifndef SMM_B8_R
 #define SMM_B8_R 4       // blocks of 8 positions for the 256-slot rings (round 3, same box: cfg2 DP 0.481 -> 0.456 ms; the 64-slot
 #endif                   // rings of cfg4 measured 10 % SLOWER with them, 0.406 -> 0.445 ms, and keep blocks of 4)
@@ -358,6 +364,9 @@ smm_viterbi_kernel(SmmDpArgs a)
         if (junk_[(threadIdx.x + 1) & 7] == 123456789) a.err[5] = 1;
     }
 #endif
+#ifdef SMM_PROFILE
+    const unsigned long long p_kern0 = __builtin_readcyclecounter();   // (diagnostic: phases of workgroup 0 -> slots 44..46)
+#endif
     const int vid = a.order[blockIdx.x];
     SmmVideo mv = a.videos[vid];
     if (a.flags & 8) mv.T -= 1;               // no EOS: the DP covers the frames before the last one (smmdp.h)
@@ -393,6 +402,11 @@ smm_viterbi_kernel(SmmDpArgs a)
     __shared__ __attribute__((aligned(16))) double sh_gh[2][B][SMM_MAX_STATES_DEV][2];
     __shared__ __attribute__((aligned(16))) double sh_e[2][B][SMM_MAX_STATES_DEV];       // elp[n-1][c] HBM -> chain
     __shared__ double sh_hm[BAND ? SN : 1][BAND ? 64 : 1];   // band mode: max h per group of 16 sources, ring of 64 groups
+    // band mode: band 0's length ring as a TABLE (see DOM in the pusher waves): sh_l0[c][kr] = len[kr][c] for the ring
+    // distances kr band 0 owns, -inf elsewhere (entry 128 = entry 0: the pair of a lane whose first slot is at distance 127),
+    // and per state how far h must RISE from one source to the next for the older one to be beaten at every target
+    __shared__ __attribute__((aligned(16))) double sh_l0[BAND ? SN : 1][BAND ? SMM_L0_ROW : 1];
+    __shared__ double sh_xd[BAND ? SN : 1];
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV][2]; // where the chain wave's other lane groups store
@@ -434,6 +448,30 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_tr[e] = (to < C && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
         }
     }
+    if constexpr (BAND) {
+        constexpr int KMIN0 = TRI ? B + D + 1 : 2 * B + D;                 // band 0's shortest length (the chain wave owns the rest)
+        const int khi = (kp - 1 < 127) ? kp - 1 : 127;
+        for (int e = threadIdx.x; e < SN * SMM_L0_ROW; e += blockDim.x) {
+            const int c = e / SMM_L0_ROW, kr = e % SMM_L0_ROW;
+            sh_l0[c][kr] = (c < C && kr >= KMIN0 && kr <= khi) ? len[(size_t)kr * cm + c] : SMM_NEG_INF;
+        }
+        // DOM (see the pusher waves): X_c = max over band 0's lengths of len[k][c] - len[k-1][c], clipped at 0 and pushed
+        // a part in 2^49 up.  h[s+1][c] - h[s][c] > X_c (both differences rounded once: relative error 2^-53 each) then
+        // implies h[s][c] + len[k][c] <= h[s+1][c] + len[k-1][c] in real arithmetic for every length of the band, hence
+        // -- rounding is monotone -- for the rounded sums the maxima are made of.  A length the table does not reach
+        // (-inf) asks for nothing; one whose predecessor is -inf can never be granted (+inf).
+        for (int c = w; c < SN; c += NW) {
+            double x = SMM_NEG_INF;
+            if (c < C)
+                for (int k = KMIN0 + lane; k <= khi; k += 64) {
+                    const double la = len[(size_t)k * cm + c], lb = len[(size_t)(k - 1) * cm + c];
+                    if (la != SMM_NEG_INF) x = fmax(x, la - lb);
+                }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+            if (lane == 0) sh_xd[c] = fmax(x, 0.0) * (1.0 + 0x1p-49);
+        }
+    }
     __syncthreads();
     if constexpr (SPEC) {
         // dl[cs][c] = min over targets of (trans[to][cs] - trans[to][c]), clipped at 0 and pushed one part in 2^50 further
@@ -457,6 +495,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     }
     __syncthreads();
 
+#ifdef SMM_PROFILE
+    const unsigned long long p_kern1 = __builtin_readcyclecounter();
+#endif
     // The chain wave touches LDS only (a wave that waits for a load waits for its older stores as well: vmcnt is one
     // in-order counter).  HBM traffic is moved block-wise by pusher wave MW: it fetches the elp rows two blocks ahead
     // (registers for one block, then LDS) and stores cumE, h and gamma a block after the chain wave produced them.
@@ -810,7 +851,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         const double *lent = a.len_t + (size_t)g * cm * SMM_BAND_ROW;       // [c][k + 1]: a state's lengths are contiguous
         const double *btab = a.band_tab + (size_t)g * cm * SMM_BAND_TAB;
         const bool bound_ok = kp - 1 >= 32 + 15 + 127;                       // the lower bound's witness needs lengths up to 174
-        double As[SPS][RS], L0[SPS][RS];
+        double As[SPS][RS];
         // The rows a wave pushes (its states' h of the block, B x SPS values) come from LDS with ONE read per 16 values:
         // lane e % 16 of every row of register e / 16 holds element e = B js + i, and a push broadcasts its source along
         // the rows (smm_row_bcast).  Every lane reading every value (a ds_read2_b64 per state and pair of rows) was 16
@@ -823,23 +864,34 @@ smm_viterbi_kernel(SmmDpArgs a)
         constexpr int BPG = 16 / B;
         constexpr int UBB = UB;                                              // blocks per iteration of the block loop (one group)
         static_assert(!BAND || (UB == BPG && K0 < SMM_BAND_LO), "a group is one unrolled iteration of the block loop");
+        // DOM: SOURCE DOMINANCE in band 0.  Candidate (s, k) and candidate (s + 1, k - 1) aim at the same target, so the
+        // source s need not be pushed for state c when h[s+1][c] - h[s][c] > X_c (sh_xd, see the prologue): its successor
+        // beats it at every target band 0 reaches -- and the successor's candidate IS evaluated, by a pusher or, at
+        // k - 1 = B, by the chain wave; the relation is transitive along the block, whose last source is always pushed.
+        // max is exact and the test is one-sided, so not a bit of A changes; what changes is the work: h = gamma - cumE of
+        // a state that does not explain the current frames RISES by the margin of the state that does, frame after frame
+        // (tens of nats on real features, X_c is a few), so on CrossTask-shaped data all but the leading state push ONE
+        // source per block instead of eight (scripts/probe_dominance.py: 1.65 of 8 on cfg3; flat lattices: all of them,
+        // as before).  The price: a state's length ring can no longer live in rotating registers (a skipped push would
+        // still have to rotate it); it is read from LDS at the phase of every push that happens (sh_l0: 16 bytes per lane).
+        static_assert(!BAND || D == 0, "DOM: the block's own sources, all of them in the rows read at its start");
         int hoff[NHR];
-        double hvp[NHR];                                                     // the previous block's rows (D = 1: its last row is pushed first)
+        double xdom[NHR];                                                    // lane = element (state, source): the state's X_c
 #pragma unroll
         for (int r = 0; r < NHR; ++r) {
             const int e = 16 * r + (lane & 15), ejs = e / B, ec = ejs * NPS + rank;
             hoff[r] = ((e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0)) * 2 + 1;   // (the h half of the (gamma, h) pairs)
-            hvp[r] = SMM_NEG_INF;
+            xdom[r] = sh_xd[BAND ? ((ejs < SPS && ec < C) ? ec : 0) : 0];
         }
+        uint32_t npush = 0;                                                  // (diagnostic: sources this wave pushed into band 0)
         unsigned long long mcur = 0, mnext = 0;          // bit 8 js + m - 1: band m of the wave's js-th state is switched on for the
                                                          // current group / for the next one, once decided
         const int nvw = (rank < C) ? ((C - 1 - rank) / NPS + 1 < SPS ? (C - 1 - rank) / NPS + 1 : SPS) : 0;   // states of this wave
         uint32_t nact = 0;                                                   // (diagnostic: delayed band-blocks this wave pushed)
 #pragma unroll
         for (int js = 0; js < SPS; ++js) {
-            const int c = js * NPS + rank;
-            const int kshort = (kp - 1 < 127) ? kp - 1 : 127;
-            smm_ring_init_range<RS>(As[js], L0[js], len + c, cm, B + D, TRI ? B + 1 : 2 * B + D, kshort, c < C, lane);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) As[js][r] = SMM_NEG_INF;
         }
         // The skip test.  The mover wave keeps max h over every group of 16 sources, one lane per state (ring sh_hm);
         // every pusher decides the bands of its own states, lane q = 8 js + (m - 1) for (state js, band m), in the block
@@ -910,23 +962,76 @@ smm_viterbi_kernel(SmmDpArgs a)
                     dsrc = qhm[(dG - 7 * qm) & 63];
                     dwit = qhm[(dG - 2) & 63];
                 }
-                // D = 1: the first source of every state is the previous block's last row: registers, no wait for LDS
-                if constexpr (D == 1 && !(SMM_ABLATE & 4)) {
+                // the ring distance of this lane's first slot at the push of the block's LAST source (i = B - 1); source i: + B - 1 - i
+                const int kr_last = (2 * lane + 1 + D - j * B) & 127;
+                // ... and the ring pairs of those pushes -- every state pushes its last source --, read with the rows
+                double2 lpl[SPS];
+#pragma unroll
+                for (int js = 0; js < SPS; ++js) {
+                    const double *l0row = &sh_l0[BAND ? ((js < nvw) ? js * NPS + rank : 0) : 0][0];
+                    lpl[js] = make_double2(l0row[kr_last], l0row[kr_last + 1]);
+                }
+                // DOM: which sources have to be pushed -- bit e = 8 js + i of keep[e / 16]: source i of the wave's js-th state is
+                // not known to be beaten by its successor (lane e: h of the successor from the lane above, one compare)
+                uint32_t keep[NHR], extra = 0;
+#pragma unroll
+                for (int r = 0; r < NHR; ++r) {
+                    const double nx = smm_dpp<SMM_DPP_ROW_SHL(1)>(hvl[r]);         // (the row's last lane keeps its own: a last source)
+                    const unsigned long long dom = (SMM_ABLATE & 1024) ? 0ull : __ballot(nx - hvl[r] > xdom[r]);
+                    keep[r] = (uint32_t)~dom & 0x7f7fu;                            // (the last sources: pushed anyway, below)
+                    extra |= keep[r];
+                }
+                if constexpr (!(SMM_ABLATE & 4)) {
+                    // the last source of every state (straight-line; a wave with fewer states pushes into accumulators nobody reads)
 #pragma unroll
                     for (int js = 0; js < SPS; ++js) {
-                        if (js * NPS + rank >= C) break;
-                        smm_push<RS>(As[js], L0[js], smm_row_bcast(hvp[(B * js + B - 1) / 16], (B * js + B - 1) % 16), (jj * B) % RS);
+                        const double hs = src_row(js, B - 1);
+                        As[js][0] = smm_fmax(As[js][0], hs + lpl[js].x);
+                        As[js][1] = smm_fmax(As[js][1], hs + lpl[js].y);
+                    }
+                    npush += nvw;
+                    // the others that are not beaten: none for most states in most blocks
+                    if (__builtin_expect(extra != 0, 0)) {
+#pragma unroll
+                        for (int js = 0; js < SPS; ++js) {
+                            if (js >= nvw) break;
+                            const uint32_t k7 = (keep[(B * js) / 16] >> ((B * js) % 16)) & 0x7fu;
+                            if (k7 == 0) continue;
+                            const double *l0row = &sh_l0[BAND ? js * NPS + rank : 0][0];
+                            if (__builtin_popcount(k7) < SMM_DOM_SPARSE) {
+                                // a few: ring pair from the table at the push's phase
+                                uint32_t rest = k7;
+                                npush += __builtin_popcount(rest);
+                                while (rest) {
+                                    const int i = __builtin_ctz(rest);
+                                    rest &= rest - 1;
+                                    const int kr = (kr_last + B - 1 - i) & 127;
+                                    const double2 lp = make_double2(l0row[kr], l0row[kr + 1]);
+                                    const double hs = smm_readlane(hvl[(B * js) / 16], (B * js) % 16 + i);
+                                    As[js][0] = smm_fmax(As[js][0], hs + lp.x);
+                                    As[js][1] = smm_fmax(As[js][1], hs + lp.y);
+                                }
+                            } else {
+                                // most of them (the state that leads; any state of a flat lattice): the ring at the phase of the
+                                // block's first push, rotated in registers from source to source (smm_push), the sources before
+                                // the last one pushed -- one that is beaten is still a candidate like any other
+                                double Lr[RS];
+                                const int kr0 = (kr_last + B - 1) & 127;
+                                Lr[0] = l0row[kr0];
+                                Lr[1] = l0row[kr0 + 1];
+                                npush += B - 1;
+#pragma unroll
+                                for (int i = 0; i < B - 1; ++i)
+                                    smm_push<RS>(As[js], Lr, src_row(js, i), (jj * B + i) % RS);
+                            }
+                        }
                     }
                 }
+                if (__builtin_expect(mcur != 0, 0)) {
 #pragma unroll
                 for (int js = 0; js < SPS; ++js) {
                     const int c = js * NPS + rank;
                     if (js >= nvw) break;
-                    if constexpr (!(SMM_ABLATE & 4)) {
-#pragma unroll
-                        for (int i = D; i < B; ++i)
-                            smm_push<RS>(As[js], L0[js], src_row(js, i - D), (jj * B + i) % RS);
-                    }
                     const uint32_t act_js = (uint32_t)(mcur >> (8 * js)) & 0xffu;
                     if (__builtin_expect(act_js != 0, 0)) {
                         // the bands that are switched on (rarely any): their rings at this block's phase come from the table
@@ -963,6 +1068,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                             m = mn;
                         }
                     }
+                }
                 }
                 // hand A' of block j+1 to the chain wave and clear those slots (the B slots are all registers of B/RS lanes) --
                 // for all of the wave's states under ONE exec mask (a masked region per state was two branches per state)
@@ -1023,7 +1129,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                 // Issued in EVERY block, after the ring loads, whether a band is on or not: the wave's loads complete in
                 // order and a wait can only name a count, so the wait for the next block's rings must know that exactly
                 // these B loads are younger -- behind a branch the compiler has to wait for everything.
-                if constexpr (!(SMM_ABLATE & 64)) {
+                if (!(SMM_ABLATE & 64) && (SMM_HQ_ALWAYS || lanes2 != 0)) {
                     const bool mine = (lanes2 >> lane) & 1ull;
                     const int s0 = (j + 1) * B + 1 - SMM_BAND_DELAY * qm;
                     // (s0 in 1-B .. -1: the words before the row are read and masked below -- a video with a band switched
@@ -1038,8 +1144,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                             if (s0 + i < 0) hq[ph][i] = SMM_NEG_INF;
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < NHR; ++r) hvp[r] = hvl[r];
                 }
                 SMM_LDS_BARRIER();                               // end of block j
             }
@@ -1047,6 +1151,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         SMM_PROF_OUT();
         if (w == MW) (void)mover_step(J, J & 1, false);                       // the last block's history
         if (lane == 0 && nact) atomicAdd(a.err + 3, (int)nact);             // error block word 3: see ops.error_words
+        if (lane == 0 && npush) atomicAdd(a.err + 2, (int)npush);           // ... and word 2: sources pushed into band 0
 #ifdef SMM_PROFILE
         if (lane == 0 && blockIdx.x == 0 && w != MW && w < 7) reinterpret_cast<unsigned long long *>(a.err)[w < MW ? w + 1 : w] = nact;   // slots 2..6: workgroup 0's waves 1, 2, 3, 5, 6
 #endif
@@ -1107,6 +1212,9 @@ smm_viterbi_kernel(SmmDpArgs a)
     // -------------------------------------------------------------------------------- last position
     // sh_gfin holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
+#ifdef SMM_PROFILE
+    const unsigned long long p_kern2 = __builtin_readcyclecounter();
+#endif
     const bool no_eos = (a.flags & 8) != 0;    // add_eos=False: T counts the frames before the last one (see smmdp.h)
     if (w == 0) {
         double f = SMM_NEG_INF;
@@ -1328,6 +1436,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.err);
         pp[40] = bt_a; pp[41] = bt_b; pp[42] = bt_c; pp[43] = (unsigned long long)nseg;
+        pp[44] = p_kern1 - p_kern0; pp[45] = p_kern2 - p_kern1; pp[46] = __builtin_readcyclecounter() - p_kern2;
     }
 #endif
     if (a.n_segs && threadIdx.x == 0) a.n_segs[vid] = nseg + (no_eos ? 1 : 0);

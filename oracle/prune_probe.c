@@ -265,3 +265,72 @@ int smm_band_probe2(const double *elp, int t, int c, const double *trans, const 
     free(cum); free(h); free(gam); free(hmax);
     return 0;
 }
+
+/* Round 4: SOURCE DOMINANCE inside band 0.  The pushers push the 8 sources of a hand-over block into the ring with the
+ * lengths 9..127.  Candidate (s, k) and candidate (s + 1, k - 1) aim at the same target, so source s need not be pushed
+ * for state c when  h[s+1][c] - h[s][c] >= X_c = max_{9 <= k <= 127} (len[k][c] - len[k-1][c])  (its successor beats it
+ * at every target, and the successor's candidate is evaluated by a pusher or -- k - 1 = 8 -- by the chain wave); the
+ * relation is transitive along the block and the block's last source is always pushed.
+ * out[0] = (state, block) pairs, out[1] = sources pushed with the successor test, out[2] = sources in all,
+ * out[3] = (state, block) pairs that push only the last source, out[4] = blocks, out[5] = sum over blocks of the
+ * largest per-state push count (the leader), out[6] = pushed with the test against EVERY later source of the block
+ * (X_c(d) = max_k len[k] - len[k-d]).
+ */
+int smm_dom_probe(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                  double *out)
+{
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    if (!cum || !h || !gam) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    const int khi = (kp - 1 < 127) ? kp - 1 : 127;
+    for (int j0 = 0; j0 * 8 + 1 <= t; ++j0) {
+        int worst = 0;
+        out[4] += 1.0;
+        for (int j = 0; j < c; ++j) {
+            double x[8];
+            for (int d = 1; d < 8; ++d) {
+                x[d] = -INFINITY;
+                for (int k = 9; k <= khi; ++k) {
+                    if (len[(size_t)k * c + j] == -INFINITY) continue;
+                    x[d] = dmax(x[d], len[(size_t)k * c + j] - len[(size_t)(k - d) * c + j]);
+                }
+                if (x[d] < 0) x[d] = 0;
+            }
+            int pushed = 0, pushed_any = 0, nsrc = 0;
+            for (int i = 0; i < 8; ++i) {
+                const int s = j0 * 8 + 1 + i;
+                if (s > t) break;
+                ++nsrc;
+                int dom = 0, dom_any = 0;
+                if (i < 7 && s + 1 <= t) dom = h[(size_t)(s + 1) * c + j] - h[(size_t)s * c + j] > x[1];
+                for (int d = 1; i + d < 8 && s + d <= t; ++d)
+                    if (h[(size_t)(s + d) * c + j] - h[(size_t)s * c + j] > x[d]) dom_any = 1;
+                pushed += !dom;
+                pushed_any += !dom_any;
+            }
+            out[0] += 1.0; out[1] += pushed; out[2] += nsrc; out[6] += pushed_any;
+            if (pushed <= 1) out[3] += 1.0;
+            if (pushed > worst) worst = pushed;
+        }
+        out[5] += worst;
+    }
+    free(cum); free(h); free(gam);
+    return 0;
+}

@@ -1,0 +1,16 @@
+# round 4: BAND-only variant libraries: parity tests of the K > 512 kernels through the FIRST tag, timings of all, segment stamps
+# usage: gpurun -- 'bash scripts/gpu_r4_l.sh "<tags to time>" "<prof tags>"'
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+first=${1%% *}
+SMM_LIB_PATH=$PWD/action-segmentation_amd/libsmmdp_$first.so timeout -k 10 600 python -m pytest tests/test_gpu_viterbi.py -m gpu -q -x -k "band_mode or long_segment or 24_to_32 or 22_23 or masked" > gpurun_out/r4l_tests.txt 2>&1; rc=$?
+tail -3 gpurun_out/r4l_tests.txt; echo "tests rc=$rc"
+if [ $rc -ne 0 ]; then exit $rc; fi
+( timeout -k 10 300 python scripts/time_variants.py $1
+  for c in 23 11; do for lib in $2; do SMM_ONLY_BAND=1 SMM_PROF_SEG=1 timeout -k 10 200 python -c "
+import sys; sys.path.insert(0,'scripts'); sys.path.insert(0,'.')
+import os; os.environ['SMM_BAND']='1'
+import prof_band
+print('== $lib'); prof_band.run(64, 4096, $c, 1024, 'libsmmdp_$lib.so')
+"; done; done
+  timeout -k 10 300 python scripts/prof_cfg3.py $1 ) 2>&1 | grep -v "amdgpu.ids\|wave  *[89] \|wave 1[0-5]\|pass 0" > gpurun_out/r4l.txt
+cat gpurun_out/r4l.txt

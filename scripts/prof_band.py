@@ -49,6 +49,9 @@ def run(b, T, C, K, lib='libsmmdp_prof16.so'):
     print(f"b={b} T={T} C={C} K={K}: {e0.elapsed_time(e1):.3f} ms = {e0.elapsed_time(e1) * 1e6 / T:.0f} ns/frame; band-blocks evaluated "
           f"{raw.view(np.int32)[3]} of {b * (T // (4 if os.environ.get('SMM_BAND_B') == '4' else 8)) * C * 8}; cycles per block (busy / in barrier) by wave:")
     if nblk:
+        if pp[45]:
+            print('   workgroup 0, cycles: prologue %d | forward %d (%.0f per block) | closing + back-trace %d (%d segments; phase A %d, phase B %d, labels %d)'
+                  % (pp[44], pp[45], pp[45] / nblk, pp[46], pp[43], pp[40], pp[41], pp[42]))
         if pp[34]:
             print("   chain wave of workgroup 0: %d of %d positions took the fast (speculated) transition" % (pp[34], T))
         for w in range(16):
@@ -60,6 +63,9 @@ def run(b, T, C, K, lib='libsmmdp_prof16.so'):
                     cnt = [raw4[0] & 0xfffff] + raw4[1:]
                     tot = raw4[0] >> 20
                     extra = '  last in %5d blocks (by j mod 4: %s), mean busy then %5.0f' % (pp[16 + w], ' '.join('%4d' % c for c in cnt), tot / max(1, pp[16 + w]))
+                elif w < 8 and pp[32 + 4 * w] and os.environ.get('SMM_PROF_SEG'):
+                    # -DSMM_PROFILE=3: the BAND pushers' block in segments: rows + dominance test | pushes | hand-over | decisions + loads
+                    extra = '  segments: %s' % ' '.join('%5.0f' % (pp[32 + 4 * w + ph] / nblk) for ph in range(4))
                 elif w < 8 and pp[32 + 4 * w]:
                     extra = '  longest %6.0f  busy by j mod 4: %s' % (pp[16 + w], ' '.join('%5.0f' % (pp[32 + 4 * w + ph] / (nblk / 4)) for ph in range(4)))
                 print("   wave %2d  busy %6.0f  barrier %6.0f%s" % (w, pp[8 + w] / nblk, pp[24 + w] / nblk, extra))

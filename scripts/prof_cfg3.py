@@ -40,6 +40,9 @@ for tag in sys.argv[1:]:
     print('%s: DP kernel %.3f ms (min %.3f); delayed band-blocks evaluated %d of %d (%.2f %%)%s'
           % (tag, float(np.mean(ms)), min(ms), raw.view(np.int32)[3], tot, 100.0 * raw.view(np.int32)[3] / tot, same))
     nblk = pp[7]
+    if nblk and pp[45]:
+        print('   workgroup 0, cycles: prologue %d | forward %d (%.0f per block) | closing + back-trace %d (%d segments; phase A %d, phase B %d, labels %d)'
+              % (pp[44], pp[45], pp[45] / nblk, pp[46], pp[43], pp[40], pp[41], pp[42]))
     if nblk:
         print('   workgroup 0: %d blocks; delayed band-blocks of its waves 1 2 3 5 6: %s' % (nblk, ' '.join('%d' % pp[k] for k in range(2, 7))))
         if pp[34]:

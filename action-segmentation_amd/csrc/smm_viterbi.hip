@@ -1028,47 +1028,44 @@ smm_viterbi_kernel(SmmDpArgs a)
                     }
                 }
                 if (__builtin_expect(mcur != 0, 0)) {
-#pragma unroll
-                for (int js = 0; js < SPS; ++js) {
-                    const int c = js * NPS + rank;
-                    if (js >= nvw) break;
-                    const uint32_t act_js = (uint32_t)(mcur >> (8 * js)) & 0xffu;
-                    if (__builtin_expect(act_js != 0, 0)) {
-                        // the bands that are switched on (rarely any): their rings at this block's phase come from the table
-                        // -- the first two of the wave were fetched during the previous block (below), like their sources:
-                        // a table row costs an L2 round trip, and a pusher that waits for one makes the whole block wait
-                        const double *lrow = lent + (size_t)c * SMM_BAND_ROW;
-                        const int off = (B + D - j * B) & 127;
-                        auto ring = [&](double (&Lr)[RS], int m_) {      // the wave's pk-th pair of this block
-                            if (pk < npre) {                             // (wave-uniform: scalar branches)
-#pragma unroll
-                                for (int k = 0; k < NPRE; ++k)
-                                    if (pk == k) { Lr[0] = Lp[k][0]; Lr[1] = Lp[k][1]; }
-                            } else {
-                                smm_band_ring_load(Lr, lrow, off, m_, kp, lane);
-                            }
-                            ++pk;
-                        };
-                        uint32_t mm = act_js;
-                        nact += __builtin_popcount(mm);
-                        int m = __builtin_ctz(mm) + 1;
+                    // The bands that are switched on (rarely any, and then nearly always bands of ONE state: the one whose long
+                    // segment is running).  ONE loop over the wave's (state, band) pairs q = 8 js + m - 1, ascending -- not a
+                    // copy of the push code per state: a pair pushes its B sources into a fresh accumulator pair, which is then
+                    // folded into the state's own (max is associative and exact: the same bits).  Round 3 had the loop once per
+                    // state inside the unrolled block: four copies whose scalar registers the compiler spilled to lanes -- 130
+                    // instructions per pair for 48 that push, and the wave that owns the running state was the one the block
+                    // barrier waited for in most blocks of a long video (profiles/round4_*).
+                    // Rings at this block's phase: the first NPRE pairs were fetched during the previous block (below), like the
+                    // sources: a table row costs an L2 round trip.
+                    const int off = (B + D - j * B) & 127;
+                    unsigned long long rest = mcur;
+                    nact += __builtin_popcountll(rest);
+                    do {
+                        const int q = __builtin_ctzll(rest);
+                        rest &= rest - 1;
+                        const int bjs = q >> 3, m = (q & 7) + 1;
                         double Lm[RS];
-                        ring(Lm, m);
-                        while (true) {
-                            mm &= mm - 1;
-                            const int mn = mm ? __builtin_ctz(mm) + 1 : 0;
-                            double Ln[RS];
-                            if (mn) ring(Ln, mn);                                         // in flight while band m is pushed
-                            const int q = js * 8 + m - 1;
+                        if (pk < npre) {                                 // (wave-uniform: scalar branches)
 #pragma unroll
-                            for (int i = 0; i < B; ++i)
-                                smm_push<RS>(As[js], Lm, smm_readlane(hq[ph][i], q), (jj * B + i) % RS);
-                            if (!mn) break;
-                            Lm[0] = Ln[0]; Lm[1] = Ln[1];
-                            m = mn;
+                            for (int k = 0; k < NPRE; ++k)
+                                if (pk == k) { Lm[0] = Lp[k][0]; Lm[1] = Lp[k][1]; }
+                        } else {
+                            smm_band_ring_load(Lm, lent + (size_t)(bjs * NPS + rank) * SMM_BAND_ROW, off, m, kp, lane);
                         }
-                    }
-                }
+                        ++pk;
+                        double At[RS];
+                        At[0] = ninf; At[1] = ninf;
+#pragma unroll
+                        for (int i = 0; i < B; ++i)
+                            smm_push<RS>(At, Lm, smm_readlane(hq[ph][i], q), (jj * B + i) % RS);
+#pragma unroll
+                        for (int js = 0; js < SPS; ++js) {
+                            if (bjs == js) {
+                                As[js][0] = smm_fmax(As[js][0], At[0]);
+                                As[js][1] = smm_fmax(As[js][1], At[1]);
+                            }
+                        }
+                    } while (rest);
                 }
                 // hand A' of block j+1 to the chain wave and clear those slots (the B slots are all registers of B/RS lanes) --
                 // for all of the wave's states under ONE exec mask (a masked region per state was two branches per state)

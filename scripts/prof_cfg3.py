@@ -49,7 +49,13 @@ for tag in sys.argv[1:]:
             print('   chain wave of workgroup 0: %d positions took the fast (speculated) transition' % pp[34])
         for w in range(8):
             extra = ''
-            if os.environ.get('SMM_PROF_LAST'):
+            if os.environ.get('SMM_PROF_CLS'):
+                # -DSMM_PROFILE=4: a pusher's busy cycles by class of block
+                r4 = [pp[32 + 4 * w + ph] for ph in range(4)]
+                mx = int(pp[16 + w])
+                extra = '  blocks without a delayed band: %5d, busy %5.0f | with: %5d, busy %5.0f | with a state that pushed most sources: %5d, busy %5.0f' % (
+                    r4[1], r4[0] / max(1, r4[1]), r4[3], r4[2] / max(1, r4[3]), mx & 0xfffff, (mx >> 20) / max(1, mx & 0xfffff))
+            elif os.environ.get('SMM_PROF_LAST'):
                 raw4 = [int(pp[32 + 4 * w + ph]) for ph in range(4)]
                 cnt = [raw4[0] & 0xfffff] + raw4[1:]
                 extra = '  last in %5d blocks (by j mod 4: %s), mean busy then %5.0f' % (pp[16 + w], ' '.join('%4d' % c for c in cnt), (raw4[0] >> 20) / max(1, pp[16 + w]))

@@ -1061,6 +1061,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                         for (int js = 0; js < SPS; ++js) {
                             if (bjs == js) {
+                                asm volatile("");   // (a real branch: not SPS x 4 conditional moves that every pair executes)
                                 As[js][0] = smm_fmax(As[js][0], At[0]);
                                 As[js][1] = smm_fmax(As[js][1], At[1]);
                             }

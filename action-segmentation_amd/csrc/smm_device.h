@@ -39,7 +39,7 @@ struct SmmDpArgs {
     int64_t *labels;           // [total_frames] or null
     double *best;              // [b] or null
     int32_t *n_segs;           // [b] or null
-    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1], [2] always 0 (rounds 1-3: gang time-outs / repairs);
+    int32_t *err;              // [0] sticky error flag (NaN in the inputs); [1] always 0 (rounds 1-3: gang time-outs); [2] Viterbi BAND mode, diagnostic: sources pushed into band 0;
                                // [3] Viterbi BAND mode, diagnostic: delayed band-blocks (the sources of one hand-over block, 8 or under SMM_BAND_B=4 4, x one band of one state) evaluated
     int32_t c_max, k_rows, t_max, b;
     int32_t flags;             // bit 0: profiling only, -DSMM_DEV builds -- stop after the forward pass (outputs undefined);

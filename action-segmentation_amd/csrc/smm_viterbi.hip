@@ -267,7 +267,9 @@ __device__ __forceinline__ double smm_ld_agent(const double *p)
 //              over changes targets; with blocks of 8 the slots within 15 of the current source have been, and a band's
 //              own lengths never come that close).
 // The accumulators A are shared by the bands of a state (all of them aim at the same 128 targets): 2 registers per
-// state for A, 2 for band 0's length ring, none for the delayed bands.
+// state for A and none for the length rings -- band 0's comes from an LDS table at the phase of every push that happens
+// (round 4: a source that its successor beats at every target is not pushed at all, see DOM in the pusher waves), the
+// delayed bands' from the state-major table in L2.
 // Blocks are 8 positions and the pushers push the block's own 8 sources (B = 8, D = 0): half as many block barriers as
 // with blocks of 4, and the barrier is where a block's slowest wave makes the other seven wait.
 //

@@ -362,7 +362,7 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 16].view(torch.int32)      # [error, 0, 0, band-blocks evaluated]
+    return ws[off:off + 16].view(torch.int32)      # [error, 0, band-0 sources pushed, band-blocks evaluated]
 
 
 def _err_copy(batch, ws):
@@ -382,8 +382,9 @@ def error_flag(batch, out=None, ws=None):
 
 
 def error_words(batch, out=None, ws=None):
-    """[error word, 0, 0, delayed band-blocks evaluated (a diagnostic of the Viterbi kernel's BAND mode:
-    smm_viterbi.hip)] of a decode (synchronises).  (Words 1 and 2 counted gang time-outs in rounds 1-3.)"""
+    """[error word, 0, sources pushed into band 0, delayed band-blocks evaluated (words 2 and 3: diagnostics of the Viterbi
+    kernel's BAND mode, smm_viterbi.hip: DOM and the band skip test)] of a decode (synchronises).  (Words 1 and 2 counted gang
+    time-outs in rounds 1-3.)"""
     if out is not None and out.get('_err') is not None:
         return [int(v) for v in out['_err'].tolist()]
     if ws is None:

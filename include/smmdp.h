@@ -101,8 +101,9 @@ size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
 
 /* Byte offset, inside the workspace, of the int32 error word the kernels set.  1: a NaN / inf-inf reached the DP of
  * some video and its decode stopped early.  It is cleared at the start of every call.  Returns 0 on invalid shape.
- * (The two int32 words behind it are always 0: rounds 1-3 counted the time-outs of multi-workgroup "gangs" there, which
- * no longer exist; the fourth word is a diagnostic of the Viterbi kernel's BAND mode.) */
+ * (The int32 word behind it is always 0: rounds 1-3 counted the time-outs of multi-workgroup "gangs" there, which no
+ * longer exist; the third and fourth words are diagnostics of the Viterbi kernel's BAND mode: sources pushed into
+ * band 0, delayed band-blocks evaluated.) */
 size_t smm_error_word_offset(const smm_shape *shape);
 
 /*

@@ -652,10 +652,54 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         assert frac < 0.12, frac                       # (long videos: ~1-3 %; the first 1000 frames of a video cost the most)
     elif kind == 'flat':
         assert frac > 0.5, frac
+    # ... and word 2: sources pushed into band 0, of frames x states (round 4, source dominance: a source that its successor
+    # beats at every target is left out -- nearly all of them where one state explains the frames, hardly any on a flat lattice)
+    if blk == 8 and c <= 24:
+        pushed = out['_err'][2] / (sum(int(t) for t in lengths) * c)
+        if kind == 'structured':
+            assert 0.125 <= pushed < 0.4, pushed         # (one source per state and block at least: the last one)
+        elif kind == 'flat':
+            assert pushed > 0.9, pushed
     monkeypatch.setenv('SMM_SPEC', '0')
     full = run_gpu(p)
     for key in ('best', 'spans', 'labels', 'n_segs'):
         np.testing.assert_array_equal(out[key], full[key])
+
+
+RAMP_SHAPES = [([1700, 900], 7, 1024), ([2500], 23, 1024), ([1300, 1290, 140], 14, 700)]
+
+
+@pytest.mark.parametrize('shape', RAMP_SHAPES)
+@pytest.mark.parametrize('slope', [-30.0, -0.5, 0.0, 0.5, 30.0])
+@pytest.mark.parametrize('integer', [False, True])
+def test_viterbi_band_source_dominance_on_ramps(shape, slope, integer, monkeypatch):
+    """The BAND pushers leave a source out of band 0 when its successor beats it at every target: h[s+1] - h[s] > X_c with
+    X_c = max_k (len[k] - len[k-1]) over the band's lengths (smm_viterbi.hip, DOM).  Length tables that are RAMPS put the
+    threshold wherever the test wants it: a steeply rising table (X_c = 30: nothing is ever beaten, every source is pushed),
+    a flat or falling one (X_c = 0: every source below its successor is left out), gentle slopes in between -- on
+    CrossTask-like emissions, whose h rises by ~18 per frame for the states that do not explain the frame, and on integer
+    emissions and tables, where h[s+1] - h[s] == X_c happens all the time (the test is strict: equal is pushed).  Bit for
+    bit against the C twin either way."""
+    lengths, c, k = shape
+    monkeypatch.delenv('SMM_SPEC', raising=False)
+    p = structured_problem(hash((tuple(lengths), c, slope)) % 1000 + 3, lengths, c, k)
+    g = np.random.default_rng(5)
+    kk = np.arange(k)[:, None]
+    p['lens'] = slope * kk + g.uniform(-3.0, 3.0, size=(1, c)) + np.zeros((k, c))
+    if integer:
+        p['elp'] = np.round(p['elp'])
+        p['lens'] = np.round(p['lens'])
+        p['trans'] = np.round(p['trans'])
+        p['init'] = np.round(p['init'])
+    out = run_gpu(p)
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    assert out['_err'][0] == 0
+    pushed = out['_err'][2] / (sum(int(t) for t in lengths) * c)
+    if slope >= 30.0:
+        assert pushed > 0.95, pushed                     # X_c = 30 or more: h never rises that fast, every source is pushed
+    elif slope <= 0.0 and not integer:
+        assert pushed < 0.45, pushed
 
 
 def masked_problem(seed, lengths, c, k, neg_inf=False):

@@ -11,13 +11,8 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             if 'smm_' not in name or row.get('Counter_Name') != ctr:
                 continue
             key = name.split('(')[0].replace('void ', '')
-            # the DP kernel's recovery launches (template argument PAIR = 0 behind a gang launch: two empty grids per
-            # decode) are their own rows; everything else is keyed without template arguments
-            # (PAIR = 1: gang launch, PAIR = 2: BAND mode -- the main DP kernels)
-            if key.startswith('smm_viterbi_kernel') and not key.rstrip('>').endswith((', 1', ', 2')):
-                key = 'smm_viterbi_kernel (recovery / non-gang launches)'
-            else:
-                key = key.split('<')[0]
+            # (rounds 1-3: the recovery launches behind a gang launch were rows of their own; round 4 has neither)
+            key = key.split('<')[0]
             res.setdefault(key, {}).setdefault(ctr, []).append(float(row['Counter_Value']))
 out = {}
 for k, v in res.items():

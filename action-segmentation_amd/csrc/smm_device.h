@@ -12,7 +12,10 @@
 #define SMM_BAND_N 8          // delayed bands
 #define SMM_BAND_ROW 1026      // doubles per state of the shifted state-major length table (row[k + 1] = len[k], k <= 1024)
 #define SMM_L0_ROW 130         // doubles per state of band 0's length table in LDS (ring distances 0..128 + padding)
-#define SMM_BAND_TAB 16       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 33..174, [m] max len over band m
+#define SMM_BAND_TAB 80       // doubles per (group, state) in SmmDpArgs::band_tab: [0] min len over 33..174, [m] max len over band m,
+                              // [16 + delta] min len over 16 delta + 1 .. 16 delta + 142 for delta = 2 .. SMM_BAND_WIT (the lengths that
+                              // connect the sources of group g - delta with the targets the band-groups of group g reach)
+#define SMM_BAND_WIT 55       // oldest witness group of the band skip test: 16 * 55 + 142 = 1022 <= the longest length
 
 // One entry per video, built on the host by smm_plan() and staged into the workspace.
 struct SmmVideo {

@@ -120,6 +120,9 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_DOM_SPARSE
 #define SMM_DOM_SPARSE 3   // BAND pushers (DOM): fewer unbeaten sources than this (besides the last) are pushed one by one from the LDS table
 #endif
+#ifndef SMM_BAND_ALLWIT
+#define SMM_BAND_ALLWIT 1  // 0 (A/B aid): the band skip test with the one witness of round 3 (group G - 2) only
+#endif
 #ifndef SMM_HQ_ALWAYS
 #define SMM_HQ_ALWAYS 0    // 1 (A/B aid): the delayed sources are fetched in every block, as in round 3, whether a band is on or not
 #endif
@@ -915,6 +918,23 @@ smm_viterbi_kernel(SmmDpArgs a)
         const double qlmx = qok ? btab[(size_t)qc * SMM_BAND_TAB + qm] : SMM_NEG_INF;
         const double qlbm = (qok && bound_ok) ? btab[(size_t)qc * SMM_BAND_TAB] : SMM_NEG_INF;
         const double *qhm = &sh_hm[BAND ? ((qjs < SPS && qc < C) ? qc : 0) : 0][0];
+        // Round 4: EVERY complete group as a witness.  The best source s* of group G - delta (delta = 2 .. 55) is a real
+        // candidate of every target the band-groups of group G reach, with 16 delta + 1 <= n - s* <= 16 delta + 142: so
+        // hm[G - delta] + min len over that window is a lower bound of the final A[n] as well, and a band-group whose upper
+        // bound is STRICTLY below any of them can be left out -- a candidate that is strictly below another candidate of
+        // its own target attains no maximum, whatever becomes of the other one (no induction over witnesses needed; the
+        // round-3 test with its one witness, group G - 2, skips ties too and argues through the witness's witness).  What
+        // it buys: inside a long segment the sources behind the segment's START are beaten by the start itself (a restart
+        // costs a self transition and a length of 1), so only the band that currently reaches back to the start has to
+        // stay on, not every band up to it: 4.2 x fewer delayed band-groups on cfg3 (scripts/probe_dominance.py).  The
+        // eight lanes of a state share the 54 windows: lane (js, m) looks at delta = 7 (m - 1) + 2 .. 7 (m - 1) + 8.
+        constexpr int NWIT = 7;
+        double qmlw[NWIT];
+#pragma unroll
+        for (int t = 0; t < NWIT; ++t) {
+            const int dlt = 7 * (qm - 1) + 2 + t;
+            qmlw[t] = (qjs < SPS && qc < C && dlt <= SMM_BAND_WIT && 16 * dlt + 142 <= kp - 1) ? btab[(size_t)qc * SMM_BAND_TAB + 16 + dlt] : SMM_NEG_INF;
+        }
         double hq[2][B];                                                     // by parity of the block that pushes them
 #pragma unroll
         for (int i = 0; i < B; ++i) { hq[0][i] = SMM_NEG_INF; hq[1][i] = SMM_NEG_INF; }
@@ -1100,7 +1120,22 @@ smm_viterbi_kernel(SmmDpArgs a)
                 }
                 if (ph == 1 && !(SMM_ABLATE & 32)) {
                     // group dG = (j+1)/2 (pushed in blocks j+2, j+3): which of this wave's (state, band) pairs are on
-                    const bool on = qok && dG - 7 * qm >= -1 && dsrc + qlmx > dwit + qlbm;
+                    bool on = qok && dG - 7 * qm >= -1 && dsrc + qlmx > dwit + qlbm;
+                    if (__ballot(on) != 0 && SMM_BAND_ALLWIT) {
+                        // a band would be switched on: look at the older (and the nearer) witnesses as well (see qmlw)
+                        double lb = SMM_NEG_INF;
+#pragma unroll
+                        for (int t = 0; t < NWIT; ++t) {
+                            const int gw = dG - (7 * (qm - 1) + 2 + t);
+                            const double hw = qhm[gw & 63];
+                            if (gw >= -1) lb = smm_fmax(lb, hw + qmlw[t]);      // (groups before the video: the ring holds nothing)
+                        }
+                        // ... the best of the state's eight lanes, in every one of them
+                        lb = smm_fmax(lb, smm_dpp<0xB1>(lb));     // quad_perm [1, 0, 3, 2]
+                        lb = smm_fmax(lb, smm_dpp<0x4E>(lb));     // quad_perm [2, 3, 0, 1]
+                        lb = smm_fmax(lb, smm_dpp<0x141>(lb));    // row_half_mirror
+                        on = on && !(dsrc + qlmx < lb);
+                    }
                     mnext = __ballot(on);                         // (bit 8 js + m - 1: lane q = 8 js + (m - 1) decides (state js, band m))
                 }
                 const unsigned long long lanes2 = mnext;          // group (j+1)/2 (decided in either block of a group)
@@ -1475,6 +1510,17 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
         }
         if (!live) v = SMM_NEG_INF;
         if (ln == 0) band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + m] = v;
+    }
+    // the witnesses of the skip test (round 4): min len over the lengths 16 delta + 1 .. 16 delta + 142, a wave per window
+    // (-inf when the window leaves the table: no witness there)
+    for (int d = 2 + wv; d <= SMM_BAND_WIT; d += 4) {
+        const int k0 = 16 * d + 1, k1 = 16 * d + 142;
+        double v = __builtin_huge_val();
+        for (int k = k0 + ln; k <= k1; k += 64) v = fmin(v, k < k_rows ? src[(size_t)k * cm] : SMM_NEG_INF);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+        if (!live) v = SMM_NEG_INF;
+        if (ln == 0) band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + 16 + d] = v;
     }
 }
 

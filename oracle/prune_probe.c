@@ -334,3 +334,83 @@ int smm_dom_probe(const double *elp, int t, int c, const double *trans, const do
     free(cum); free(h); free(gam);
     return 0;
 }
+
+/* Round 4: the band skip test with EVERY complete group as a witness.  smm_band_probe2 (the kernel of round 3) bounds the
+ * final A[n] of the targets a band-group can reach from below with ONE witness, the best source of group g - 2; here the
+ * lower bound is the best of all groups g - delta, delta = 2..55 (the best source s* of group g - delta is a real candidate
+ * of every target n the band-group reaches, with 16 delta + 1 <= n - s* <= 16 delta + 142), and a band-group is skipped only
+ * when its upper bound is STRICTLY below it.  Groups of 16 sources, bands as built (16 + 112 m .. 127 + 112 m, sources
+ * delayed by 112 m).  out[0] = band-groups with sources (m >= 1), out[1] = evaluated with the round-3 test,
+ * out[2] = evaluated with every witness, out[3] = frames.
+ */
+int smm_band_probe3(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                    double *out)
+{
+    const int grp = 16;
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    const int ng = t / grp + 2;
+    double *hmax = (double *)malloc(sizeof(double) * (size_t)ng * c);
+    if (!cum || !h || !gam || !hmax) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    /* group g = sources 16 g + 1 .. 16 g + 16 (the kernel's D = 0 convention); position 0 counts into "group -1" */
+    for (int g = 0; g < ng; ++g)
+        for (int j = 0; j < c; ++j) {
+            double m = -INFINITY;
+            for (int s = g * grp + 1; s <= g * grp + grp && s <= t; ++s) m = dmax(m, h[(size_t)s * c + j]);
+            hmax[(size_t)g * c + j] = m;
+        }
+    out[3] = t;
+    for (int j = 0; j < c; ++j) {
+        double mlw[56];
+        for (int d = 2; d <= 55; ++d) {
+            double mn = INFINITY;
+            const int k0 = 16 * d + 1, k1 = 16 * d + 142;
+            if (k1 > kp - 1) mn = -INFINITY;
+            else for (int k = k0; k <= k1; ++k) mn = dmin(mn, len[(size_t)k * c + j]);
+            mlw[d] = mn;
+        }
+        for (int m = 1; m <= 8; ++m) {
+            if (16 + 112 * m > kp - 1) continue;
+            double lm = -INFINITY;
+            for (int k = 16 + 112 * m; k <= 127 + 112 * m && k <= kp - 1; ++k) lm = dmax(lm, len[(size_t)k * c + j]);
+            for (int g = 0; g * grp < t; ++g) {
+                const int gs = g - 7 * m;                      /* the band's source group */
+                if (gs < -1) continue;
+                const double hm = (gs == -1) ? h[j] : hmax[(size_t)gs * c + j];
+                const double ub = hm + lm;
+                out[0] += 1.0;
+                const double lb2 = (g >= 2) ? hmax[(size_t)(g - 2) * c + j] + mlw[2] : ((g == 1) ? h[j] + mlw[2] : -INFINITY);
+                const int on3 = ub > lb2;
+                double lb = -INFINITY;
+                for (int d = 2; d <= 55; ++d) {
+                    const int gw = g - d;
+                    if (gw < -1) break;
+                    const double hw = (gw == -1) ? h[j] : hmax[(size_t)gw * c + j];
+                    lb = dmax(lb, hw + mlw[d]);
+                }
+                const int on4 = on3 && !(ub < lb);
+                out[1] += on3;
+                out[2] += on4;
+            }
+        }
+    }
+    free(cum); free(h); free(gam); free(hmax);
+    return 0;
+}

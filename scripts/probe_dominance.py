@@ -38,6 +38,17 @@ def probe(elp, trans, init, len_scores):
     return out
 
 
+def probe3(elp, trans, init, len_scores):
+    t, c = elp.shape
+    kp = min(len_scores.shape[0], t)
+    out = np.zeros(8)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (elp, trans, init, len_scores[:kp])]
+    rc = lib.smm_band_probe3(arrs[0].ctypes.data_as(P), t, c, arrs[1].ctypes.data_as(P), arrs[2].ctypes.data_as(P),
+                             arrs[3].ctypes.data_as(P), kp, out.ctypes.data_as(P))
+    assert rc == 0
+    return out
+
+
 def main():
     per_task = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     wl = sys.argv[2] if len(sys.argv) > 2 else 'cfg3'
@@ -50,6 +61,7 @@ def main():
     model.fit(data.subset(6), use_labels=True)
     m = model.model
     tot = np.zeros(8)
+    tot3 = np.zeros(8)
     t0 = time.time()
     for task, names in sorted(data._videos_by_task.items()):
         vc = torch.tensor(data.corpus._indices_by_task[task])
@@ -60,11 +72,17 @@ def main():
             elp = (tab['cst'] + x @ tab['w'] - 0.5 * (x * x) @ tab['inv_var'].unsqueeze(1)).numpy()
             o = probe(elp, tab['trans'].numpy(), tab['init'].numpy(), tab['len'].numpy())
             tot += o
+            o3 = probe3(elp, tab['trans'].numpy(), tab['init'].numpy(), tab['len'].numpy())
+            tot3 += o3
+            print('#    delayed band-groups: %d with sources, %d evaluated with the one witness of round 3 (%.2f %%), %d with every complete group as a witness (%.2f %%)' % (
+                o3[0], o3[1], 100 * o3[1] / o3[0], o3[2], 100 * o3[2] / o3[0]), flush=True)
             print('# %s %s T=%d C=%d: %.2f pushes per (state, block), leader %.2f  (%.0f s)' % (
                 task, name, elp.shape[0], elp.shape[1], o[1] / o[0], o[5] / o[4], time.time() - t0), flush=True)
     print("workload %s seed 2 (CPU draw), %d videos per task, K = %d" % (wl, per_task, cfg['max_k']))
     print("sources per (state, block of 8): %.3f of %.3f pushed with the successor test (%.1f %%); every-later-source test: %.3f" % (
         tot[1] / tot[0], tot[2] / tot[0], 100 * tot[1] / tot[2], tot[6] / tot[0]))
+    print("delayed band-groups (16 sources x one band of one state): %d; evaluated with round 3's witness (group g - 2): %.3f %%; with every complete group g - 2 .. g - 55 as a witness, strict: %.3f %% (%.2f x fewer)" % (
+        tot3[0], 100 * tot3[1] / tot3[0], 100 * tot3[2] / tot3[0], tot3[1] / max(1.0, tot3[2])))
     print("(state, block) pairs that push the last source only: %.1f %%; largest push count of a block's states, mean: %.2f" % (
         100 * tot[3] / tot[0], tot[5] / tot[4]))
 

@@ -619,7 +619,7 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
     against the C twin, with and without the chain wave's speculative transition (SMM_SPEC=0), bit for bit -- on random
     lattices, on CrossTask-like lattices (nearly every delayed band is skipped), on integer lattices full of exact ties
     (a skipped candidate may TIE with the maximum, never beat it) and on FLAT lattices (every state emits the same, so no
-    state ever falls behind and hardly a band can be skipped: the worst case of the test's cost, not of its result)."""
+    state ever falls behind and few bands can be skipped: the worst case of the test's cost, not of its result)."""
     lengths, c, k = shape
     ops = _ops()
     monkeypatch.delenv('SMM_SPEC', raising=False)
@@ -651,7 +651,9 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
     if kind == 'structured':
         assert frac < 0.12, frac                       # (long videos: ~1-3 %; the first 1000 frames of a video cost the most)
     elif kind == 'flat':
-        assert frac > 0.5, frac
+        # (round 3's test, one witness: > 0.5.  With every complete group as a witness -- round 4 -- an OLD source that is
+        # no worse than the new ones beats the bands between it and the present: still the worst case, a quarter of them)
+        assert frac > 0.1, frac
     # ... and word 2: sources pushed into band 0, of frames x states (round 4, source dominance: a source that its successor
     # beats at every target is left out -- nearly all of them where one state explains the frames, hardly any on a flat lattice)
     if blk == 8 and c <= 24:

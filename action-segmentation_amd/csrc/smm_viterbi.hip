@@ -1487,20 +1487,28 @@ smm_viterbi_kernel(SmmDpArgs a)
 __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len, const int32_t *n_states, double *len_t,
                                                               double *band_tab, int cm, int k_rows)
 {
+    // the state's column of the length table, once from memory (strided by c_max: every load is a trip to L2), then
+    // every bound from LDS: this kernel sits in front of the DP kernel on the critical path of every decode (round 3: nine
+    // serial loops of ~140 strided loads took 35 us; round 4's 54 witness windows straight from memory 23 us)
+    __shared__ double col[SMM_BAND_ROW];                          // col[k] = len[k] (-inf beyond the table / for a dead state)
     const int g = blockIdx.x / cm, c = blockIdx.x % cm;
     const double *src = len + (size_t)g * k_rows * cm + c;
     double *dst = len_t + ((size_t)g * cm + c) * SMM_BAND_ROW;     // row[k + 1] = len[k]; -inf beyond the table
     const bool live = c < n_states[g];
-    for (int k = threadIdx.x; k < SMM_BAND_ROW; k += blockDim.x)
-        dst[k] = (live && k >= 1 && k - 1 < k_rows) ? src[(size_t)(k - 1) * cm] : SMM_NEG_INF;
-    // nine bounds per state, a wave each (lanes stride over the lengths, then a butterfly): this kernel sits in front of the
-    // DP kernel on the critical path of every decode (nine serial loops of ~140 strided loads took 35 us)
+    for (int k = threadIdx.x; k < SMM_BAND_ROW; k += blockDim.x) {
+        const double v = (live && k >= 1 && k - 1 < k_rows) ? src[(size_t)(k - 1) * cm] : SMM_NEG_INF;
+        dst[k] = v;
+        if (k >= 1) col[k - 1] = v;
+    }
+    if (threadIdx.x == 0) col[SMM_BAND_ROW - 1] = SMM_NEG_INF;
+    __syncthreads();
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    // [0] min len over 33..174 (clipped to the table: the kernel checks the video's own limit), [m] max len over band m
     for (int m = wv; m <= SMM_BAND_N; m += 4) {
         const int k0 = m ? SMM_BAND_LO + SMM_BAND_DELAY * m : 33, k1 = m ? 127 + SMM_BAND_DELAY * m : 174;
         double v = m ? SMM_NEG_INF : __builtin_huge_val();
         for (int k = k0 + ln; k <= k1 && k < k_rows; k += 64) {
-            const double x = src[(size_t)k * cm];
+            const double x = col[k];
             v = m ? fmax(v, x) : fmin(v, x);
         }
 #pragma unroll
@@ -1516,7 +1524,7 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
     for (int d = 2 + wv; d <= SMM_BAND_WIT; d += 4) {
         const int k0 = 16 * d + 1, k1 = 16 * d + 142;
         double v = __builtin_huge_val();
-        for (int k = k0 + ln; k <= k1; k += 64) v = fmin(v, k < k_rows ? src[(size_t)k * cm] : SMM_NEG_INF);
+        for (int k = k0 + ln; k <= k1; k += 64) v = fmin(v, k < k_rows ? col[k] : SMM_NEG_INF);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
         if (!live) v = SMM_NEG_INF;

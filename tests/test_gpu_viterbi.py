@@ -194,6 +194,45 @@ def test_viterbi_22_23_states_next_to_smaller_tasks():
         np.testing.assert_array_equal(out['spans'][i], spans[0])
 
 
+def test_one_parameter_group_per_video_at_size():
+    """Per-INSTANCE parameters -- the layout of the reference's ComponentSemiMarkovModule (semimarkov_modules.py:895-897,
+    log_hsmm(all_batched=True) :439-441): every video brings its own transition / initial / length tables, i.e.
+    n_groups == b.  48 videos of 1500..4000 frames, 11..23 states each, K = 1024 (BAND mode: per-group band tables, per-group
+    dominance thresholds), CrossTask-like lattices; every video bit for bit against its own twin."""
+    ops = _ops()
+    dev = torch.device('cuda:0')
+    g = np.random.default_rng(77)
+    b, k, cm = 48, 1024, 23
+    cs = [int(x) for x in g.integers(11, 24, size=b)]
+    cs[0], cs[1] = 23, 11
+    lengths = g.integers(1500, 4001, size=b).astype(np.int64)
+    tmax = int(lengths.max())
+    group = np.arange(b, dtype=np.int32)
+    elp = np.zeros((b, tmax, cm))
+    trans = np.full((b, cm, cm), -1e9)
+    init = np.full((b, cm), -1e9)
+    lens = np.full((b, k, cm), -1e9)
+    probs = []
+    for i in range(b):
+        p = structured_problem(500 + i, [int(lengths[i])], cs[i], k)
+        probs.append(p)
+        elp[i, :lengths[i], :cs[i]] = p['elp'][0]
+        trans[i, :cs[i], :cs[i]] = p['trans']
+        init[i, :cs[i]] = p['init']
+        lens[i, :, :cs[i]] = p['lens']
+    batch = ops.Batch(lengths, cs, k, c_max=cm, t_max=tmax, total_frames=b * tmax, group=group)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    out = ops.viterbi(batch, t(elp.reshape(b * tmax, cm)), t(trans), t(init), t(lens))
+    torch.cuda.synchronize()
+    assert ops.error_flag(batch) == 0
+    out = {kk: v.cpu().numpy() for kk, v in out.items()}
+    for i in range(b):
+        p = probs[i]
+        spans, v = F.viterbi(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], None)
+        assert out['best'][i] == v[0], i
+        np.testing.assert_array_equal(out['spans'][i, :lengths[i] + 1], spans[0])
+
+
 def test_labels_written_to_pinned_host_memory():
     """labels_on_host: the DP kernel stores the frame labels straight into pinned host memory; same values as the
     device tensor, for a padded layout (filler -1 between videos) and for one above the pairing threshold."""

@@ -69,8 +69,14 @@ def _dev(t, dtype, name):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _raw_stream():
+    """Handle of torch's current stream on the current device, by the C-level getters (torch.cuda.current_stream() builds a
+    Stream object and resolves the device through three python layers: ~10 us, twice per call, of a 150 us viterbi())."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 _ws_cache = {}
@@ -78,7 +84,7 @@ _ws_cache = {}
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream).  (Caller-owned from the library's point of view.)"""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _raw_stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -118,9 +124,9 @@ def _pinned_small(kind, device, numel, dtype):
     return buf[:numel]
 
 
-def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None, spans_on_host=False):
+def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None, spans_on_host=False, host_slot=0):
     if want_spans and spans_on_host:
-        spans = _pinned_small('spans', device, batch.b * (batch.t_max + 1), torch.int64).view(batch.b, batch.t_max + 1)
+        spans = _pinned_small(('spans', host_slot), device, batch.b * (batch.t_max + 1), torch.int64).view(batch.b, batch.t_max + 1)
     else:
         spans = torch.empty((batch.b, batch.t_max + 1), dtype=torch.int64, device=device) if want_spans else None
     if labels_out is not None:
@@ -262,14 +268,17 @@ def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, wa
 
 
 def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen=None, class_map=None,
-           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False, labels_out=None, spans_on_host=False):
+           want_spans=True, want_labels=True, want_elp=False, labels_on_host=False, labels_out=None, spans_on_host=False,
+           host_slot=0):
     """Features -> spans / labels in one call (smm_decode_f32): emission kernel + DP kernel on the current stream.
     ``labels_on_host`` / ``labels_out``: see ``viterbi``.  ``spans_on_host``: the kernel writes the span encoding into
     pinned host memory and the error words follow by an asynchronous copy (small batches: the reference's per-batch call
-    pattern); both are valid once the stream has been synchronised, until the next such call."""
+    pattern); both are valid once the stream has been synchronised, until the next such call with the same ``host_slot``
+    (a caller that keeps two decodes in flight alternates two slots)."""
     lib = _lib.load()
     dev = x.device
-    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out, spans_on_host)
+    spans, labels, best, n_segs = _outputs(batch, dev, want_spans, want_labels, labels_on_host, labels_out, spans_on_host,
+                                           host_slot)
     elp32 = torch.zeros((batch.total_frames, batch.c_max), dtype=torch.float32, device=dev) if want_elp else None
     ws = workspace(batch.workspace_bytes(), dev)
     ln, fo, gr, kp, ns = batch.host_ptrs()
@@ -283,7 +292,7 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     if spans_on_host:
-        err = _pinned_small('err', dev, 4, torch.int32)
+        err = _pinned_small(('err', host_slot), dev, 4, torch.int32)
         err.copy_(_err_view(batch, ws), non_blocking=True)
     else:
         err = _err_copy(batch, ws)

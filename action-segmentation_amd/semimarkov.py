@@ -468,26 +468,31 @@ class SemiMarkovModel(object):
                                   shard=shard)
         cons_fn = self._test_constraints(test_data)
 
-        def launch(batch):
+        def launch(batch, slot):
             tasks = batch['task_name']
             assert len(set(tasks)) == 1
             features, lengths = batch['features'].to(self.device), batch['lengths']
             cons = cons_fn(batch) if cons_fn else None
             addl = self.make_additional_allowed_ends(tasks, lengths)
             return self.model.viterbi_launch(features, lengths, batch['task_indices'], add_eos=True, use_mean_z=True,
-                                             additional_allowed_ends_per_instance=addl, constraints=cons)
+                                             additional_allowed_ends_per_instance=addl, constraints=cons, slot=slot)
 
-        # The reference's call pattern, one decode per single-task batch (:318-410) -- with the NEXT batch collated while the
-        # GPU decodes this one (a batch of five 300-frame videos is 0.1 ms of GPU time and as much host time to collate)
+        # The reference's call pattern, one decode per single-task batch (:318-410) -- two batches deep: batch i + 1 is collated
+        # and LAUNCHED (on the other pinned result slot) before the spans of batch i are waited for and unpacked, so the GPU
+        # decodes while the host collates and unpacks (a batch of five 300-frame videos is 0.15 ms of GPU time and 0.3 ms of
+        # host time; the device work of consecutive batches is ordered by the stream)
         it = iter(loader)
         batch = next(it, None)
+        pending = launch(batch, 0) if batch is not None else None
+        slot = 0
         while batch is not None:
-            pending = launch(batch)
             nxt = next(it, None)
+            slot ^= 1
+            pending_next = launch(nxt, slot) if nxt is not None else None
             pred_spans = pending()
             pred_labels = semimarkov_utils.spans_to_labels(pred_spans)
             for video, seq in zip(batch['video_name'], self.model.trim(pred_labels, batch['lengths'], check_eos=True)):
                 predictions[video] = seq.numpy()
                 assert self.model.n_classes not in predictions[video], "predictions should not contain EOS"
-            batch = nxt
+            batch, pending = nxt, pending_next
         return predictions

@@ -393,8 +393,12 @@ class SemiMarkovModule(nn.Module):
         # (the collate hands over the task's ONE index tensor b times: identity first -- the element-wise comparison of the
         # reference, :600-601, walks every tensor in Python, 80 us of a 240 us call)
         if not all(vc is first for vc in valid_classes_per_instance):
-            assert all_equal(set(int(v) for v in vc) for vc in valid_classes_per_instance), \
-                "must have same valid_classes for all instances in the batch"
+            # ... then element-wise (one torch.equal per instance: the loader hands over equal COPIES of the task's indices),
+            # and only then as sets, like the reference
+            import torch
+            if not all(vc.shape == first.shape and torch.equal(vc, first) for vc in valid_classes_per_instance):
+                assert all_equal(set(int(v) for v in vc) for vc in valid_classes_per_instance), \
+                    "must have same valid_classes for all instances in the batch"
         return first.detach().cpu().long()
 
     def factor_tables(self, valid_classes, device=None):
@@ -436,7 +440,7 @@ class SemiMarkovModule(nn.Module):
         the same few class sets, and building the tables is a dozen small torch ops (half of a small batch's latency).
         The key includes the parameters' version counters, so any in-place update (an optimiser step, load_state_dict,
         fit_supervised) invalidates the entry."""
-        key = (None if valid_classes is None else tuple(int(v) for v in valid_classes), str(device), self.max_k,
+        key = (self._class_key(valid_classes), str(device), self.max_k,
                tuple((p.data_ptr(), p._version) for p in (self.poisson_log_rates, self.gaussian_means, self.gaussian_cov,
                                                          self.transition_logits, self.init_logits)),
                self._constraint_key())
@@ -449,6 +453,12 @@ class SemiMarkovModule(nn.Module):
                 tab = self.factor_tables(valid_classes, device)
             cache[key] = tab
         return tab
+
+    @staticmethod
+    def _class_key(valid_classes):
+        if isinstance(valid_classes, torch.Tensor):
+            return tuple(valid_classes.tolist())         # (iterating a tensor costs ~1 us per element)
+        return None if valid_classes is None else tuple(int(v) for v in valid_classes)
 
     def _constraint_key(self):
         """Identity of everything besides the five parameters that factor_tables reads."""
@@ -464,7 +474,7 @@ class SemiMarkovModule(nn.Module):
         if self.allowed_ends is None:
             return None
         add = additional_allowed_ends_per_instance
-        key = (None if valid_classes is None else tuple(int(v) for v in valid_classes), b, c, str(device),
+        key = (self._class_key(valid_classes), b, c, str(device),
                tuple(sorted(self.allowed_ends)), None if add is None else tuple(tuple(int(x) for x in a) for a in add))
         cache = self.__dict__.setdefault('_endpen_cache', {})
         hit = cache.get(key)
@@ -498,18 +508,20 @@ class SemiMarkovModule(nn.Module):
                                    additional_allowed_ends_per_instance, constraints, predict_single, return_elp)()
 
     def viterbi_launch(self, features, lengths, valid_classes_per_instance, add_eos=True, use_mean_z=False,
-                       additional_allowed_ends_per_instance=None, constraints=None, predict_single=False, return_elp=False):
+                       additional_allowed_ends_per_instance=None, constraints=None, predict_single=False, return_elp=False,
+                       slot=0):
         """``viterbi`` in two halves: this one enqueues the decode and returns at once; calling the returned function waits
-        for it and hands out what ``viterbi`` returns.  ONE launch may be outstanding per device (the spans land in a
-        pinned host buffer that the next launch reuses): a caller can collate its next batch in between
-        (``SemiMarkovModel.predict(fused=False)`` does)."""
+        for it and hands out what ``viterbi`` returns.  ONE launch may be outstanding per device AND ``slot`` (the spans land
+        in a pinned host buffer that the next launch with the same slot reuses): a caller can collate and launch its next
+        batch on the other slot in between (``SemiMarkovModel.predict(fused=False)`` does: the GPU decodes batch i + 1 while
+        the host unpacks batch i)."""
         self._require_device(features, 'viterbi')
         valid_classes = self._check_valid_classes(valid_classes_per_instance)
         self.set_z(features, lengths, use_mean=use_mean_z)
         # (the spans land in pinned host memory, the error words follow by an asynchronous copy: ONE synchronisation, no
         # blocking device -> host copy -- this call is host latency at the reference's batch size)
         out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                           want_elp=return_elp, want_labels=False, no_eos=not add_eos, spans_on_host=True)
+                           want_elp=return_elp, want_labels=False, no_eos=not add_eos, spans_on_host=True, host_slot=slot)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(features.device))
         tmax = features.size(1)
@@ -535,7 +547,7 @@ class SemiMarkovModule(nn.Module):
                              "in the reference's lattice)")
 
     def _decode(self, features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                want_elp=False, want_labels=True, want_spans=True, no_eos=False, spans_on_host=False):
+                want_elp=False, want_labels=True, want_spans=True, no_eos=False, spans_on_host=False, host_slot=0):
         b, tmax, d = features.shape
         dev = features.device
         lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
@@ -550,11 +562,13 @@ class SemiMarkovModule(nn.Module):
         if constraints is not None:
             cons = constraints.detach().to(device=dev, dtype=torch.float32).contiguous().view(b * tmax, c)
         endpen = None if no_eos else self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
-        out = ops.decode(batch, x, tab['w'].unsqueeze(0).contiguous(), tab['cst'].unsqueeze(0).contiguous(),
-                         tab['inv_var'], tab['trans'].unsqueeze(0).contiguous(), tab['init'].unsqueeze(0).contiguous(),
-                         tab['len'].unsqueeze(0).contiguous(), cons=cons, endpen=endpen,
-                         class_map=tab['class_map'].view(1, -1), want_spans=want_spans, want_labels=want_labels,
-                         want_elp=want_elp, spans_on_host=spans_on_host)
+        g1 = tab.get('_one_group')            # the cached tables as a stack of ONE group (ten views less per call)
+        if g1 is None:
+            g1 = tab['_one_group'] = tuple(tab[k].unsqueeze(0).contiguous() for k in ('w', 'cst', 'trans', 'init', 'len')) \
+                + (tab['class_map'].view(1, -1),)
+        out = ops.decode(batch, x, g1[0], g1[1], tab['inv_var'], g1[2], g1[3], g1[4], cons=cons, endpen=endpen,
+                         class_map=g1[5], want_spans=want_spans, want_labels=want_labels,
+                         want_elp=want_elp, spans_on_host=spans_on_host, host_slot=host_slot)
         out['_batch'] = batch
         return out
 

@@ -23,3 +23,4 @@ for _ in range(5):
     model.predict(data, fused=False)
 pr.disable()
 pstats.Stats(pr).sort_stats('cumtime').print_stats(45)
+pstats.Stats(pr).sort_stats('tottime').print_stats(30)

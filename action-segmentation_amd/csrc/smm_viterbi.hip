@@ -1378,10 +1378,15 @@ smm_viterbi_kernel(SmmDpArgs a)
 #endif
     if (threadIdx.x == 0) { sh_kmin[0] = 0xffffffffu; sh_kmin[1] = 0xffffffffu; sh_kmin[2] = 0xffffffffu; }
     // Phase B depends on phase A (which state's column to scan), and each is a round trip to a history that has long
-    // left the caches (4-5 us per segment under load).  The column of the state that preceded `to` the LAST time (at the
+    // left the caches (~2000 cycles per trip).  The column of the state that preceded `to` the LAST time (at the
     // start: the most likely one a priori, arg-max of its transition row) is therefore fetched SPECULATIVELY together
     // with phase A's rows; when phase A confirms the guess -- nearly always on ordered tasks -- the segment costs one
     // round trip.  Same expressions, same first-(k, state) order: a wrong guess only costs the second trip.
+    // Round 4: (1) the lengths of a column come from the state-major table in BAND mode (the [k][c] table is one cache line
+    // per candidate: 512 lines per round against 64); (2) the loop's barriers wait for LDS only, every wave keeps the guess
+    // table current by itself, and (3) the NEXT segment's trip is issued in front of this segment's label stores: a segment
+    // no longer waits for its predecessor's stores to be acknowledged, then for its own loads.  cfg3's longest video (92
+    // segments): 5040 -> 3380 cycles per segment, of which ~2000 are the one trip (profiles/round4_backtrace.txt).
     if (threadIdx.x <= (unsigned)C) {
         const int t2 = threadIdx.x;
         int bi = C - 1;
@@ -1398,26 +1403,31 @@ smm_viterbi_kernel(SmmDpArgs a)
         }
         sh_guess[t2] = bi;
     }
-    while (n > 0) {
-        __syncthreads();                                       // sh_guess (written at the end of the previous segment)
-        const int fg = sh_guess[to];
-        const int kmax = (kp - 1 < n) ? kp - 1 : n;
-        double wgt = 0.0, gmv = SMM_NEG_INF, cnl = 0.0;
+    __syncthreads();
+    const double *lcol0 = nullptr;                            // BAND: [c][k + 1] = len[k][c], a state's lengths contiguous
+    if constexpr (BAND) lcol0 = a.len_t + (size_t)g * cm * SMM_BAND_ROW + 1;
+    // one round trip for everything phase A and B need of position n_: gamma row, cumE row, weights, and the first round
+    // of phase B for the guessed state (clamped, unconditional loads)
+    int fg = 0, kmax = 0;
+    double wgt = 0.0, g0 = SMM_NEG_INF, cnl = 0.0, sp_h = 0.0, sp_l = 0.0;
+    auto trip = [&](int n_, int to_) {
+        fg = sh_guess[to_];                                  // (this wave's own lane 0 wrote it last: see below)
+        kmax = (kp - 1 < n_) ? kp - 1 : n_;
         if (lane < C) {
-            // one round trip for everything phase A and B need of position n: gamma row, cumE row, weights
-            const double g0 = hgam[(size_t)n * C + lane];
-            cnl = hcum[(size_t)n * C + lane];
-            wgt = (to == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to * cm + lane];
-            gmv = g0 + wgt;
+            g0 = hgam[(size_t)n_ * C + lane];
+            cnl = hcum[(size_t)n_ * C + lane];
+            wgt = (to_ == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to_ * cm + lane];
         }
-        // speculative first round of phase B for state fg (clamped, unconditional loads: same round trip as phase A)
-        double sp_h, sp_l;
-        {
-            const int kk0 = w * 64 + lane + 1;
-            const int kc = kk0 <= kmax ? kk0 : kmax;
-            sp_h = hh[(size_t)fg * (T + 1) + n - kc];
-            sp_l = len[(size_t)kc * cm + fg];
-        }
+        const int kk0 = w * 64 + lane + 1;
+        const int kc = kk0 <= kmax ? kk0 : kmax;
+        sp_h = hh[(size_t)fg * (T + 1) + n_ - kc];
+        sp_l = BAND ? lcol0[(size_t)fg * SMM_BAND_ROW + kc] : len[(size_t)kc * cm + fg];
+    };
+    // (lane c keeps the global id of state c: a load of cmap[c] behind the trip's loads would wait for all of them)
+    const int64_t gid_l = cmap ? cmap[lane < C ? lane : C] : (int64_t)lane;
+    if (n > 0) trip(n, to);
+    while (n > 0) {
+        const double gmv = (lane < C) ? g0 + wgt : SMM_NEG_INF;
         const double rmax = smm_row_max16(gmv);
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
         unsigned long long fmask = __ballot(lane < C && gmv == best);
@@ -1429,18 +1439,19 @@ smm_viterbi_kernel(SmmDpArgs a)
             const double cn = smm_readlane(cnl, f);
             const double wf = smm_readlane(wgt, f);
             const double *hcol = hh + (size_t)f * (T + 1);     // contiguous: this state's h over all positions
+            const double *lcol = BAND ? lcol0 + (size_t)f * SMM_BAND_ROW : len + f;
             const int lim = (kmax < k - 1) ? kmax : k - 1;      // an equal k with a larger state loses
             for (int kb = 0; kb < lim; kb += NW * 64) {
                 const int kk = kb + w * 64 + lane + 1;
                 bool hit = false;
                 if (kb == 0 && f == fg) {                       // the guess was right: its first round is already here
                     if (kk <= lim) hit = ((cn + (sp_h + sp_l)) + wf) == best;
-                } else if (kk <= lim) hit = ((cn + (hcol[n - kk] + len[(size_t)kk * cm + f])) + wf) == best;
+                } else if (kk <= lim) hit = ((cn + (hcol[n - kk] + lcol[BAND ? (size_t)kk : (size_t)kk * cm])) + wf) == best;
                 const unsigned long long m = __ballot(hit);
                 const int slot = round % 3;
                 if (lane == 0 && m) atomicMin(&sh_kmin[slot], (unsigned)(kb + w * 64 + __ffsll(m)));
                 if (threadIdx.x == 0) sh_kmin[(round + 1) % 3] = 0xffffffffu;
-                __syncthreads();
+                smm_lds_barrier();                              // (LDS only: the label stores below are never waited for)
                 const unsigned kf = sh_kmin[slot];
                 ++round;
                 if (kf != 0xffffffffu) {
@@ -1455,16 +1466,20 @@ smm_viterbi_kernel(SmmDpArgs a)
             break;
         }
         const int s = n - k;
-        const int64_t gid = cmap ? cmap[c] : c;
-        if (labels)
-            for (int f = s + threadIdx.x; f < n; f += blockDim.x) labels[f] = gid;
-        if (threadIdx.x == 0) {
-            if (spans) spans[s] = gid;
-            sh_guess[to] = c;                                   // (read behind the barrier at the top of the loop)
-        }
-        ++nseg;
+        // every wave writes the guess it has just learned (the same value in all of them) and reads its OWN write back at
+        // its next visit of that state: LDS operations of a wave execute in order, no barrier needed.  (An entry another
+        // wave wrote was written a segment or more ago, i.e. in front of a barrier this wave has passed since.)
+        if (lane == 0) sh_guess[to] = c;
+        const int n0 = n;
         n = s;
         to = c;
+        if (n > 0) trip(n, to);                                // the next segment's trip goes out in front of the stores
+        const int64_t gid = ((int64_t)__builtin_amdgcn_readlane((int)(gid_l >> 32), c) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)gid_l, c);
+        if (labels)
+            for (int f = s + threadIdx.x; f < n0; f += blockDim.x) labels[f] = gid;
+        if (threadIdx.x == 0 && spans) spans[s] = gid;
+        ++nseg;
         SMM_BT_STAMP(bt_c);
     }
 #ifdef SMM_PROFILE

@@ -440,10 +440,7 @@ class SemiMarkovModule(nn.Module):
         the same few class sets, and building the tables is a dozen small torch ops (half of a small batch's latency).
         The key includes the parameters' version counters, so any in-place update (an optimiser step, load_state_dict,
         fit_supervised) invalidates the entry."""
-        key = (self._class_key(valid_classes), str(device), self.max_k,
-               tuple((p.data_ptr(), p._version) for p in (self.poisson_log_rates, self.gaussian_means, self.gaussian_cov,
-                                                         self.transition_logits, self.init_logits)),
-               self._constraint_key())
+        key = (self._class_key(valid_classes), str(device), self.max_k, self._param_key(), self._constraint_key())
         cache = self.__dict__.setdefault('_table_cache', {})
         tab = cache.get(key)
         if tab is None:
@@ -453,6 +450,11 @@ class SemiMarkovModule(nn.Module):
                 tab = self.factor_tables(valid_classes, device)
             cache[key] = tab
         return tab
+
+    def _param_key(self):
+        """Identity + version of the five parameters: any in-place update changes it."""
+        return tuple((p.data_ptr(), p._version) for p in (self.poisson_log_rates, self.gaussian_means, self.gaussian_cov,
+                                                          self.transition_logits, self.init_logits))
 
     @staticmethod
     def _class_key(valid_classes):
@@ -583,11 +585,14 @@ class SemiMarkovModule(nn.Module):
         if differentiable:
             tabs = [self.factor_tables(g['valid_classes'], dev) for g in pc.groups]
         else:
-            tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
-            key = tuple(id(t) for t in tabs)        # the cached per-group tables are the same objects while the
-            hit = getattr(pc, '_stacked', None)     # parameters have not changed: so is their stack
+            # the stack of a corpus is good while the parameters (and what else the tables read) have not changed: one key
+            # for the corpus, looked at before the per-group tables (whose keys list the classes of a group: a device ->
+            # host copy per group when the corpus is resident -- 18 of them were 0.3 ms of a 3.2 ms predict() on cfg3)
+            key = (self._param_key(), self._constraint_key(), str(dev), self.max_k)
+            hit = getattr(pc, '_stacked', None)
             if hit is not None and hit[0] == key:
                 return hit[1]
+            tabs = [self._decode_tables(g['valid_classes'], dev) for g in pc.groups]
         n_states = [int(t['init'].numel()) for t in tabs]
         cm = max(n_states)
         pad = lambda t, c, rows=False: F.pad(t, (0, cm - c) + ((0, cm - c) if rows else ()))

@@ -124,6 +124,51 @@ def _pinned_small(kind, device, numel, dtype):
     return buf[:numel]
 
 
+_label_leases = {}
+LABEL_LEASES = 3      # pinned label buffers per device that can be out on lease at once
+
+
+def _storage_users(t):
+    """How many tensors (and numpy arrays made from them) share ``t``'s storage, ``t`` included; None if this torch build
+    cannot tell (then nothing is ever leased)."""
+    fn = getattr(torch._C, '_storage_Use_Count', None)
+    return None if fn is None else fn(t.untyped_storage()._cdata)
+
+
+def lease_host_labels(batch, device):
+    """A pinned int64 [total_frames] label buffer that belongs to the CALLER for as long as the returned tensor -- or
+    anything that shares its storage, such as the numpy arrays of ``SemiMarkovModel.predict`` -- is alive; pass it as
+    ``labels_out``.  The buffer is free again when the last of them has died (the storage's use count tells: a numpy array
+    made from a tensor keeps a NEW tensor object alive, not the one it was made from, so a weak reference would not), i.e. a
+    caller that drops its result before the next decode keeps reusing one buffer and never copies 8 bytes per frame out of a
+    staging buffer (cfg3: 20 MB).  At most LABEL_LEASES buffers per device are out at once: None when all are (the caller
+    then decodes into the shared staging buffer and copies, as before)."""
+    pool = _label_leases.setdefault(device.index, [])
+    n = batch.total_frames
+    entry = None
+    for e in pool:
+        if _storage_users(e[0]) == e[1]:               # nobody but the pool holds it
+            entry = e
+            if e[0].numel() >= n:
+                break
+    if entry is None or entry[0].numel() < n:
+        if entry is None and len(pool) >= LABEL_LEASES:
+            return None
+        buf = torch.empty(int(n * 1.25) + 16, dtype=torch.int64, pin_memory=True)
+        users = _storage_users(buf)
+        if users is None:
+            return None
+        if entry is None:
+            entry = [buf, users]
+            pool.append(entry)
+        else:
+            entry[0], entry[1] = buf, users
+    out = entry[0][:n]
+    if int(batch.lengths.sum()) != n:
+        out.fill_(-1)                                  # frames no video covers (padded layouts) keep the -1 filler
+    return out
+
+
 def _outputs(batch, device, want_spans, want_labels, labels_on_host=False, labels_out=None, spans_on_host=False, host_slot=0):
     if want_spans and spans_on_host:
         spans = _pinned_small(('spans', host_slot), device, batch.b * (batch.t_max + 1), torch.int64).view(batch.b, batch.t_max + 1)

@@ -335,12 +335,22 @@ class SemiMarkovModel(object):
         from . import ops
         if pc.n_videos == 0:
             return {}                                       # this rank's shard is empty
-        # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here
-        out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
-        torch.cuda.current_stream().synchronize()
-        # (the pinned staging buffer is reused by the next decode: copy out of it -- torch's copy and reduction run on
-        # all host cores, numpy's on one: 20 MB of labels per cfg3 decode)
-        lab_t = out['labels'].clone()
+        # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here -- in a
+        # buffer that is OURS until the caller drops the result (ops.lease_host_labels): no copy out of a staging buffer ...
+        lease = ops.lease_host_labels(pc.batch, pc.device or pc.x.device)
+        if lease is not None:
+            out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_out=lease)
+            torch.cuda.current_stream().synchronize()
+            lab_t = lease
+        else:
+            # ... unless LABEL_LEASES earlier results are still alive: then into the shared staging buffer, which the next
+            # decode reuses, and the caller gets a copy.  Its pages are fresh from the kernel (20 MB of labels per cfg3
+            # decode = 4800 page faults), so they are touched HERE, while the GPU decodes, and the copy behind the
+            # synchronisation runs at memcpy speed (torch's fill, copy and reduction run on all host cores)
+            out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_on_host=True)
+            lab_t = torch.empty_like(out['labels'], pin_memory=False).zero_()
+            torch.cuda.current_stream().synchronize()
+            lab_t.copy_(out['labels'])
         ops.check_decoded(pc.batch, out)
         # one pass over the whole frame axis instead of one scan per video (frames no video covers hold -1)
         assert lab_t.numel() == 0 or int(lab_t.max()) < self.model.n_classes, "predictions should not contain EOS"

@@ -4,7 +4,8 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r4_final
+T=${SMM_TAG:-r4_final}
+export SMM_TAG=$T
 python -c "import __graft_entry__ as g; g.smoke()"
 timeout -k 10 1000 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/${T}_pytest.log 2>&1 ; echo "all tests rc=$?"
 tail -14 gpurun_out/${T}_pytest.log
@@ -40,9 +41,12 @@ PY
 cat gpurun_out/${T}_sq_counters.txt
 timeout -k 10 600 python scripts/sweep_split.py > gpurun_out/${T}_split_sweep.txt 2>&1; echo "sweep rc=$?"
 timeout -k 10 200 python scripts/probe_viterbi_call.py > gpurun_out/${T}_viterbi_call.txt 2>&1
+timeout -k 10 200 python scripts/probe_predict_refdef.py > gpurun_out/${T}_predict_refdef.txt 2>&1
+timeout -k 10 200 python scripts/probe_predict_fused.py > gpurun_out/${T}_predict_fused.txt 2>&1
 python - <<'PY'
 import json
-T = 'r4_final'
+import os
+T = os.environ.get('SMM_TAG', 'r4_final')
 for w in ('cfg3', 'cfg2', 'cfg1', 'cfg4', 'refdef'):
     try:
         r = json.load(open('gpurun_out/%s_%s.json' % (T, w)))

@@ -36,3 +36,20 @@ ms, lab = t(lambda: out['labels'].clone()); print('labels.clone(): %.3f ms (%d b
 ms, _ = t(lambda: int(lab.max())); print('labels.max(): %.3f ms' % ms)
 labels = lab.numpy()
 ms, _ = t(lambda: {name: labels[off:off + tt] for name, off, tt in zip(pc.video_names, pc.frame_offset, pc.lengths)}); print('dict of views: %.3f ms' % ms)
+# as bench.py's predict_end_to_end times it (gc.collect() in front, the previous result still alive) and the variations
+import gc
+for hold in (True, False):
+    for collect in (True, False):
+        ts = []
+        preds = None
+        for _ in range(8):
+            if collect:
+                gc.collect()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if hold:
+                preds = model.predict(data)
+            else:
+                model.predict(data)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print('predict(fused), previous result held: %s, gc.collect() in front: %s: %s ms' % (hold, collect, ' '.join('%.2f' % x for x in ts)))

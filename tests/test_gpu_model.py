@@ -59,6 +59,38 @@ def test_predict_matches_reference_path(constrain, narration):
     assert acc > 0.5                                          # it also segments the synthetic videos sensibly
 
 
+def test_predict_results_stay_valid_while_referenced_and_their_buffers_are_reused_afterwards():
+    """predict() hands out views of a pinned label buffer on lease (ops.lease_host_labels): a result the caller still holds
+    must survive later decodes -- also when more results are alive than there are leases (the copy path) -- and a
+    dropped result's buffer must be the one the next call decodes into."""
+    import gc
+    from action_segmentation_amd import ops
+    data, args, model = build(False, ())
+    other = data.subset(1)
+    first = model.predict(data)
+    keep = {k: v.copy() for k, v in first.items()}
+    held = [model.predict(other if i % 2 == 0 else data) for i in range(ops.LABEL_LEASES + 2)]   # more than the pool leases
+    for k in keep:
+        np.testing.assert_array_equal(first[k], keep[k], err_msg=k)
+    for i, r in enumerate(held):
+        if i % 2 == 1:
+            for k in keep:
+                np.testing.assert_array_equal(r[k], keep[k], err_msg='%d %s' % (i, k))
+    pool = ops._label_leases[torch.cuda.current_device()]
+    assert len(pool) == ops.LABEL_LEASES and all(ops._storage_users(e[0]) > e[1] for e in pool)
+    del first, held, r
+    gc.collect()
+    assert all(ops._storage_users(e[0]) == e[1] for e in pool)   # every lease came back with its last reference
+    again = model.predict(data)
+    some = next(iter(again.values()))
+    base = some
+    while getattr(base, 'base', None) is not None and isinstance(base.base, np.ndarray):
+        base = base.base
+    assert any(base.ctypes.data == e[0].data_ptr() for e in pool)   # ... and the next result lives in one of them
+    for k in keep:
+        np.testing.assert_array_equal(again[k], keep[k], err_msg=k)
+
+
 def test_unsupervised_fit_improves_marginal_likelihood():
     """A few epochs of the reference's unsupervised objective (-log Z, Adam) through the HIP forward/backward kernels."""
     data = synth.SynthDatasplit('tiny', seed=9)

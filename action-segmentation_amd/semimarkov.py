@@ -337,7 +337,8 @@ class SemiMarkovModel(object):
             return {}                                       # this rank's shard is empty
         # the DP kernel writes the labels into pinned host memory while it decodes: synchronise, then they are here -- in a
         # buffer that is OURS until the caller drops the result (ops.lease_host_labels): no copy out of a staging buffer ...
-        lease = ops.lease_host_labels(pc.batch, pc.device or pc.x.device)
+        dev = pc.device or pc.x.device
+        lease = ops.lease_host_labels(pc.batch, dev) if dev.type == 'cuda' else None   # (no GPU: decode_packed says so, loudly)
         if lease is not None:
             out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_out=lease)
             torch.cuda.current_stream().synchronize()

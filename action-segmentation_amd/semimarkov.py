@@ -18,6 +18,11 @@ from .semimarkov_modules import SemiMarkovModule, all_equal
 
 
 class SemiMarkovModel(object):
+    DECODE_DEPTH = 8      # predict(fused=False): single-task batches in flight, one pinned result slot each ...
+    STREAM_MIN_FRAMES = 1500   # ... and a stream each when the batch's longest video is at least this long: below, the GPU is
+                               # done with a batch (0.17 us per frame) before the host has launched the next (0.25 ms), and
+                               # a second stream would only add its hand-over (refdef, T <= 600: 4.4 -> 5.1 ms for 18 batches)
+
     @classmethod
     def add_args(cls, parser):
         SemiMarkovModule.add_args(parser)
@@ -479,6 +484,13 @@ class SemiMarkovModel(object):
                                   shard=shard)
         cons_fn = self._test_constraints(test_data)
 
+        depth = max(1, int(getattr(self.args, 'decode_depth', self.DECODE_DEPTH)))
+        streams = self.__dict__.setdefault('_decode_streams', {})
+        key = (str(self.device), depth)
+        if key not in streams:
+            on_gpu = torch.device(self.device).type == 'cuda'     # (no GPU: the first decode says so, loudly)
+            streams[key] = [torch.cuda.Stream(device=self.device) if on_gpu and depth > 1 else None for _ in range(depth)]
+
         def launch(batch, slot):
             tasks = batch['task_name']
             assert len(set(tasks)) == 1
@@ -486,24 +498,26 @@ class SemiMarkovModel(object):
             cons = cons_fn(batch) if cons_fn else None
             addl = self.make_additional_allowed_ends(tasks, lengths)
             return self.model.viterbi_launch(features, lengths, batch['task_indices'], add_eos=True, use_mean_z=True,
-                                             additional_allowed_ends_per_instance=addl, constraints=cons, slot=slot)
+                                             additional_allowed_ends_per_instance=addl, constraints=cons, slot=slot,
+                                             stream=streams[key][slot] if features.size(1) >= self.STREAM_MIN_FRAMES else None)
 
-        # The reference's call pattern, one decode per single-task batch (:318-410) -- two batches deep: batch i + 1 is collated
-        # and LAUNCHED (on the other pinned result slot) before the spans of batch i are waited for and unpacked, so the GPU
-        # decodes while the host collates and unpacks (a batch of five 300-frame videos is 0.15 ms of GPU time and 0.3 ms of
-        # host time; the device work of consecutive batches is ordered by the stream)
-        it = iter(loader)
-        batch = next(it, None)
-        pending = launch(batch, 0) if batch is not None else None
-        slot = 0
-        while batch is not None:
-            nxt = next(it, None)
-            slot ^= 1
-            pending_next = launch(nxt, slot) if nxt is not None else None
-            pred_spans = pending()
-            pred_labels = semimarkov_utils.spans_to_labels(pred_spans)
+        def finish(batch, pending):
+            pred_labels = semimarkov_utils.spans_to_labels(pending())
             for video, seq in zip(batch['video_name'], self.model.trim(pred_labels, batch['lengths'], check_eos=True)):
                 predictions[video] = seq.numpy()
                 assert self.model.n_classes not in predictions[video], "predictions should not contain EOS"
-            batch, pending = nxt, pending_next
+
+        # The reference's call pattern, one decode per single-task batch (:318-410) -- DECODE_DEPTH batches deep: batch i is
+        # collated and LAUNCHED (on pinned result slot and stream i mod depth) before the spans of batch i - depth + 1 are
+        # waited for and unpacked.  A batch of five videos occupies five CUs for as long as its longest video takes (cfg3:
+        # 1.7 ms; refdef: 0.15 ms) and costs 0.25 ms of host time: on separate streams the batches in flight decode side by
+        # side, and the loop runs at the host's pace instead of one video latency per batch.
+        from collections import deque
+        in_flight = deque()
+        for i, batch in enumerate(loader):
+            if len(in_flight) == depth:
+                finish(*in_flight.popleft())                  # (frees slot i mod depth)
+            in_flight.append((batch, launch(batch, i % depth)))
+        while in_flight:
+            finish(*in_flight.popleft())
         return predictions

@@ -15,6 +15,7 @@ small-shape inspection; nothing in this package's decode path calls them.
 import math
 from typing import Dict, Set
 
+import contextlib
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -511,21 +512,35 @@ class SemiMarkovModule(nn.Module):
 
     def viterbi_launch(self, features, lengths, valid_classes_per_instance, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None, predict_single=False, return_elp=False,
-                       slot=0):
+                       slot=0, stream=None):
         """``viterbi`` in two halves: this one enqueues the decode and returns at once; calling the returned function waits
         for it and hands out what ``viterbi`` returns.  ONE launch may be outstanding per device AND ``slot`` (the spans land
         in a pinned host buffer that the next launch with the same slot reuses): a caller can collate and launch its next
         batch on the other slot in between (``SemiMarkovModel.predict(fused=False)`` does: the GPU decodes batch i + 1 while
-        the host unpacks batch i)."""
+        the host unpacks batch i).  ``stream``: decode on this stream instead of the current one (it first waits for the
+        current stream, which produced the batch): a batch of five videos occupies five of 256 CUs for as long as its longest
+        video takes, so batches launched on different streams decode side by side."""
         self._require_device(features, 'viterbi')
         valid_classes = self._check_valid_classes(valid_classes_per_instance)
-        self.set_z(features, lengths, use_mean=use_mean_z)
-        # (the spans land in pinned host memory, the error words follow by an asynchronous copy: ONE synchronisation, no
-        # blocking device -> host copy -- this call is host latency at the reference's batch size)
-        out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
-                           want_elp=return_elp, want_labels=False, no_eos=not add_eos, spans_on_host=True, host_slot=slot)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(features.device))
+        ctx = contextlib.nullcontext()
+        if stream is not None:
+            # tables that are not cached yet are built HERE, on the caller's stream, which `stream` then waits for: the
+            # next batch of the same task finds them cached and may run on a third stream that waited for this point too
+            self._decode_tables(valid_classes, features.device)
+            stream.wait_stream(torch.cuda.current_stream(features.device))
+            ctx = torch.cuda.stream(stream)
+        with ctx:
+            self.set_z(features, lengths, use_mean=use_mean_z)
+            # (the spans land in pinned host memory, the error words follow by an asynchronous copy: ONE synchronisation, no
+            # blocking device -> host copy -- this call is host latency at the reference's batch size)
+            out = self._decode(features, lengths, valid_classes, additional_allowed_ends_per_instance, constraints,
+                               want_elp=return_elp, want_labels=False, no_eos=not add_eos, spans_on_host=True, host_slot=slot)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(features.device))
+        if stream is not None:
+            for t in (features, constraints):                # (allocated on the caller's stream, read on this one)
+                if t is not None and t.is_cuda:
+                    t.record_stream(stream)
         tmax = features.size(1)
         b = features.size(0)
 

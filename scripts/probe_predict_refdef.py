@@ -4,6 +4,7 @@ import sys, time, cProfile, pstats
 sys.path.insert(0, '.')
 import numpy as np, torch
 import bench
+torch.set_num_threads(8)      # as bench.py and cli.py do: the box shows 256 CPUs, and a 256-thread pool only adds latency to small host ops
 from action_segmentation_amd import synth
 a = bench.parse(['--workload', 'refdef'])
 dev = torch.device('cuda:0')

@@ -59,6 +59,24 @@ def test_predict_matches_reference_path(constrain, narration):
     assert acc > 0.5                                          # it also segments the synthetic videos sensibly
 
 
+@pytest.mark.parametrize('depth', [1, 3, 8])
+@pytest.mark.parametrize('constrain,narration', [(False, ()), (True, ('test',))])
+def test_predict_per_batch_on_streams_equals_fused(depth, constrain, narration):
+    """predict(fused=False) keeps up to DECODE_DEPTH batches in flight, each on its own stream and pinned result slot once
+    its videos are long (STREAM_MIN_FRAMES): forced on here for the tiny corpus, twice in a row (slots and streams reused)."""
+    data, args, model = build(constrain, narration)
+    args.decode_depth = depth
+    model.STREAM_MIN_FRAMES = 0
+    ref = model.predict(data)
+    for _ in range(2):
+        got = model.predict(data, fused=False)
+        assert set(got) == set(ref)
+        for name in ref:
+            np.testing.assert_array_equal(got[name], ref[name], err_msg=name)
+    streams = model._decode_streams[(str(model.device), depth)]
+    assert len(streams) == depth and all((s is not None) == (depth > 1) for s in streams)
+
+
 def test_predict_results_stay_valid_while_referenced_and_their_buffers_are_reused_afterwards():
     """predict() hands out views of a pinned label buffer on lease (ops.lease_host_labels): a result the caller still holds
     must survive later decodes -- also when more results are alive than there are leases (the copy path) -- and a

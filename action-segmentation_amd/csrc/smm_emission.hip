@@ -29,6 +29,13 @@ typedef double smm_d4 __attribute__((ext_vector_type(4)));
 typedef float smm_f4 __attribute__((ext_vector_type(4)));
 
 #define SMM_EM_WAVES 8
+#ifndef SMM_EM_PAIR
+#define SMM_EM_PAIR 1            // tiles in pairs per wave (smm_emission_pair_kernel); 0: one at a time (A/B aid)
+#endif
+#ifndef SMM_EM_ABLATE
+#define SMM_EM_ABLATE 0           // development builds only (results WRONG, timing experiments): bit 0 no x^2 term,
+                                  // bit 1 no loads of x, bit 2 no MFMA (one VALU add each instead), bit 3 no 4x4x4 MFMAs
+#endif
 #ifndef SMM_EM_TILES_PER_WAVE
 #define SMM_EM_TILES_PER_WAVE 4   // same-box A/B on cfg3 (scripts/ab_prof.sh): 2: 0.611 ms, 3: 0.598, 4: 0.593, 8: 0.601, 16: 0.64
 #endif
@@ -139,7 +146,8 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                 const int ms = (4 * lc + m < nms) ? 4 * lc + m : nms - 1;
                 int db = 16 * ms + 4 * kq;                           // this lane's 4 features of the macro-step
                 db = db + 3 < D ? db : D - 4;                        // (the zero-padded weights ignore what is read there)
-                buf[m] = *reinterpret_cast<const float4 *>(xrow + db);
+                if (SMM_EM_ABLATE & 2) buf[m] = make_float4((float)db, 1.f, 2.f, (float)f);
+                else buf[m] = *reinterpret_cast<const float4 *>(xrow + db);
             }
         } else {
 #pragma unroll
@@ -199,16 +207,19 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
                         for (int g4 = 0; g4 < NG; ++g4)
                             wg[g4] = wl[(size_t)(16 * ms + 4 * kq + j) * WS + 16 + 4 * (g4 < ng1 ? g4 : 0) + jj];
                     }
+                    if (SMM_EM_ABLATE & 4) { acc[j] += av[j] + wcur[j]; if constexpr (NT == 2) acc1[0] += wg[0] + wg[NG - 1]; }
+                    else {
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], wcur[j], acc, 0, 0, 0);
                     if constexpr (NT == 2) {
 #pragma unroll
                         for (int g4 = 0; g4 < NG; ++g4)
-                            if (g4 < ng1) acc1[g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[j], wg[g4], acc1[g4], 0, 0, 0);
+                            if (g4 < ng1 && !(SMM_EM_ABLATE & 8)) acc1[g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[j], wg[g4], acc1[g4], 0, 0, 0);
+                    }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    q = fma(av[j] * iv4[j], av[j], q);
+                    if (!(SMM_EM_ABLATE & 1)) q = fma(av[j] * iv4[j], av[j], q);
                     wcur[j] = wnext[j];
                 }
             }
@@ -258,6 +269,245 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     // latency; the extra prologue fetch only delays the first MFMA.)
     float4 b0[4], b1[4];
     float c0[CONS ? 4 * NT : 1], c1[CONS ? 4 * NT : 1];
+    fetch(b0, c0);
+    for (int it = 0; it < total; it += 2) {
+        fetch(b1, c1);
+        consume(b0, c0);
+        if (it + 1 >= total) break;
+        fetch(b0, c0);
+        consume(b1, c1);
+    }
+}
+
+// The same kernel on PAIRS of tiles (round 4).  Template arguments as above.
+// CONS narration constraints are added (they travel through the same pipeline as x: a load in the epilogue would make
+//      the wave wait for every x load in flight)
+// NG  (NT = 2) 4-state groups behind the first 16 states that the launch's largest class set needs: 1..4
+template <int NT, bool VEC, bool CONS, int NG>
+__global__ void __launch_bounds__(SMM_EM_WAVES * 64)
+smm_emission_pair_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restrict__ order, const int32_t *__restrict__ n_states,
+                    const float *__restrict__ xall, const double *__restrict__ wall, const double *__restrict__ cstall,
+                    const double *__restrict__ iv, const float *__restrict__ cons, double *__restrict__ elp64,
+                    float *__restrict__ elp32, int D, int cm, int tpw, const int32_t *__restrict__ blk_cum, int nvid, int blk_base)
+{
+    // LDS: this group's weights (zero padded), row d = w[d][0 .. 16 NT), then inv_var[D16].  Row stride 20 (NT = 1) /
+    // 36 (NT = 2) doubles: rows 4 apart -- the two k groups of a ds_read_b64 half-wave -- land 128 B apart modulo the
+    // 256-B bank span and do not collide.
+    // NT = 2 (17..32 states): states 0..15 are one 16x16x4 tile as for NT = 1; states 16.. go through
+    // v_mfma_f64_4x4x4_4b_f64 in groups of FOUR: its four blocks are the four 4-frame groups of the tile, all with the
+    // same B (A[i][k] of block b: lane 16 k + 4 b + i -- the lane <-> (frame, k) mapping of the A operand above, so the
+    // x registers serve both forms; B[k][j]: lane 16 k + 4 b + j; D[i][j]: lane 16 i + 4 b + j).  16 cycles per group
+    // and 4 features against 64 for a second 16-state tile (same FLOP rate at a quarter of the granularity,
+    // profiles/round2_ubench_mfma_f64_4x4.txt): 21..24 states cost 96 cycles instead of 128, 17..20 cost 80.
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    // flat grid: blk_cum[i] = workgroups of the videos order[0..i) (longest videos first: no long workgroup starts late)
+    // (blk_base: a launch may cover only the videos order[v0 .. v0 + nvid) -- blk_cum and order arrive offset by v0 and the
+    // cumulative block counts stay absolute)
+    const int bid = blockIdx.x + blk_base;
+    const int slot = smm_em_find_video(blk_cum, nvid, bid);
+    const int chunk = bid - blk_cum[slot];
+    const int vid = order[slot];
+    const SmmVideo mv = videos[vid];
+    const int T = mv.T, g = mv.group;
+    const int C = n_states[g];
+    const int ntiles = (T + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
+    const int nbv = blk_cum[slot + 1] - blk_cum[slot];
+    const int D16 = (D + 15) & ~15;
+    constexpr int WS = (NT == 2) ? 36 : 20;                          // LDS row stride (doubles)
+    const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // more than the first 16-state tile?
+    const int ng1 = (NT == 2 && C > 16) ? (C - 13) >> 2 : 0;         // groups of 4 states behind it: ceil((C - 16) / 4)
+    double *ivl = wl + (size_t)D16 * WS;
+    {
+        const double *__restrict__ w = wall + (size_t)g * D * cm;
+        for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
+            const int d = i / (16 * NT), c = i - d * (16 * NT);
+            wl[(size_t)d * WS + c] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
+        }
+        for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
+    }
+    __syncthreads();
+    const int fr = lane & 15, kq = lane >> 4;
+    const int jj = lane & 3, row1 = (fr & 12) + kq;                  // 4x4x4 result: state 16 + 4 g + jj of frame row1
+    const float *__restrict__ xv = xall + (size_t)mv.frame_off * D;
+    const double *__restrict__ cst = cstall + (size_t)g * cm;
+
+    // PAIRS of tiles (32 consecutive frames): the B operands of a macro-step -- 4 + 4 NG ds_read_b64 per wave, the kernel's
+    // LDS traffic -- are read once and feed the MFMAs of both tiles
+    const int npairs = (ntiles + 1) >> 1;
+    const int tile0 = chunk * SMM_EM_WAVES + wave, tstride = nbv * SMM_EM_WAVES;   // (in pairs)
+    if (tile0 >= npairs) return;
+    const int nmy = (npairs - tile0 + tstride - 1) / tstride;        // pairs of this wave
+    const int nms = D16 >> 4;                                        // macro-steps of 16 features per tile
+    constexpr int MC = 2;                                            // macro-steps per chunk (x 2 tiles: 4 KB per wave, as before)
+    const int nch = (nms + MC - 1) / MC;                             // chunks per pair
+    const int total = nmy * nch;                                     // chunk sequence of this wave
+
+    // fetch side of the pipeline: chunk (lt, lc) = tile tile0 + lt * tstride, macro-steps 4 lc .. 4 lc + 3
+    int lt = 0, lc = 0;
+    // (branch-free on the vector path: tiles past the end re-read the last tile, macro-steps past the end re-read the
+    // last macro-step -- cache hits that are never consumed -- so that the compiler can count the loads in flight
+    // instead of waiting for all of them)
+    auto fetch = [&](float4 (&buf)[2][MC], float (&cb)[2][CONS ? 4 * NT : 1]) {
+        const int ltc = lt < nmy ? lt : nmy - 1;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int f0 = (2 * (tile0 + ltc * tstride) + tl) << 4;
+            const int f = (f0 + fr < T) ? f0 + fr : T - 1;           // clamp: rows past the end are computed, not stored
+            const float *__restrict__ xrow = xv + (size_t)f * D;
+            if constexpr (CONS) {
+                // constraints of this chunk's tile in the accumulator layout (used by the pair's last chunk only)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ff = f0 + kq + 4 * i;
+                    const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
+                    cb[tl][i] = cons[rowo + (fr < cm ? fr : cm - 1)];
+                }
+                if constexpr (NT == 2) {                             // states 16 + 4 g + jj of frame row1 (4x4x4 result layout)
+                    const int ff = f0 + row1;
+                    const size_t rowo = (size_t)(mv.frame_off + (ff < T ? ff : T - 1)) * cm;
+#pragma unroll
+                    for (int g4 = 0; g4 < NG; ++g4) {
+                        const int c = 16 + 4 * g4 + jj;
+                        cb[tl][4 + g4] = cons[rowo + (c < cm ? c : cm - 1)];
+                    }
+                }
+            }
+            if constexpr (VEC) {
+#pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    const int ms = (MC * lc + m < nms) ? MC * lc + m : nms - 1;
+                    int db = 16 * ms + 4 * kq;                       // this lane's 4 features of the macro-step
+                    db = db + 3 < D ? db : D - 4;                    // (the zero-padded weights ignore what is read there)
+                    buf[tl][m] = *reinterpret_cast<const float4 *>(xrow + db);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    const int db = 16 * (MC * lc + m) + 4 * kq;
+                    float4 r;
+                    r.x = (db + 0 < D) ? xrow[db + 0] : 0.f;
+                    r.y = (db + 1 < D) ? xrow[db + 1] : 0.f;
+                    r.z = (db + 2 < D) ? xrow[db + 2] : 0.f;
+                    r.w = (db + 3 < D) ? xrow[db + 3] : 0.f;
+                    buf[tl][m] = r;
+                }
+            }
+        }
+        if (++lc == nch) { lc = 0; ++lt; }
+    };
+
+    // compute side
+    int ct = 0, cc = 0;
+    smm_d4 acc[2] = {(smm_d4){0.0, 0.0, 0.0, 0.0}, (smm_d4){0.0, 0.0, 0.0, 0.0}};
+    constexpr int G1 = (NT == 2) ? NG : 1;                           // (NT = 1: unused dummies)
+    double acc1[2][G1];
+#pragma unroll
+    for (int g4 = 0; g4 < G1; ++g4) { acc1[0][g4] = 0.0; acc1[1][g4] = 0.0; }
+    double q[2] = {0.0, 0.0};
+    const double cstv = (fr < C) ? cst[fr] : 0.0;
+    double cst1[G1];
+#pragma unroll
+    for (int g4 = 0; g4 < G1; ++g4) cst1[g4] = (NT == 2 && 16 + 4 * g4 + jj < C) ? cst[16 + 4 * g4 + jj] : 0.0;
+    // B operands: as in smm_emission_kernel (the 16x16x4 tile's a macro-step ahead, the 4x4x4 groups' at the top of their
+    // j step), each read serving the MFMAs of BOTH tiles of the pair
+    double wcur[4];
+    auto load_ops = [&](int ms, double (&wv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = wl[(size_t)(16 * ms + 4 * kq + j) * WS + fr];
+    };
+    load_ops(0, wcur);
+    auto consume = [&](const float4 (&buf)[2][MC], const float (&cb)[2][CONS ? 4 * NT : 1]) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            const int ms = MC * cc + m;
+            if (ms < nms) {
+                double wnext[4], iv4[4];
+                load_ops(ms + 1 < nms ? ms + 1 : 0, wnext);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) iv4[j] = ivl[16 * ms + 4 * kq + j];
+                double av[2][4];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    av[tl][0] = (double)buf[tl][m].x; av[tl][1] = (double)buf[tl][m].y;
+                    av[tl][2] = (double)buf[tl][m].z; av[tl][3] = (double)buf[tl][m].w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double wg[G1];
+                    if constexpr (NT == 2) {
+#pragma unroll
+                        for (int g4 = 0; g4 < NG; ++g4)
+                            wg[g4] = wl[(size_t)(16 * ms + 4 * kq + j) * WS + 16 + 4 * (g4 < ng1 ? g4 : 0) + jj];
+                    }
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tl][j], wcur[j], acc[tl], 0, 0, 0);
+                        if constexpr (NT == 2) {
+#pragma unroll
+                            for (int g4 = 0; g4 < NG; ++g4)
+                                if (g4 < ng1) acc1[tl][g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[tl][j], wg[g4], acc1[tl][g4], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[0] = fma(av[0][j] * iv4[j], av[0][j], q[0]);
+                    q[1] = fma(av[1][j] * iv4[j], av[1][j], q[1]);
+                    wcur[j] = wnext[j];
+                }
+            }
+        }
+        if (++cc < nch) return;
+        // pair finished.  q: this lane summed the features with k index kq of frame fr; add the four k groups
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int f0 = (2 * (tile0 + ct * tstride) + tl) << 4;
+            double qq = q[tl];
+            qq += __shfl_xor(qq, 16);
+            qq += __shfl_xor(qq, 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = kq + 4 * i;                          // frame of accumulator register i
+                const double qr = __shfl(qq, row);
+                const int ff = f0 + row;
+                if (ff < T && fr < C) {
+                    const size_t o = (size_t)(mv.frame_off + ff) * cm + fr;
+                    double v = (cstv + acc[tl][i]) - 0.5 * qr;
+                    if constexpr (CONS) v += (double)cb[tl][i];
+                    if (elp64) elp64[o] = v;
+                    if (elp32) elp32[o] = (float)v;
+                }
+            }
+            if constexpr (NT == 2) {                                 // 4x4x4 groups: frame row1, states 16 + 4 g + jj
+                const double qr = __shfl(qq, row1);
+                const int ff = f0 + row1;
+#pragma unroll
+                for (int g4 = 0; g4 < NG; ++g4) {
+                    const int c = 16 + 4 * g4 + jj;
+                    if (g4 < ng1 && ff < T && c < C) {
+                        const size_t o = (size_t)(mv.frame_off + ff) * cm + c;
+                        double v = (cst1[g4] + acc1[tl][g4]) - 0.5 * qr;
+                        if constexpr (CONS) v += (double)cb[tl][4 + g4];
+                        if (elp64) elp64[o] = v;
+                        if (elp32) elp32[o] = (float)v;
+                    }
+                    acc1[tl][g4] = 0.0;
+                }
+            }
+            acc[tl] = (smm_d4){0.0, 0.0, 0.0, 0.0};
+            q[tl] = 0.0;
+        }
+        cc = 0;
+        ++ct;
+    };
+
+    // two chunk buffers: one in flight while the other feeds the MFMAs.  (A third -- the 4x4x4 form left the registers for
+    // it -- measured 1 % SLOWER on the same box, cfg2 and cfg3: two chunks per wave x 16 waves per CU already cover the
+    // latency; the extra prologue fetch only delays the first MFMA.)
+    float4 b0[2][MC], b1[2][MC];
+    float c0[2][CONS ? 4 * NT : 1], c1[2][CONS ? 4 * NT : 1];
     fetch(b0, c0);
     for (int it = 0; it < total; it += 2) {
         fetch(b1, c1);
@@ -530,11 +780,17 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
         return;
     }
     const int ng = ct <= 16 ? 0 : (ct - 13) >> 2;                            // 4-state groups behind the first 16 states
+    // tiles in PAIRS (each read of the weights from LDS feeds two tiles' MFMAs: cfg3 0.645 -> 0.584 ms, bit-identical) where the
+    // second tile's registers leave 4 waves per SIMD (<= 128 VGPRs: 16-byte loads, <= 28 states, constraints only up to 16
+    // states) and the launch is large enough for >= 2 tiles per wave (a small one loses parallelism to pairs: cfg4)
+    const bool pair = SMM_EM_PAIR && vec && tpw >= 2 && (a.cons ? ng == 0 : ng <= 3);
 #define SMM_EM_V1(NG_)                                                                          \
     switch ((vec ? 2 : 0) + (a.cons ? 1 : 0)) {                                                 \
     case 0: go1(smm_emission_kernel<2, false, false, NG_>); break;                             \
     case 1: go1(smm_emission_kernel<2, false, true, NG_>); break;                              \
-    case 2: go1(smm_emission_kernel<2, true, false, NG_>); break;                              \
+    case 2: if (pair) go1(smm_emission_pair_kernel<2, true, false, (NG_ <= 3 ? NG_ : 3)>);     \
+            else go1(smm_emission_kernel<2, true, false, NG_>);                                \
+            break;                                                                             \
     default: go1(smm_emission_kernel<2, true, true, NG_>); break;                              \
     }
     switch (ng) {
@@ -542,8 +798,8 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
         switch ((vec ? 2 : 0) + (a.cons ? 1 : 0)) {
         case 0: go1(smm_emission_kernel<1, false, false, 0>); break;
         case 1: go1(smm_emission_kernel<1, false, true, 0>); break;
-        case 2: go1(smm_emission_kernel<1, true, false, 0>); break;
-        default: go1(smm_emission_kernel<1, true, true, 0>); break;
+        case 2: if (pair) go1(smm_emission_pair_kernel<1, true, false, 0>); else go1(smm_emission_kernel<1, true, false, 0>); break;
+        default: if (pair) go1(smm_emission_pair_kernel<1, true, true, 0>); else go1(smm_emission_kernel<1, true, true, 0>); break;
         }
         break;
     case 1: SMM_EM_V1(1) break;

@@ -366,6 +366,40 @@ def test_emission_matches_oracle(cfg):
         np.testing.assert_allclose(e32[i, :t], ref[i, :t], rtol=2e-7, atol=1e-6)
 
 
+@pytest.mark.parametrize('cfg', [(9, False), (9, True), (16, True), (18, False), (23, False), (27, False), (30, False), (23, True)])
+def test_emission_on_pairs_of_tiles_matches_oracle(cfg):
+    """Launches of >= 2 tiles per wave (>= 131 072 frames) walk the frame axis in PAIRS of 16-frame tiles that share the
+    weights they read from LDS (smm_emission_pair_kernel: up to 28 states, constraints up to 16 states; the others stay on
+    the one-tile kernel): ragged lengths with odd tile counts, a video shorter than one tile, every 4-state group count."""
+    ops = _ops()
+    c, with_cons = cfg
+    d, b = 24, 46
+    g = np.random.default_rng(c * 7 + with_cons)
+    lengths = g.integers(3000, 3700, size=b)
+    lengths[0], lengths[1], lengths[2], lengths[3] = 3700, 9, 3216 + 16, 3216 + 17      # longest; < 1 tile; odd tile counts
+    tmax = int(lengths.max())
+    assert int(lengths.sum()) >= 131072
+    x = g.standard_normal((b, tmax, d)).astype(np.float32)
+    mu = g.standard_normal((c, d)) * 0.5
+    var = 0.5 + g.random(d)
+    cons = (g.random((b, tmax, c)) < 0.05) * -1e4 if with_cons else None
+    lognorm = float(-0.5 * d * np.log(2 * np.pi) - 0.5 * np.log(var).sum())
+    ref = F.emission(x, lengths, mu, 1.0 / var, lognorm, cons)
+    dev = torch.device('cuda:0')
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    offs = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    xp = np.concatenate([x[i, :t] for i, t in enumerate(lengths)])                       # packed frame axis
+    cp = None if cons is None else torch.tensor(np.concatenate([cons[i, :t] for i, t in enumerate(lengths)]),
+                                                dtype=torch.float32, device=dev)
+    batch = ops.Batch(lengths, [c], 4, t_max=tmax, frame_offset=offs, total_frames=int(lengths.sum()), d=d)
+    e64, _ = ops.emission(batch, torch.tensor(xp, device=dev), t64((mu / var).T[None]),
+                          t64((lognorm - 0.5 * (mu * mu / var).sum(1))[None]), t64(1.0 / var), cp)
+    torch.cuda.synchronize()
+    e64 = e64.cpu().numpy()
+    for i, t in enumerate(lengths):
+        np.testing.assert_allclose(e64[offs[i]:offs[i] + t], ref[i, :t], rtol=1e-12, atol=1e-9, err_msg='video %d' % i)
+
+
 @pytest.mark.parametrize('cfg', [(7, 700, 200, (12, 21, 5)), (3, 90, 40, (7,)), (4, 300, 257, (30, 17)),
                                  (5, 520, 256, (9, 24, 16, 3)), (40, 37, 12, (4, 8))])
 def test_emission_chain_rule_matches_torch(cfg):

@@ -72,7 +72,10 @@ def _dev(t, dtype, name):
 def _raw_stream():
     """Handle of torch's current stream on the current device, by the C-level getters (torch.cuda.current_stream() builds a
     Stream object and resolves the device through three python layers: ~10 us, twice per call, of a 150 us viterbi())."""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    get = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if get is None:                                    # (a torch build without the C-level getter)
+        return torch.cuda.current_stream().cuda_stream
+    return get(torch._C._cuda_getDevice())
 
 
 def _stream():

@@ -184,6 +184,11 @@ def main(argv=None):
     dev = torch.device('cuda', torch.cuda.current_device())
     train_data = synth.SynthDatasplit(cfg_name, seed=args.seed, device=dev)
     test_data = synth.SynthDatasplit(cfg_name, seed=args.seed, video_seed=1, device=dev)     # same label space
+    # the datasplits are thousands of long-lived tensors: out of the collector's sight, or every full collection a decode's
+    # few hundred result arrays trigger walks all of them (60-90 ms beside a 3 ms predict: scripts/probe_predict_fused.py)
+    import gc
+    gc.collect()
+    gc.freeze()
     if args.model_input_path:
         with open(make_model_path(args.model_input_path, split_name), 'rb') as f:
             model = pickle.load(f)

@@ -122,3 +122,37 @@ def test_shard_costs_follow_the_kernel_that_will_run():
     frames = sum(int(data[k]['features'].shape[0]) for k in keys)
     per_frame = batch_cost(data, keys, 1024) / frames
     assert 170.0 < per_frame < 170.0 + 3.3 * 33
+
+
+def test_label_lease_pool_follows_the_last_reference(monkeypatch):
+    """ops.lease_host_labels (the pinned buffers SemiMarkovModel.predict hands out views of): a buffer is out for as long as
+    ANYTHING shares its storage -- a numpy slice made from the tensor counts, the tensor object itself need not survive --,
+    at most LABEL_LEASES are out at once, and a dropped one is the next to be handed out.  (Pageable stand-ins for the pinned
+    allocations: there is no GPU here; the GPU test covers the real thing.)"""
+    from action_segmentation_amd import ops
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, 'empty', lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != 'pin_memory'}))
+    monkeypatch.setattr(ops, '_label_leases', {})
+
+    class B:
+        def __init__(self, n, covered=None):
+            self.total_frames, self.lengths = n, np.array([n if covered is None else covered])
+    dev = torch.device('cuda', 0)
+    if ops._storage_users(real_empty(1)) is None:
+        assert ops.lease_host_labels(B(10), dev) is None          # a torch build that cannot tell never leases
+        return
+    a = ops.lease_host_labels(B(100), dev)
+    view = a.numpy()[3:7]                                         # what predict() returns: numpy views
+    ptr_a = a.data_ptr()
+    del a
+    taken = [ops.lease_host_labels(B(100), dev) for _ in range(ops.LABEL_LEASES - 1)]
+    assert all(t is not None and t.data_ptr() != ptr_a for t in taken)
+    assert ops.lease_host_labels(B(100), dev) is None             # all out
+    del view
+    again = ops.lease_host_labels(B(50), dev)
+    assert again is not None and again.data_ptr() == ptr_a and again.numel() == 50
+    del again, taken
+    padded = ops.lease_host_labels(B(80, covered=60), dev)        # frames no video covers keep the -1 filler
+    assert padded.numel() == 80 and int(padded.min()) == -1 and int(padded.max()) == -1
+    bigger = ops.lease_host_labels(B(1000), dev)                  # a free buffer that is too small is replaced, not added
+    assert bigger.numel() == 1000 and len(ops._label_leases[0]) <= ops.LABEL_LEASES

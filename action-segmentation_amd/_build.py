@@ -19,8 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
          "-mllvm", "-pragma-unroll-threshold=1048576", "-mllvm", "-unroll-threshold=1048576"]
 
 
-# per translation unit: the Viterbi kernels take fmax() as a bare v_max_f64 (smm_device.h: smm_fmax) -- no NaN ever enters
-# the DP (inputs are finite or -inf and nothing subtracts infinities), and -fno-honor-nans says so to the compiler
+# per translation unit: the Viterbi kernels take fmax() as a bare v_max_f64 (smm_device.h: smm_fmax): inputs are finite or
+# -inf by contract and -fno-honor-nans says so to the compiler.  What still has to work when the contract is broken -- the
+# error word for a NaN in the inputs -- is done on the bits (smm_nan_bits), never by a float compare that is meant to fail;
+# the two one-sided tests that can subtract -inf from -inf (DOM, SPEC) take either compare result (smm_device.h)
 UNIT_FLAGS = {"smm_viterbi.hip": ["-fno-honor-nans", "-DSMM_FMAX_BUILTIN"]}
 
 
@@ -80,9 +82,11 @@ def kernel_resources(lib=LIB):
     import struct
     import tempfile
     readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(lib) or not os.path.exists(readelf):
+        return {}                      # (nothing built / no tool: the caller skips)
     blob = open(lib, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    out = {}
+    out = {}                           # (stays empty for a compressed bundle -- magic CCOB, --offload-compress: the caller skips)
     pos = blob.find(magic)
     while pos >= 0:
         n = struct.unpack_from("<Q", blob, pos + len(magic))[0]

@@ -1,5 +1,6 @@
 // smm_api.hip -- host side of libsmmdp.so: argument checks, launch planning, C ABI (include/smmdp.h).
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <cstdio>
 #include <cstdlib>
@@ -40,7 +41,10 @@ struct SmmEnv {
 #endif
     std::string key;          // what the planning functions depend on, for the resident plans' keys
 };
-SmmEnv g_env;
+// The current set of switches.  Other threads hold `const SmmEnv &` from env() across a whole call (plan_key reads
+// env().key), so a reload never writes into a struct that has been published: it publishes a NEW one, and the old ones
+// stay allocated (a few hundred bytes per smm_env_reload(), which only tests and A/B scripts call).
+std::atomic<const SmmEnv *> g_env{nullptr};
 std::once_flag g_env_once;
 
 void env_read()
@@ -64,12 +68,12 @@ void env_read()
         if (it.d) *it.d = std::atof(v);
         e.key += it.name; e.key += '='; e.key += v; e.key += ';';
     }
-    g_env = e;
+    g_env.store(new SmmEnv(e), std::memory_order_release);
 }
 const SmmEnv &env()
 {
     std::call_once(g_env_once, env_read);
-    return g_env;
+    return *g_env.load(std::memory_order_acquire);
 }
 }  // namespace
 
@@ -324,7 +328,7 @@ struct PlanEntry {
 struct PlanSlabs {                                                      // per device: metadata buffers are cut from 1 MB slabs
     char *cur = nullptr;
     size_t left = 0;
-    std::vector<char *> all;
+    std::vector<std::pair<char *, size_t>> all;                         // (slab, its real size: a plan larger than 1 MB gets its own)
 };
 struct PlanCache {
     std::mutex mu;
@@ -352,7 +356,7 @@ char *plan_alloc(size_t bytes, int dev)
         const size_t want = std::max(bytes, SMM_PLAN_SLAB);
         char *p = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&p), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        sl.all.push_back(p);               // (the rest of the previous slab is given up)
+        sl.all.emplace_back(p, want);      // (the rest of the previous slab is given up)
         sl.cur = p;
         sl.left = want;
     }
@@ -509,7 +513,7 @@ extern "C" size_t smm_release_cached_plans(void)
         PlanSlabs &sl = g_plans.slabs[d];
         if (sl.all.empty()) continue;
         (void)hipSetDevice(d);
-        for (char *p : sl.all) if (hipFree(p) == hipSuccess) freed += SMM_PLAN_SLAB;
+        for (auto &ps : sl.all) if (hipFree(ps.first) == hipSuccess) freed += ps.second;
         sl = PlanSlabs{};
     }
     if (have_cur) (void)hipSetDevice(cur);
@@ -521,7 +525,8 @@ extern "C" size_t smm_cached_plan_bytes(void)
 {
     std::lock_guard<std::mutex> lock(g_plans.mu);
     size_t n = 0;
-    for (int d = 0; d < 64; ++d) n += g_plans.slabs[d].all.size() * SMM_PLAN_SLAB;
+    for (int d = 0; d < 64; ++d)
+        for (auto &ps : g_plans.slabs[d].all) n += ps.second;
     return n;
 }
 

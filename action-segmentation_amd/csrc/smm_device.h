@@ -102,8 +102,21 @@ __device__ __forceinline__ float smm_wave_ror1f(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), SMM_DPP_WAVE_ROR1, 0xf, 0xf, false));
 }
 
+// NaN by its BITS (exponent all ones, mantissa non-zero).  The Viterbi translation unit is compiled with -fno-honor-nans
+// (see smm_fmax): a floating-point compare that is meant to FAIL for a NaN is formally poison there and may be folded, so
+// the error-word contract of smmdp.h ("a NaN reached the DP -> err[0] = 1, the back-trace stops") rests on integer tests
+// only.  The empty asm keeps the compiler from reasoning about where the bits came from.
+__device__ __forceinline__ bool smm_nan_bits(double x)
+{
+    int hi = __double2hiint(x), lo = __double2loint(x);
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    return (hi & 0x7ff00000) == 0x7ff00000 && (((hi & 0x000fffff) | lo) != 0);
+}
+
 // v_max_f64 without the canonicalising self-max hipcc puts in front of fmax() operands it cannot prove quiet
-// (no NaNs ever enter the DP: inputs are finite or -inf and nothing subtracts infinities).
+// (inputs are finite or -inf by contract; a NaN that enters anyway -- or an inf - inf of the two one-sided tests that subtract
+// possibly infinite values, DOM's h[s+1] - h[s] and SPEC's gamma[c] - gamma[cs]: their compares read a NaN as "not beaten" /
+// "objects", the conservative side -- is swallowed by v_max_f64 or caught by smm_nan_bits in the back-trace).
 __device__ __forceinline__ double smm_fmax(double a, double b)
 {
 #ifdef SMM_FMAX_BUILTIN

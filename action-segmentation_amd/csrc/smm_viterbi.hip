@@ -1331,6 +1331,9 @@ smm_viterbi_kernel(SmmDpArgs a)
                             wgt = (to == C) ? ep_l : tab_t[(size_t)to * C + lane];
                             gmv = win_g[(size_t)row * C + lane] + wgt;
                         }
+                        // a NaN in the row (the inputs broke the contract): by its bits -- this unit is compiled with
+                        // -fno-honor-nans, a compare that is meant to fail proves nothing here (smm_nan_bits)
+                        if (__ballot(lane < C && smm_nan_bits(gmv)) != 0) { bad = true; break; }
                         const double rmax = smm_row_max16(gmv);
                         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
                         unsigned long long fmask = __ballot(lane < C && gmv == best);
@@ -1428,9 +1431,11 @@ smm_viterbi_kernel(SmmDpArgs a)
     if (n > 0) trip(n, to);
     while (n > 0) {
         const double gmv = (lane < C) ? g0 + wgt : SMM_NEG_INF;
+        // a NaN in the row (the inputs broke the contract): detected by its bits, in every wave alike (smm_nan_bits)
+        const bool nan_row = __ballot(lane < C && smm_nan_bits(gmv)) != 0;
         const double rmax = smm_row_max16(gmv);
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
-        unsigned long long fmask = __ballot(lane < C && gmv == best);
+        unsigned long long fmask = nan_row ? 0ull : __ballot(lane < C && gmv == best);
         int k = 0x7fffffff, c = 0x7fffffff;
         SMM_BT_STAMP(bt_a);
         while (fmask) {
@@ -1461,7 +1466,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             }
         }
         SMM_BT_STAMP(bt_b);
-        if (k < 1 || k > kmax || c < 0 || c >= C) {           // NaN / inf-inf in the inputs: stop, flag, never spin
+        if (nan_row || k < 1 || k > kmax || c < 0 || c >= C) {   // NaN in the inputs / no candidate attains the maximum: stop, flag, never spin
             if (threadIdx.x == 0) atomicExch(a.err, 1);
             break;
         }

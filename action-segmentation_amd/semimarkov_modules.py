@@ -587,6 +587,10 @@ class SemiMarkovModule(nn.Module):
                          class_map=g1[5], want_spans=want_spans, want_labels=want_labels,
                          want_elp=want_elp, spans_on_host=spans_on_host, host_slot=host_slot)
         out['_batch'] = batch
+        # the cached tables and end penalties are read by kernels that may run on a side stream (viterbi_launch) long after
+        # this call has returned, and the caches evict (`cache.clear()` above 64 / 256 entries): the pending result keeps what
+        # its launch reads alive until the caller has synchronised on it
+        out['_keep'] = (tab, g1, endpen, x, cons)
         return out
 
     # ------------------------------------------------------------------ packed multi-task decode

@@ -13,13 +13,15 @@ N > 1: one process per GPU.  Under ``torchrun`` (RANK / WORLD_SIZE in the enviro
 plainly as ``python bench.py --gpus N`` it spawns the N ranks itself as child processes BEFORE touching the GPU and
 relays rank 0's line.  Either way the job fails (non-zero exit) unless the group comes up with exactly N ranks on RCCL
 (backend "nccl"); ``--backend gloo`` is an explicit opt-in for rehearsals without one GPU per rank.
-  * headline (``scaling: weak``): every rank decodes its own cfg3-sized corpus (seed + rank); videos are independent, so
-    there is no data-path collective; RCCL carries the MAX of the step time and the SUM of the frame counters;
-  * ``strong_scaling`` (second object in the same line, N > 1 or --strong-leg): ONE corpus (default cfg5 = the full
-    CrossTask primary set, 2754 videos) sharded by video over the ranks (distributed.shard_batches), every rank decodes
-    its share, and the reference's evaluation counters (Datasplit.accuracy_corpus, src/data/corpus.py:405-604, summed
-    as src/main.py:486-532 does) are all-reduced over RCCL before they are finalised: the statistics printed are those
-    of the whole corpus and do not depend on N.  ``--scaling strong`` makes this leg the headline instead.
+  * headline, at EVERY N (``scaling: weak``; the same ``config.workload`` string for N = 1, 2, 4, 8): every rank decodes
+    its own cfg3-sized corpus (seed + rank); videos are independent, so there is no data-path collective; RCCL carries
+    the MAX of the step time and the SUM of the frame counters;
+  * ``strong_scaling`` (second object in the same line, at every N including 1; --no-strong-leg skips it): ONE corpus
+    (default cfg5 = the full CrossTask primary set, 2754 videos) sharded by video over the ranks
+    (distributed.shard_batches), every rank decodes its share, and the reference's evaluation counters
+    (Datasplit.accuracy_corpus, src/data/corpus.py:405-604, summed as src/main.py:486-532 does) are all-reduced over
+    RCCL before they are finalised: the statistics printed are those of the whole corpus and do not depend on N.
+    ``--scaling strong`` makes this leg the headline instead -- again at every N, so a curve never mixes the two.
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (the DP kernel), timed live with HIP events
 on the stream it is launched on; ``cpu_baseline`` is the oracle's dense reference-path restatement on a bounded
@@ -56,11 +58,12 @@ def parse(argv=None):
     p.add_argument('--labels-via-copy', action='store_true',
                    help='labels to a device tensor + D->H copy through a pinned buffer instead of kernel stores to pinned host memory')
     p.add_argument('--scaling', default=None, choices=['weak', 'strong'],
-                   help='which leg is the headline value when N > 1 (the other one is reported beside it).  Default: strong '
-                        '(BASELINE config 5: ONE corpus sharded by video over the ranks) for N > 1, weak for N = 1')
+                   help='which leg is the headline value (the other one is reported beside it), the same for every N.  Default: '
+                        'weak (every rank its own cfg3-sized corpus: the workload BASELINE.json quotes the metric on); strong = '
+                        'BASELINE config 5, ONE corpus sharded by video over the ranks')
     p.add_argument('--strong-workload', default='cfg5', choices=['cfg3', 'cfg5', 'cfg4', 'tiny'],
                    help='corpus of the strong-scaling leg (one corpus, seed --seed, sharded by video over the ranks)')
-    p.add_argument('--strong-leg', action='store_true', help='run the strong-scaling leg with one rank too')
+    p.add_argument('--strong-leg', action='store_true', help='(kept for old command lines: the strong-scaling leg runs at every N since round 5)')
     p.add_argument('--no-strong-leg', action='store_true')
     p.add_argument('--no-predict-e2e', action='store_true', help='skip the SemiMarkovModel.predict wall-time figures')
     p.add_argument('--second-seed', type=int, default=1000,
@@ -81,7 +84,7 @@ def parse(argv=None):
     if a.gpus < 1:
         p.error('--gpus must be >= 1')
     if a.scaling is None:
-        a.scaling = 'strong' if a.gpus > 1 else 'weak'
+        a.scaling = 'weak'                  # ONE headline leg for every N (a 1 -> 8 curve must not change workload)
     return a
 
 
@@ -720,6 +723,23 @@ def pmc_traffic(workload):
         return None, None
 
 
+def weak_workload_text(a, cfg, lengths, n_states):
+    """``config.workload`` of the weak leg: a function of the workload name, the seed and rank 0's corpus STRUCTURE only, so
+    that the N = 1 line, the N > 1 lines and the host-only rehearsal all print the same string (tests/test_bench_spawn.py)."""
+    lengths = [int(t) for t in lengths]
+    return ("%s seed %d: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
+            "task (mean over videos %.1f; per task: %s), max span length %d, D=%d; closed-form-fitted HSMM parameters"
+            % (a.workload, a.seed, cfg['n_tasks'], len(lengths) // cfg['n_tasks'], sum(lengths), min(lengths),
+               max(lengths), min(n_states), max(n_states), float(np.mean(n_states)),
+               ' '.join(str(c) for c in sorted(set_per_task(n_states, cfg))), cfg['max_k'] - 1, cfg['d']))
+
+
+def set_per_task(n_states_per_video, cfg):
+    """states per task from states per video (videos of a task are consecutive and equally many)."""
+    per = len(n_states_per_video) // cfg['n_tasks']
+    return [n_states_per_video[i * per] for i in range(cfg['n_tasks'])]
+
+
 def dry_run(a, rank, world, D):
     """Host-only rehearsal of the N-rank path (tests/test_bench_spawn.py): shard the corpus STRUCTURE, reduce the frame
     counters over gloo, print the line with value null."""
@@ -734,8 +754,21 @@ def dry_run(a, rank, world, D):
     frames = sum(int(dry[key]['features'].shape[0]) for i in mine for key in batches[i])
     red = D.all_reduce_counters({'frames': [frames, len(mine)], 'ranks': [1, rank]})
     if rank == 0:
+        # the headline leg's workload string, from rank 0's corpus structure alone (no features, no GPU)
+        wcfg = synth.CONFIGS[a.workload]
+        wdry = synth.SynthDatasplit(a.workload, seed=a.seed, keep=set(), scale=a.scale)
+        w_len, w_c = [], []
+        for task, names in wdry._videos_by_task.items():
+            for nm in names:
+                w_len.append(int(wdry[(task, nm)]['features'].shape[0]))
+                w_c.append(len(wdry.corpus._indices_by_task[task]))
+        weak_text = weak_workload_text(a, wcfg, w_len, w_c)
+        strong_text = "%s seed %d: %d videos, %d frames, sharded by video (whole single-task batches of %d, greedy LPT on the DP work)" % (
+            wl, a.seed, len(dry), dry.n_frames, cfg['batch_size'])
         print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
                           "scaling": a.scaling,
+                          "config": {"workload": weak_text if a.scaling == 'weak' else strong_text},
+                          "strong_scaling": {"workload": strong_text, "scaling": "strong", "n_gpus": world},
                           "frames": int(red['frames'][0]), "batches": int(red['frames'][1]), "ranks_seen": int(red['ranks'][0]),
                           "corpus_frames": dry.n_frames, "n_batches": len(batches), "backend": "gloo" if world > 1 else None}),
               flush=True)
@@ -803,7 +836,7 @@ def main():
     dt = float(tmax[0])
 
     strong = None
-    if (world > 1 or a.strong_leg) and not a.no_strong_leg:
+    if not a.no_strong_leg:
         del labels_dev, gt_dev
         strong = strong_leg(a, rank, world, dev, D)
 
@@ -818,13 +851,11 @@ def main():
         par = {None: "1 rank, no collective", "nccl": "RCCL", "gloo": "gloo (rehearsal: NOT a measurement of the RCCL path)"}[backend]
         weak = {"value": total_frames * a.steps / dt, "ms_per_step": dt / a.steps * 1e3}
         head = weak if (a.scaling == 'weak' or strong is None) else strong
-        wl_text = ("%s seed %d: %d tasks x %d videos per GPU, %d frames per GPU (T %d..%d), %d..%d states per "
-                   "task (mean %.1f; per task: %s), max span length %d, D=%d; closed-form-fitted HSMM parameters"
-                   % (a.workload, a.seed, cfg['n_tasks'], len(pc.lengths) // cfg['n_tasks'], frames, min(pc.lengths),
-                      max(pc.lengths), min(pc.n_states), max(pc.n_states), c_avg,
-                      ' '.join(str(c) for c in sorted(pc.n_states)), cfg['max_k'] - 1, cfg['d']))
+        by_name = {nm: (ln, pc.n_states[g]) for nm, ln, g in zip(pc.video_names, pc.lengths, pc.group)}
+        in_order = [by_name[nm] for names in data._videos_by_task.values() for nm in names]
+        wl_text = weak_workload_text(a, cfg, [t for t, _ in in_order], [c for _, c in in_order])
         if head is not weak:
-            wl_text = head["workload"] + " (BASELINE config 5; the weak leg beside it: " + wl_text + ")"
+            wl_text = head["workload"]
         res = {
             "metric": METRIC,
             "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": a.steps,

@@ -111,6 +111,16 @@ def test_cfg3_longest_videos(c):
     check_equivalent(cp, *res)
 
 
+@pytest.mark.parametrize('c', [23, 12])
+def test_cfg3_longest_videos_at_d300(c):
+    """The reference's i3d + resnet + audio feature setting after PCA gives D = 300 (src/main.py:283-286): the emission
+    kernel's LDS weight table is 8 * 304 * 37 bytes = 90 KB above 16 states there (one workgroup per CU instead of two).
+    Feature-driven, full size: T = 14 000, K = 1024 next to short videos, against the C twin."""
+    cp = make_corpus(300 + c, [14000, 700, 9000, 14000], c, 1024, d=300)
+    res = decode_both(cp)
+    check_equivalent(cp, *res)
+
+
 def test_cfg3_with_and_without_the_speculative_transition_agree(monkeypatch):
     """The same ragged launch with the chain wave's speculative transition switched off decodes to the same bits."""
     from action_segmentation_amd import ops

@@ -5,7 +5,8 @@ import torch
 
 from oracle import dense_ref as O
 from oracle import factored as F
-from golden_util import CASES, case_inputs, assert_spans_equivalent
+from golden_util import (CASES, case_inputs, assert_spans_equivalent, span_start_differences, crosstask_magnitude_case,
+                         fp32_near_tie_certificate)
 from module_util import module_from_golden, make_args
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +35,60 @@ def test_viterbi_matches_reference_path_on_golden_cases(golden, case):
                                rtol=1e-9, atol=1e-7)
     # and identical to what the reference's own host code produced with the restated DP (fixture)
     assert_spans_equivalent(spans.numpy(), golden[case + '/f64/ref_spans'], lengths, p.n_classes)
+
+
+@pytest.mark.parametrize('case', EOS_CASES)
+def test_viterbi_against_the_reference_fp32_run(golden, case):
+    """SURVEY 8c(1), fp32 clause, on the fixtures: the reference's OWN host code run in fp32 (``*/f32/ref_spans``; the
+    reference computes in fp32) against ``viterbi()``: identical frame labels and EOS placement, and every span start
+    that differs sits inside a run of one class -- which is also the only way the reference's fp32 run differs from its
+    own fp64 run (tests/test_oracle_golden.py pins that: 2 positions each on ``k_gt_t`` and ``constrained``)."""
+    dev = torch.device('cuda:0')
+    m = module_from_golden(golden, case).to(dev)
+    p, feats, lengths, valid, cons, cfg = case_inputs(golden, case, torch.float64)
+    vc = None if valid is None else [valid for _ in range(feats.shape[0])]
+    spans = m.viterbi(feats.float().to(dev), lengths.to(dev), vc, add_eos=True,
+                      additional_allowed_ends_per_instance=cfg.get('additional'),
+                      constraints=None if cons is None else cons.float().to(dev))
+    ref32 = golden[case + '/f32/ref_spans']
+    assert_spans_equivalent(spans.numpy(), ref32, lengths, p.n_classes)
+    diffs = span_start_differences(spans.numpy(), ref32, lengths)       # asserts "inside one-class runs" position by position
+    assert len(diffs) <= 2, diffs
+    # ... and against the fp64 run of the same host code there is nothing to certify on these cases
+    assert len(span_start_differences(spans.numpy(), golden[case + '/f64/ref_spans'], lengths)) == 0
+
+
+def test_fp32_near_tie_certificate_at_crosstask_magnitudes():
+    """T = 800, 8 states, K = 24, D = 200, per-frame emissions ~ -280, best score ~ -2.2e5 (one
+    fp32 ulp = 2^-6), twelve seeds.  ``viterbi()`` equals the reference path run in fp64 frame for frame; against the
+    reference path run in fp32 (the precision the reference really computes in) it differs on one of the twelve videos,
+    by 4 frames, and there carries the certificate: re-scored under the dense fp64 potentials it is within 4 fp32 ulps
+    of the fp32 run's optimum AND scores higher than the fp32 run's own path -- the difference is the fp32 run's
+    rounding."""
+    from action_segmentation_amd.semimarkov_modules import SemiMarkovModule
+    dev = torch.device('cuda:0')
+    differing = []
+    for seed in range(12):
+        p32, feats, lengths = crosstask_magnitude_case(seed)
+        c, d = p32.n_classes, feats.shape[2]
+        m = SemiMarkovModule(make_args(p32.max_k), c, d, allow_self_transitions=True)
+        with torch.no_grad():
+            m.poisson_log_rates.copy_(p32.poisson_log_rates)
+            m.gaussian_means.copy_(p32.gaussian_means)
+            m.gaussian_cov.copy_(torch.diag(p32.gaussian_cov_diag))
+            m.transition_logits.copy_(p32.transition_logits)
+            m.init_logits.copy_(p32.init_logits)
+        m = m.to(dev)
+        spans = m.viterbi(feats.to(dev), lengths.to(dev), None, add_eos=True)
+        local = O.map_spans_to_local(spans, None, c)
+        cert = fp32_near_tie_certificate(p32, feats, lengths, local.numpy())
+        assert cert['labels_equal_fp64_run'], (seed, cert)
+        assert abs(cert['ulps_from_fp32_optimum']) <= 4.0, (seed, cert)
+        assert cert['gain_over_fp32_path'] >= 0.0, (seed, cert)
+        if cert['frames_differing']:
+            differing.append((seed, cert['frames_differing']))
+            assert cert['gain_over_fp32_path'] > 0.0, (seed, cert)
+    assert differing == [(6, 4)], differing
 
 
 @pytest.mark.parametrize('case', EOS_CASES)

@@ -133,16 +133,19 @@ def test_bench_two_ranks_one_corpus_same_stats_as_one_rank():
     one = _bench(['--gpus', '1', '--strong-leg'] + common)
     two = _bench(['--gpus', '2', '--backend', 'gloo', '--share-gpus'] + common)
     assert one['n_gpus'] == 1 and two['n_gpus'] == 2
-    assert two['backend'] == 'gloo' and two['scaling'] == 'strong'      # BASELINE config 5 is the N > 1 headline
+    # ONE headline leg for every N (round 5): weak, the same workload string at N = 1 and N = 2
+    assert two['backend'] == 'gloo' and two['scaling'] == 'weak' == one['scaling']
+    assert two['config']['workload'] == one['config']['workload']
     s1, s2 = one['strong_scaling'], two['strong_scaling']
     assert s2['n_gpus'] == 2 and s1['frames'] == s2['frames'] and s1['videos'] == s2['videos']
     assert s2['max_frames_on_a_rank'] < s2['frames']
     assert s1['stats'] == s2['stats']
-    assert two['weak_scaling']['value'] > 0 and two['value'] == two['strong_scaling']['value']
-    assert two['config']['workload'].startswith(s2['workload'])
-    weak_head = _bench(['--gpus', '2', '--backend', 'gloo', '--share-gpus', '--scaling', 'weak'] + common)
-    assert weak_head['scaling'] == 'weak' and weak_head['value'] == weak_head['weak_scaling']['value']
-    assert weak_head['strong_scaling']['stats'] == s1['stats']
+    assert two['strong_scaling']['value'] > 0 and two['value'] == two['weak_scaling']['value']
+    assert s1['workload'] == s2['workload']
+    strong_head = _bench(['--gpus', '2', '--backend', 'gloo', '--share-gpus', '--scaling', 'strong'] + common)
+    assert strong_head['scaling'] == 'strong' and strong_head['value'] == strong_head['strong_scaling']['value']
+    assert strong_head['config']['workload'] == s2['workload']
+    assert strong_head['strong_scaling']['stats'] == s1['stats']
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
@@ -174,7 +177,7 @@ def test_bench_under_torchrun_launcher():
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['strong_scaling']['n_gpus'] == 2 and line['scaling'] == 'strong'
+    assert line['n_gpus'] == 2 and line['strong_scaling']['n_gpus'] == 2 and line['scaling'] == 'weak'
     one = _bench(['--gpus', '1', '--strong-leg', '--workload', 'tiny', '--strong-workload', 'tiny', '--steps', '2', '--warmup', '1',
                   '--no-cpu-baseline', '--no-predict-e2e', '--seed', '5'])
     assert one['strong_scaling']['stats'] == line['strong_scaling']['stats']

@@ -526,10 +526,14 @@ def test_unsupported_shapes_fail_loudly():
         ops.logz(ops.Batch([3000], [3], 2000), z(3000, 3), z(1, 3, 3), z(1, 3), z(1, 2000, 3))
 
 
-def test_nan_input_sets_error_word_and_terminates():
+@pytest.mark.parametrize('shape', [(2, 50, 4, 6), (2, 300, 7, 100), (2, 700, 18, 400), (2, 1300, 9, 1024), (1, 1500, 23, 1024)])
+def test_nan_input_sets_error_word_and_terminates(shape):
+    """Every back-trace -- the window walk (kp <= 64), the general one on the ring kernels (kp <= 512) and in BAND mode
+    (kp > 512) -- sees a NaN by its bits (the unit is compiled with -fno-honor-nans), flags it and stops."""
     ops = _ops()
-    p = make_problem(3, 2, 50, 4, 6)
-    p['elp'][1, 7, 2] = np.nan
+    b_, tmax_, c_, k_ = shape
+    p = make_problem(3, b_, tmax_, c_, k_)
+    p['elp'][b_ - 1, 7, 2] = np.nan
     dev = torch.device('cuda:0')
     b, tmax, cm = p['elp'].shape
     batch = ops.Batch(p['lengths'], [p['c']], p['k'], c_max=cm, t_max=tmax, total_frames=b * tmax)

@@ -153,6 +153,8 @@ def test_no_viterbi_kernel_has_a_private_segment():
     if not (shutil.which("llvm-readelf") or os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf")):
         pytest.skip("llvm-readelf not available")
     res = _build.kernel_resources()
+    if not res:
+        pytest.skip("libsmmdp.so is not built, or its offload bundle cannot be read (compressed)")
     vit = {k: v for k, v in res.items() if 'smm_viterbi_kernel' in k}
     assert len(vit) >= 40, sorted(res)[:5]
     bad = {k: v for k, v in vit.items() if v.get('private_segment_fixed_size', 0) != 0 or v.get('vgpr_spill_count', 0) != 0}

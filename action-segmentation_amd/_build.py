@@ -69,6 +69,12 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # objects of development variants (scripts/build_variants.sh: <unit>_<tag>.o) are debris once the library is rebuilt --
+    # and everything under the package travels to the GPU box with every lease
+    keep = {os.path.basename(_obj(s)) for s in SOURCES}
+    for f in os.listdir(OBJ):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(OBJ, f))
     return LIB
 
 

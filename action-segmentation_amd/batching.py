@@ -88,9 +88,13 @@ class BatchSampler(Sampler):
 def batch_cost(datasplit, keys, max_k):
     """~ time of the DP over one single-task batch, for balancing shards (any unit; one corpus = one max_k).
     Spans of up to 512: the lattice cells, sum over the videos of T * ((K-1) * C + C^2).  Longer spans run in the Viterbi
-    kernel's BAND mode, whose time per frame is its serial chain's and hardly depends on K or C (207 ns at 11 states, 246 at
-    23: DESIGN.md 3d) -- weighting a 23-state task twice as heavy as an 11-state one would hand its rank half the frames."""
+    kernel's BAND mode, whose time per frame is its serial chain's and hardly depends on K or C (the library's
+    ``smm_band_frame_ns``: 167 ns at 11 states, 191 at 23 with round 4's kernels) -- weighting a 23-state task twice as heavy as an 11-state one would hand its rank half the frames."""
     cost = 0.0
+    band_ns = None
+    if max_k > 512:
+        from . import _lib
+        band_ns = _lib.load().smm_band_frame_ns        # the shipped kernel's own model (include/smmdp.h): one constant, one place
     for key in keys:
         smp = datasplit[key]
         if smp is None:
@@ -98,7 +102,7 @@ def batch_cost(datasplit, keys, max_k):
         t = int(smp['features'].shape[0])
         c = len(smp['task_indices']) if smp.get('task_indices') is not None else datasplit.corpus.n_classes
         if max_k > 512:
-            cost += t * (170.0 + 3.3 * c)
+            cost += t * band_ns(c)
         else:
             cost += t * ((min(max_k, t + 1) - 1) * c + c * c)
     return cost

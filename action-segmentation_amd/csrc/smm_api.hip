@@ -27,7 +27,7 @@ namespace {
 struct SmmEnv {
     int spec = 1;             // SMM_SPEC=0: Viterbi without the speculative transition (A/B aid; same results)
     int no_split = 0;         // SMM_NO_SPLIT=1: smm_decode_f32 never splits a launch over two streams (same results)
-    double split_min_us = 100.0, split_ns = 330.0;   // SMM_SPLIT_MIN_US, SMM_SPLIT_NS, SMM_SPLIT_MARGIN: choose_split's model
+    double split_min_us = 100.0, split_ns = 0.0;     // SMM_SPLIT_MIN_US, SMM_SPLIT_NS (0: from smm_band_frame_ns), SMM_SPLIT_MARGIN: choose_split's model
     int split_margin = 400;
     int plan_cache = 1;       // SMM_PLAN_CACHE=0: no resident plans
     int no_bt_window = 0;     // SMM_NO_BT_WINDOW=1: the general back-trace also for kp <= 64 (same results)
@@ -274,6 +274,16 @@ static int device_cus()
     return n_cu[dev] > 0 ? n_cu[dev] : 0;
 }
 
+// ns per frame of one BAND-mode video on its CU (include/smmdp.h).  Measured, round 4's final kernels, CrossTask-like
+// lattices of 64 x 4096 frames (profiles/round4_band_stamps.txt): 167 / 172 / 186 / 191 ns at 11 / 16 / 20 / 23 states.
+// Re-fit these two numbers when the kernel changes; everything that needs the kernel's speed reads them from here.
+constexpr double SMM_BAND_NS_BASE = 145.0, SMM_BAND_NS_PER_STATE = 2.0;
+extern "C" double smm_band_frame_ns(int n_states)
+{
+    if (n_states < 1 || n_states > SMM_MAX_STATES) return 0.0;
+    return SMM_BAND_NS_BASE + SMM_BAND_NS_PER_STATE * n_states;
+}
+
 static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_max, int64_t total_frames)
 {
     const SmmEnv &ev = env();
@@ -289,7 +299,11 @@ static int choose_split(const SmmVideo *hv, int32_t *order, int b, int d, int c_
     // BAND kernel of round 3, ~250 ns per frame beside a full GPU): 230 / 250 ns 3.72-3.74 ms per step, 300 3.58-3.62,
     // 400 3.59-3.62, 600 3.65-3.71, 1000+ 3.68-3.70 -- the em_us estimate below (4 TB/s) is already on the long side.
     // SMM_SPLIT_NS / SMM_SPLIT_MARGIN: tuning aids
-    const int thr = tmax - (int)(em_us * 1000.0 / ev.split_ns) - ev.split_margin;
+    // (round 5: the slack per microsecond of emission follows the kernel's own speed -- split_slack x the modelled ns per
+    // frame of the launch's largest class set, 1.75 x 191 = 334 at 23 states, the value the scans above settled on when it
+    // was a literal -- instead of being re-fitted by hand each time the DP kernel gets faster; SMM_SPLIT_NS overrides)
+    const double split_ns = ev.split_ns > 0.0 ? ev.split_ns : 1.75 * smm_band_frame_ns(std::min(c_max, (int)SMM_MAX_STATES));
+    const int thr = tmax - (int)(em_us * 1000.0 / split_ns) - ev.split_margin;
     int n1 = 0;
     for (int i = 0; i < b; ++i) n1 += hv[i].T >= thr;
     // ... and only a launch that is bound by its longest videos: with more than two rounds of workgroups the DP is bound by

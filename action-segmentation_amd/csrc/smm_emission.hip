@@ -518,6 +518,7 @@ smm_emission_pair_kernel(const SmmVideo *__restrict__ videos, const int32_t *__r
     }
 }
 
+#ifdef SMM_DEV   // (development builds only: the variant lost its A/B; the product library does not carry it)
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel v2 (D % 4 == 0): x goes through LDS in whole 128-byte lines.
 //
@@ -702,6 +703,7 @@ smm_emission_lds_kernel(const SmmVideo *__restrict__ videos, const int32_t *__re
         }
     }
 }
+#endif   // SMM_DEV
 
 // fp32 -> fp64 widening of a [n] array (smm_viterbi_f32 boundary)
 __global__ void smm_widen_kernel(const float *src, double *dst, size_t n)
@@ -762,6 +764,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a.videos, order_v, a.n_states, a.x, a.w, a.cst, a.inv_var, a.cons,
                            a.elp64, a.elp32, a.d, a.c_max, rs, (int64_t)total_frames * a.d, blk_cum, nvid, blk_base);
     };
+#ifdef SMM_DEV
     if (v2) {
 #define SMM_EM_V2(NLD_)                                                                         \
         switch ((ct <= 16 ? 0 : 2) + (a.cons ? 1 : 0)) {                                        \
@@ -779,6 +782,9 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
 #undef SMM_EM_V2
         return;
     }
+#else
+    (void)v2; (void)nsel; (void)go2;
+#endif
     const int ng = ct <= 16 ? 0 : (ct - 13) >> 2;                            // 4-state groups behind the first 16 states
     // tiles in PAIRS (each read of the weights from LDS feeds two tiles' MFMAs: cfg3 0.645 -> 0.584 ms, bit-identical) where the
     // second tile's registers leave 4 waves per SIMD (<= 128 VGPRs: 16-byte loads, <= 28 states, constraints only up to 16

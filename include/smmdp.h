@@ -122,6 +122,17 @@ int smm_dp_timing_read(float *ms, int cap);
 int smm_dp_timing_read_tagged(float *ms, int32_t *tags, int cap);
 
 /*
+ * Cost model of the shipped Viterbi kernel (not part of the reference's interface): nanoseconds per frame of ONE video
+ * of `n_states` states decoded with segment lengths beyond 512 (BAND mode: the time of its serial chain, which hardly
+ * depends on the span limit), as measured on an MI355X with this library's kernels (the constants sit next
+ * to the kernel's dispatch and move with it).  ONE place for the number that two host-side decisions need: the split of
+ * smm_decode_f32 (how much shorter than the launch's longest video a video must be to start behind the emission pass
+ * of the whole corpus) and the balancing of video shards over ranks (batching.batch_cost).  Returns 0 for n_states
+ * outside 1..32.
+ */
+double smm_band_frame_ns(int n_states);
+
+/*
  * Library state (see "State" above).  smm_release_cached_plans frees every resident plan (all devices), the split
  * decode's second streams and all pooled events, and returns the device bytes it gave back.  The caller's promise: no
  * libsmmdp call is in flight on any stream, and no hipGraph captured from a call will be replayed afterwards (a captured

@@ -414,3 +414,92 @@ int smm_band_probe3(const double *elp, int t, int c, const double *trans, const 
     free(cum); free(h); free(gam); free(hmax);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ round 5: rank convergence
+ * Go / no-go probe for parallelism INSIDE one video.  A (max,+) recurrence forgets its start: run the
+ * forward recursion from position a with a GUESSED ring -- beta[s][c] = 0 for every ring position s <= a and state c --
+ * and the values it produces differ from the true ones by one constant (over states and positions) from some n0 on; a
+ * chunk of the time axis could then be decoded from a guess after n0 - a positions of warm-up.
+ * true_beta: beta[n][c] of the real forward pass, n = 0 .. T-1 (row 0 unused), computed here first.
+ * For each of the n_starts positions a: first n0 >= a + 1 such that for every n in [n0, T-1] and every state c
+ *   | (beta_g[n][c] - beta[n][c]) - delta | <= tol,   delta = the difference at (T-1, state 0).
+ * out[i] = n0 - a  (T - a if it never converges before the end).  Same expressions as smm_oracle.c's forward pass. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static void conv_forward(const double *elp, int t, int c, const double *trans, const double *len, int kp, const double *cum,
+                         double *h, double *beta, int n_from)
+{
+    /* h[s][c] valid for s < n_from (at least the last kp-1 of them); fills h, beta for n = n_from .. t-1 */
+    double *gam = (double *)malloc(sizeof(double) * c);
+    (void)elp;
+    for (int n = n_from; n < t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) {
+                const double v = h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j];
+                a = v > a ? v : a;
+            }
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) {
+                const double v = gam[j] + trans[(size_t)to * c + j];
+                bt = v > bt ? v : bt;
+            }
+            beta[(size_t)n * c + to] = bt;
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    free(gam);
+}
+
+/* mode 0: the flat ring (beta = 0 at every ring position up to a); mode 1: a BOUNDARY forced at a with a uniform start --
+ * h[a][c] = 0 for every state, nothing older in the ring (what a chunk of a time-split decode starts from: "the video
+ * begins at a") */
+int smm_conv_probe_mode(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                        const int32_t *starts, int n_starts, double tol, int mode, int32_t *out);
+int smm_conv_probe(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                   const int32_t *starts, int n_starts, double tol, int32_t *out)
+{
+    return smm_conv_probe_mode(elp, t, c, trans, init, len, kp, starts, n_starts, tol, 0, out);
+}
+int smm_conv_probe_mode(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                        const int32_t *starts, int n_starts, double tol, int mode, int32_t *out)
+{
+    double *cum = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *h = (double *)malloc(sizeof(double) * (size_t)t * c);
+    double *beta = (double *)calloc((size_t)t * c, sizeof(double));
+    if (!cum || !h || !beta) return -1;
+    for (int j = 0; j < c; ++j) { cum[j] = 0.0; h[j] = init[j]; }
+    for (int n = 1; n <= t; ++n)
+        for (int j = 0; j < c; ++j) cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+    conv_forward(elp, t, c, trans, len, kp, cum, h, beta, 1);
+    #pragma omp parallel for schedule(dynamic)
+    for (int i = 0; i < n_starts; ++i) {
+        const int a = starts[i];
+        double *hg = (double *)malloc(sizeof(double) * (size_t)t * c);
+        double *bg = (double *)calloc((size_t)t * c, sizeof(double));
+        /* the guessed ring: beta = 0 at every position up to a (positions before a - kp + 1 are never read) */
+        for (int s = (a - kp + 1 > 0 ? a - kp + 1 : 0); s <= a; ++s)
+            for (int j = 0; j < c; ++j) hg[(size_t)s * c + j] = mode == 0 ? 0.0 - cum[(size_t)s * c + j] : (s == a ? 0.0 : -INFINITY);
+        conv_forward(elp, t, c, trans, len, kp, cum, hg, bg, a + 1);
+        const double delta = bg[(size_t)(t - 1) * c] - beta[(size_t)(t - 1) * c];
+        int n0 = t;
+        for (int n = t - 1; n > a; --n) {
+            int ok = 1;
+            for (int j = 0; j < c; ++j) {
+                const double d = (bg[(size_t)n * c + j] - beta[(size_t)n * c + j]) - delta;
+                if (!(d <= tol && d >= -tol)) { ok = 0; break; }
+            }
+            if (!ok) break;
+            n0 = n;
+        }
+        out[i] = n0 - a;
+        free(hg); free(bg);
+    }
+    free(cum); free(h); free(beta);
+    return 0;
+}

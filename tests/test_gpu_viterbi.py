@@ -541,7 +541,7 @@ def test_nan_input_sets_error_word_and_terminates(shape):
     ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
     torch.cuda.synchronize()
     assert ops.error_flag(batch) != 0
-    p['elp'][1, 7, 2] = 0.0
+    p['elp'][b_ - 1, 7, 2] = 0.0
     ops.viterbi(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]))
     torch.cuda.synchronize()
     assert ops.error_flag(batch) == 0

@@ -214,7 +214,7 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.hist_doubles = h;
     p.elp_doubles = (size_t)s->total_frames * s->c_max;
     p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
-    p.band_doubles = (size_t)s->n_groups * s->c_max * ((size_t)SMM_BAND_ROW + SMM_BAND_TAB);
+    p.band_doubles = (size_t)s->n_groups * s->c_max * ((size_t)SMM_BAND_ROW + SMM_BAND_TAB + 64);   // len_t | band_tab | dmin_t
     p.total = p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles + p.band_doubles) + 1024;
     return p;
 }
@@ -740,9 +740,11 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     if (!env().spec) a.flags |= 256;                          // A/B aid: no speculative transition
     if (st.band_mode) {
         double *len_t = st.band, *band_tab = st.band + (size_t)s->n_groups * s->c_max * SMM_BAND_ROW;
-        if (prep) smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, s->n_groups, s->c_max, s->k_rows, stream);
+        double *dmin_t = band_tab + (size_t)s->n_groups * s->c_max * SMM_BAND_TAB;
+        if (prep) smm_launch_band_tables(len_scores, st.n_states, len_t, band_tab, dmin_t, s->n_groups, s->c_max, s->k_rows, stream);
         a.len_t = len_t;
         a.band_tab = band_tab;
+        a.dmin_t = dmin_t;
         a.flags |= 128;
     }
     if (ring_regs(st.kp_max) == 1 && !env().no_bt_window) {

@@ -53,6 +53,7 @@ struct SmmDpArgs {
     double *logz_b;            // ... and where the reversed runs put their closing value [b]
     const double *len_t;       // Viterbi BAND mode (flags bit 7, 128): [g][c_max][k_rows] state-major length table ...
     const double *band_tab;    // ... and [g][c_max][16] bounds of the band skip test (smm_viterbi.hip: smm_band_tables_kernel)
+    const double *dmin_t;      // ... and [g][c_max][64] thresholds of the anchor test, minima over buckets of 16 distances (round 5: ANCHOR in the BAND pushers, -DSMM_ANCHOR=1 builds only)
     int32_t bt_window;         // Viterbi, kp <= 64: positions per LDS window of the back-trace (0: the general back-trace) ...
     int32_t bt_dyn_bytes;      // ... and the dynamic LDS it needs: (3 W + c + kp) c doubles for the launch's largest c, kp
 };

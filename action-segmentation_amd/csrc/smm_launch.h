@@ -49,8 +49,8 @@ void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stre
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
 // Viterbi BAND mode: the state-major length table and the skip-test bounds of every (group, state) (smm_viterbi.hip)
-void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, int n_groups, int cm,
-                            int k_rows, hipStream_t stream);
+void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, double *dmin_t,
+                            int n_groups, int cm, int k_rows, hipStream_t stream);
 // tuning switches other translation units read (smm_api.hip: SmmEnv; read once, see smm_env_reload)
 int smm_env_fit_grid();        // SMM_FIT_GRID (0: default)
 int smm_env_emission_v2();     // SMM_EMISSION_V2 (-DSMM_DEV builds only)

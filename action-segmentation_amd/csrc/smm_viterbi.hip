@@ -117,9 +117,21 @@ __device__ __forceinline__ void smm_lds_barrier()
 #ifndef SMM_PIPE0_ALWAYS
 #define SMM_PIPE0_ALWAYS 0
 #endif
+#ifndef SMM_SPEC8
+#define SMM_SPEC8 0      // the chain wave's BLOCK-level speculation (see SPEC8 in the kernel).  Built, bit-exact (every GPU test passes
+#endif                   // with it) and NOT shipped: same-box A/B on three boxes, cfg3 DP kernel +2.2 / +2.3 / +3.8 % with it (round 5,
+                         // profiles/round5_chain_spec8_anchor.txt) -- the chain wave's busy time falls (2716 -> 2380 cycles per block)
+                         // and the block does not get shorter: its dense instruction stream takes issue slots from the mover wave on
+                         // the same SIMD (1650 -> 2130 busy), which becomes the wave the barrier waits for
 #ifndef SMM_DOM_SPARSE
 #define SMM_DOM_SPARSE 3   // BAND pushers (DOM): fewer unbeaten sources than this (besides the last) are pushed one by one from the LDS table
 #endif
+#ifndef SMM_ANCHOR
+#define SMM_ANCHOR 0       // BAND pushers: anchor dominance in band 0 (see ANCHOR in the pusher waves).  Built, bit-exact, and NOT
+#endif                     // shipped: it leaves out what it was meant to (sources pushed per (state, block) on cfg3 1.75 -> 1.31, the
+                           // leading state's 7.9 -> 1.8) and the kernel is 4 % SLOWER with it (same box, cfg3 DP 2.52 -> 2.62 ms;
+                           // 64 x 4096 lattices, 23 states: 229 -> 253 ns per frame): the pusher waves' ~2000 busy cycles per block
+                           // are not those pushes (profiles/round5_chain_spec8_anchor.txt)
 #ifndef SMM_BAND_ALLWIT
 #define SMM_BAND_ALLWIT 1  // 0 (A/B aid): the band skip test with the one witness of round 3 (group G - 2) only
 #endif
@@ -412,6 +424,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     // and per state how far h must RISE from one source to the next for the older one to be beaten at every target
     __shared__ __attribute__((aligned(16))) double sh_l0[BAND ? SN : 1][BAND ? SMM_L0_ROW : 1];
     __shared__ double sh_xd[BAND ? SN : 1];
+    __shared__ double sh_dlow[(BAND && SMM_ANCHOR) ? SN : 1][(BAND && SMM_ANCHOR) ? 64 : 1];   // ANCHOR (pusher waves): min of D_c over buckets of 16 distances
     __shared__ __attribute__((aligned(16))) double sh_gam[SMM_MAX_STATES_DEV];           // gamma[n][.] chain-private broadcast
     __shared__ double sh_gfin[SMM_MAX_STATES_DEV];                                        // gamma[T][.] for the closing step
     __shared__ __attribute__((aligned(16))) double sh_junk[2][B][SMM_MAX_STATES_DEV][2]; // where the chain wave's other lane groups store
@@ -459,6 +472,11 @@ smm_viterbi_kernel(SmmDpArgs a)
         for (int e = threadIdx.x; e < SN * SMM_L0_ROW; e += blockDim.x) {
             const int c = e / SMM_L0_ROW, kr = e % SMM_L0_ROW;
             sh_l0[c][kr] = (c < C && kr >= KMIN0 && kr <= khi) ? len[(size_t)kr * cm + c] : SMM_NEG_INF;
+        }
+        if constexpr (SMM_ANCHOR != 0) {
+            const double *dl = a.dmin_t + (size_t)g * cm * 64;           // (smm_band_tables_kernel fills it in -DSMM_ANCHOR=1 builds only)
+            for (int e = threadIdx.x; e < SN * 64; e += blockDim.x)
+                sh_dlow[e / 64][e % 64] = (e / 64 < C) ? dl[(size_t)(e / 64) * 64 + e % 64] : SMM_NEG_INF;
         }
         // DOM (see the pusher waves): X_c = max over band 0's lengths of len[k][c] - len[k-1][c], clipped at 0 and pushed
         // a part in 2^49 up.  h[s+1][c] - h[s][c] > X_c (both differences rounded once: relative error 2^-53 each) then
@@ -638,6 +656,10 @@ smm_viterbi_kernel(SmmDpArgs a)
 #endif
             bool spec = false;                                // the leader cs is believed to hold
             int cs = 0, spec_wait = 0, spec_back = 1;         // leader; blocks until the next try; back-off
+            int sb_wait = 0, sb_back = 1;                     // SPEC8: blocks until the next block-level try; back-off
+#ifdef SMM_PROFILE
+            unsigned long long p_sb_ok = 0, p_sb_fail = 0;    // (diagnostic: blocks of workgroup 0 that the block-level speculation decided / had to replay)
+#endif
             double trS = SMM_NEG_INF, dlt = SMM_NEG_INF;      // trans[to][cs], dl[cs][to] (-inf: no leader holds, every position takes the full fold)
             const bool spec_off = !SPEC || (a.flags & 256);   // (SMM_SPEC=0: A/B aid)
             if (spec_off) spec_wait = 0x7fffffff;
@@ -656,11 +678,6 @@ smm_viterbi_kernel(SmmDpArgs a)
                     auto stage = [&](int i) {
                         if (i < B) { ap[i] = sh_apart[jj & 1][i][to]; ev[i] = sh_e[jj & 1][i][to]; }
                     };
-                    if constexpr (TIGHT) { stage(0); stage(1); stage(2); }
-                    else {
-    #pragma unroll
-                        for (int i = 0; i < B; ++i) stage(i);
-                    }
                     // Software pipeline inside the block: everything of position n+1 that does not depend on h[n] -- the
                     // candidates k = 2..K0, A'[n+1], cumE[n+1] -- is evaluated in the shadow of position n's LDS round trip
                     // (gamma broadcast), so that the serial path of a position is add, max, add, LDS, transition, sub.
@@ -684,6 +701,101 @@ smm_viterbi_kernel(SmmDpArgs a)
                         }
                         return acc;
                     };
+                    // SPEC8: the whole BLOCK speculated at once (round 5).  A fast position still hangs on its predecessor: h[n-1] feeds
+                    // the k = 1 candidate of gamma[n], gamma[n] of the leader lane feeds h[n], and between two positions sit a
+                    // v_readlane pair and the check's compare -> ballot -> branch -- ~330 cycles per position for ~40 instructions.
+                    // But while a leader cs holds, its own gamma hardly ever comes from a source inside the current block (a
+                    // segment that long does not restart every few frames), and gamma[cs] is all that the OTHER lanes' h depend on.
+                    // So: (1) everything that needs only sources of earlier blocks -- cumE of the 8 positions and, per position, the
+                    // maximum pp[i] over A'[i] and the candidates k > i -- is computed for all 8 positions, no dependence between
+                    // them; (2) GUESS gamma[i][cs] = cumE[i][cs] + pp[i][cs] (no source of this block wins for the leader) and read all
+                    // 8 from lane cs; (3) h[i][.] = (gs[i] + trans[.][cs]) - cumE[i][.] for all 8 at once; (4) with those, the
+                    // in-block candidates k <= i and the TRUE gamma[i][.] of every lane; (5) ONE check for the block: no lane, at no
+                    // position, has gamma[i][c] - gs[i] > dl[cs][c].  In lane cs the threshold is 0 and gamma >= the guess by
+                    // construction, so passing there means the guess WAS gamma[i][cs]; by induction over i every h used was the true
+                    // one, the per-position checks of the serial code would all have passed, and what was stored is what the serial
+                    // code stores, bit for bit (the same candidates in the same expressions; max is exact and order-free).  A block
+                    // that fails -- a boundary inside it, a competitor within reach -- has changed nothing but its own LDS rows and
+                    // is run again by the serial code below.  (Back-off as for the leader search: a lattice on which blocks keep
+                    // failing tries every 8th block.)
+                    bool block_done = false;
+                    if constexpr (SPEC && SMM_SPEC8) {
+                        if (spec && sb_wait == 0) {
+                            double cumv[B], pp[B];
+                            {
+                                // (the block's A' and elp rows are asked for first and needed last: the candidates of the earlier
+                                // blocks' sources come from registers and run while the LDS answers)
+                                double apv[B], evv[B];
+    #pragma unroll
+                                for (int i = 0; i < B; ++i) { apv[i] = sh_apart[jj & 1][i][to]; evv[i] = sh_e[jj & 1][i][to]; }
+    #pragma unroll
+                                for (int i = 0; i < B; ++i) {
+                                    double acc = SMM_NEG_INF;
+                                    const int kmax = TRI ? B + D + i : K0;
+    #pragma unroll
+                                    for (int k0 = K0; k0 >= 1; k0 -= 4) {
+                                        double sq[4];
+    #pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                            if (k0 - q > i && k0 - q <= kmax) sq[q] = hq[(jj * B + 1 + i - (k0 - q) + 4 * M) % M] + lk[k0 - q];
+    #pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                            if (k0 - q > i && k0 - q <= kmax) acc = smm_fmax(acc, sq[q]);
+                                    }
+                                    pp[i] = acc;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                double cr = cum;
+    #pragma unroll
+                                for (int i = 0; i < B; ++i) {
+                                    cr = cr + evv[i];
+                                    cumv[i] = cr;
+                                    pp[i] = smm_fmax(pp[i], apv[i]);
+                                }
+                            }
+                            double gsv[B], hg[B];
+    #pragma unroll
+                            for (int i = 0; i < B; ++i) gsv[i] = smm_readlane(cumv[i] + pp[i], cs);
+    #pragma unroll
+                            for (int i = 0; i < B; ++i) hg[i] = (gsv[i] + trS) - cumv[i];
+                            double viol = SMM_NEG_INF;
+    #pragma unroll
+                            for (int i = 0; i < B; ++i) {
+                                double acc = pp[i];
+                                const int kmax = TRI ? B + D + i : K0;
+    #pragma unroll
+                                for (int k = 1; k <= i; ++k)
+                                    if (k <= kmax) acc = smm_fmax(acc, hg[i - k] + lk[k]);
+                                const double gm = cumv[i] + acc;
+                                viol = smm_fmax(viol, gm - gsv[i]);
+                                *reinterpret_cast<double2 *>(st_gh + ((jj & 1) * B + i) * 2 * SMM_MAX_STATES_DEV) = make_double2(gm, hg[i]);
+                            }
+                            if (__ballot(viol > dlt) == 0) {
+    #pragma unroll
+                                for (int i = 0; i < B; ++i) hq[(jj * B + 1 + i) % M] = hg[i];
+                                cum = cumv[B - 1];
+                                block_done = true;
+                                sb_back = 1;
+#ifdef SMM_PROFILE
+                                p_fastn += B; ++p_sb_ok;
+#endif
+                            } else {
+                                sb_wait = sb_back;
+                                sb_back = sb_back < 8 ? 2 * sb_back : 8;
+#ifdef SMM_PROFILE
+                                ++p_sb_fail;
+#endif
+                            }
+                        } else if (sb_wait > 0) {
+                            --sb_wait;
+                        }
+                    }
+                    if (!block_done) {
+                    if constexpr (TIGHT) { stage(0); stage(1); stage(2); }
+                    else {
+    #pragma unroll
+                        for (int i = 0; i < B; ++i) stage(i);
+                    }
                     double pacc = partial(0);
                     double cumn = (SMM_ABLATE & 2) ? ev[0] : cum + ev[0];
                     const bool spec0 = spec;
@@ -826,6 +938,7 @@ smm_viterbi_kernel(SmmDpArgs a)
                             else { dlt = SMM_NEG_INF; spec_wait = spec_back; spec_back = spec_back < 32 ? 2 * spec_back : 32; }
                         }
                     }
+                    }   // (!block_done)
                     SMM_LDS_BARRIER();                           // end of block j (LDS-only: see smm_lds_barrier)
                 }
             }
@@ -834,6 +947,7 @@ smm_viterbi_kernel(SmmDpArgs a)
             if (half == 0) sh_gfin[to] = sh_gh[(J - 1) & 1][(T - 1) % B][to][0];
 #ifdef SMM_PROFILE
             p_ph[2] = p_fastn;                                // (slot 34 of the stamps: wave 0 has no blocks with j mod 4 = 2)
+            p_ph[1] = p_sb_ok; p_ph[3] = p_sb_fail;           // (slots 33 / 35: blocks the block-level speculation decided / replayed)
 #endif
             SMM_PROF_OUT();
         };
@@ -888,6 +1002,37 @@ smm_viterbi_kernel(SmmDpArgs a)
             hoff[r] = ((e % B) * SMM_MAX_STATES_DEV + ((ejs < SPS && ec < C) ? ec : 0)) * 2 + 1;   // (the h half of the (gamma, h) pairs)
             xdom[r] = sh_xd[BAND ? ((ejs < SPS && ec < C) ? ec : 0) : 0];
         }
+        // ANCHOR (round 5): dominance by an OLDER source.  DOM leaves a source out when its SUCCESSOR beats it at every target;
+        // the state that currently explains the frames never passes that test (inside its segment h moves by len[m+1] - len[m],
+        // a fraction of a nat), so its wave pushed all 8 sources of every block -- ~60 instructions and one or two dependent LDS
+        // round trips, and that wave is the one the block barrier waits for.  But those sources are hopeless against the source
+        // the segment STARTED from: candidate (s, k) and candidate (a, k + s - a) aim at the same target, and
+        //     h[s][c] - h[a][c]  <  D_c[s - a]  =  (1 -+ 2^-49) min_{band 0's k} (len[k + s - a][c] - len[k][c])
+        // (both sides rounded once; the deflated threshold makes it hold in real arithmetic for every length of the band, STRICTLY)
+        // says that the older source a beats s at every target band 0 reaches -- a candidate that is strictly below another
+        // candidate of its own target attains no maximum, whatever becomes of the other one (it may sit in a delayed band that
+        // is skipped, or be left out by DOM: each of those is below yet another candidate; strict edges go to older sources,
+        // the non-strict ones of DOM and of the band skip test to younger ones, every edge is an inequality of real numbers, so
+        // a cycle would need x < x, and a chain of edges ends at a candidate that IS evaluated).  Inside a segment h[s] = h[a] +
+        // len[s - a] + trans[c][c] for the segment's start a: a restart costs a self transition and a whole Poisson normaliser,
+        // hundreds of nats below D.  The test lives in the RARE path only (a state with sources that DOM could not leave out):
+        // per state of the wave one anchor (position, h) in wave-uniform registers, moved to the FIRST source that survives both
+        // tests whenever there is one -- a state that becomes the leader drags a stale anchor along, fails the test once at its
+        // segment's start, and has its anchor there from then on.  D_c is used through its minima over buckets of 16 distances
+        // (sh_dlow, 64 per state, from smm_band_tables_kernel: a lower bound of D_c[d] is as good, and fits the LDS).  CPU probe
+        // first (oracle/prune_probe.c: smm_anchor_probe): sources pushed per block by the leading state 7.9 -> 1.8 on cfg3.
+        constexpr bool ANCHOR = SMM_ANCHOR != 0;
+        static_assert(!BAND || !ANCHOR || (TRI ? B + D + 1 : 2 * B + D) >= 9, "dlow covers band 0's lengths from 9 on (smm_band_tables_kernel)");
+        double anc_h[SPS];
+        int anc_s[SPS];
+#pragma unroll
+        for (int js = 0; js < SPS; ++js) {
+            const int ec = js * NPS + rank;
+            anc_h[js] = (BAND && ec < C) ? init[ec] : SMM_NEG_INF;           // position 0: the start of every first segment
+            anc_s[js] = 0;
+        }
+        const int dlim = ANCHOR ? kp - 1 - 127 : 0;                          // largest distance s - a whose candidates (a, k + s - a) all exist
+        uint32_t nanch = 0;                                                  // (diagnostic: sources the anchor test left out)
         uint32_t npush = 0;                                                  // (diagnostic: sources this wave pushed into band 0)
         unsigned long long mcur = 0, mnext = 0;          // bit 8 js + m - 1: band m of the wave's js-th state is switched on for the
                                                          // current group / for the next one, once decided
@@ -1017,8 +1162,26 @@ smm_viterbi_kernel(SmmDpArgs a)
 #pragma unroll
                         for (int js = 0; js < SPS; ++js) {
                             if (js >= nvw) break;
-                            const uint32_t k7 = (keep[(B * js) / 16] >> ((B * js) % 16)) & 0x7fu;
+                            uint32_t k7 = (keep[(B * js) / 16] >> ((B * js) % 16)) & 0x7fu;
                             if (k7 == 0) continue;
+                            if (ANCHOR && dlim > 0) {
+                                // ANCHOR (above): the sources DOM could not leave out, against the state's anchor.  Lane (lane & 15) in
+                                // [8 (js & 1), 8 (js & 1) + 8) of every row holds source i = lane & 7 of this state (block j pushes the
+                                // sources (j-1)B + 1 .. jB); the other half-rows hold the neighbour state's and are masked off
+                                const int dd = (j - 1) * B + 1 + (lane & 7) - anc_s[js];
+                                const double dl = sh_dlow[BAND ? js * NPS + rank : 0][(dd >> 4) & 63];
+                                const bool ad = dd >= 1 && dd <= dlim && hvl[(B * js) / 16] - anc_h[js] < dl;
+                                const uint32_t a8 = (uint32_t)(__ballot(ad) >> ((B * js) % 16)) & 0x7fu;
+                                nanch += __builtin_popcount(k7 & a8);
+                                k7 &= ~a8;
+                                if (k7 == 0) continue;
+                                // the FIRST survivor is the state's next anchor: at the start of a segment the survivors are the start
+                                // itself and the sources behind it, which the start beats from the next block on (an anchor INSIDE
+                                // the segment would not: against it the self transition and the normaliser cancel)
+                                const int il = __builtin_ctz(k7);
+                                anc_s[js] = (j - 1) * B + 1 + il;
+                                anc_h[js] = smm_readlane(hvl[(B * js) / 16], (B * js) % 16 + il);
+                            }
                             const double *l0row = &sh_l0[BAND ? js * NPS + rank : 0][0];
                             if (__builtin_popcount(k7) < SMM_DOM_SPARSE) {
                                 // a few: ring pair from the table at the push's phase
@@ -1187,6 +1350,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         if (w == MW) (void)mover_step(J, J & 1, false);                       // the last block's history
         if (lane == 0 && nact) atomicAdd(a.err + 3, (int)nact);             // error block word 3: see ops.error_words
         if (lane == 0 && npush) atomicAdd(a.err + 2, (int)npush);           // ... and word 2: sources pushed into band 0
+        (void)nanch;
 #ifdef SMM_PROFILE
         if (lane == 0 && blockIdx.x == 0 && w != MW && w < 7) reinterpret_cast<unsigned long long *>(a.err)[w < MW ? w + 1 : w] = nact;   // slots 2..6: workgroup 0's waves 1, 2, 3, 5, 6
 #endif
@@ -1505,7 +1669,7 @@ smm_viterbi_kernel(SmmDpArgs a)
 // from it, 128 consecutive lengths per wave instruction) and the bounds of the skip test: [0] min len over 33..174,
 // [m] max len over band m = 16+112m .. 127+112m (clipped to the table; a video's own kp only makes the bound looser).
 __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len, const int32_t *n_states, double *len_t,
-                                                              double *band_tab, int cm, int k_rows)
+                                                              double *band_tab, double *dmin_t, int cm, int k_rows)
 {
     // the state's column of the length table, once from memory (strided by c_max: every load is a trip to L2), then
     // every bound from LDS: this kernel sits in front of the DP kernel on the critical path of every decode (round 3: nine
@@ -1539,6 +1703,31 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
         if (!live) v = SMM_NEG_INF;
         if (ln == 0) band_tab[((size_t)g * cm + c) * SMM_BAND_TAB + m] = v;
     }
+    // ANCHOR (round 5, see the pusher waves): D[d] = min over band 0's lengths k = 9 .. 127 of (len[k + d] - len[k]), pushed a
+    // part in 2^49 DOWN (the test h[s] - h[a] < D[s - a] must hold in real arithmetic, strictly), and of that the minimum
+    // over each bucket of 16 distances, dmin_t[q] = min_{16 q <= d < 16 q + 16, d >= 1} D[d]: a lower bound of D[d] serves as
+    // well and 64 numbers per state fit the LDS.  -inf where some k + d of the bucket leaves the table (no such candidate:
+    // never beaten); a length the table does not reach (len[k] = -inf) asks for nothing.
+    if constexpr (SMM_ANCHOR != 0) {
+        const int klo = 9, khi = (k_rows - 1 < 127) ? k_rows - 1 : 127;
+        double *drow = dmin_t + ((size_t)g * cm + c) * 64;
+        if (threadIdx.x < 64) {
+            const int q = threadIdx.x;
+            double mq = __builtin_huge_val();
+            for (int d = (q ? 16 * q : 1); d < 16 * q + 16; ++d) {
+                double m = __builtin_huge_val();
+                if (!live || khi + d > k_rows - 1) m = SMM_NEG_INF;
+                else
+                    for (int k = klo; k <= khi; ++k) {
+                        const double lb = col[k];
+                        if (lb == SMM_NEG_INF) continue;
+                        m = fmin(m, col[k + d] - lb);
+                    }
+                mq = fmin(mq, m);
+            }
+            drow[q] = mq > 0.0 ? mq * (1.0 - 0x1p-49) : mq * (1.0 + 0x1p-49);
+        }
+    }
     // the witnesses of the skip test (round 4): min len over the lengths 16 delta + 1 .. 16 delta + 142, a wave per window
     // (-inf when the window leaves the table: no witness there)
     for (int d = 2 + wv; d <= SMM_BAND_WIT; d += 4) {
@@ -1552,10 +1741,10 @@ __global__ void __launch_bounds__(256) smm_band_tables_kernel(const double *len,
     }
 }
 
-void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, int n_groups, int cm,
-                            int k_rows, hipStream_t stream)
+void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, double *dmin_t,
+                            int n_groups, int cm, int k_rows, hipStream_t stream)
 {
-    hipLaunchKernelGGL(smm_band_tables_kernel, dim3(n_groups * cm), dim3(256), 0, stream, len, n_states, len_t, band_tab, cm, k_rows);
+    hipLaunchKernelGGL(smm_band_tables_kernel, dim3(n_groups * cm), dim3(256), 0, stream, len, n_states, len_t, band_tab, dmin_t, cm, k_rows);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch

@@ -503,3 +503,83 @@ int smm_conv_probe_mode(const double *elp, int t, int c, const double *trans, co
     free(cum); free(h); free(beta);
     return 0;
 }
+
+/* Round 5: ANCHOR dominance in band 0, on top of the successor test of smm_dom_probe.  A source s of state c is also left
+ * out when an OLDER source a ("anchor": the last source that was not itself dominated this way; position 0 at first)
+ * beats it STRICTLY at every target band 0 reaches: candidate (a, k + s - a) exists for every band-0 length k (k + s - a
+ * <= kp - 1) and  h[s][c] - h[a][c] < D_c[s - a] = min_{9 <= k <= min(127, kp-1)} (len[k + s - a][c] - len[k][c])
+ * (deflated by 2^-49 relative).  Inside a long segment the segment's START is such an anchor for every later source.
+ * The block's last source is still always pushed (the successor test's chain ends there).
+ * out[0] = (state, block) pairs, out[1] = pushed with the successor test only, out[2] = pushed with both tests,
+ * out[3] = blocks, out[4] = sum over blocks of the largest per-state push count, successor test only, out[5] = the same
+ * with both tests, out[6] = anchor changes. */
+int smm_anchor_probe(const double *elp, int t, int c, const double *trans, const double *init, const double *len, int kp,
+                     double *out)
+{
+    double *cum = (double *)calloc((size_t)(t + 1) * c, sizeof(double));
+    double *h = (double *)malloc(sizeof(double) * (size_t)(t + 1) * c);
+    double *gam = (double *)malloc(sizeof(double) * c);
+    double *dmn = (double *)malloc(sizeof(double) * (size_t)kp * c);
+    if (!cum || !h || !gam || !dmn) return -1;
+    memset(out, 0, sizeof(double) * 8);
+    for (int j = 0; j < c; ++j) h[j] = init[j];
+    for (int n = 1; n <= t; ++n) {
+        const int kmax = (kp - 1 < n) ? kp - 1 : n;
+        for (int j = 0; j < c; ++j) {
+            cum[(size_t)n * c + j] = cum[(size_t)(n - 1) * c + j] + elp[(size_t)(n - 1) * c + j];
+            double a = -INFINITY;
+            for (int k = 1; k <= kmax; ++k) a = dmax(a, h[(size_t)(n - k) * c + j] + len[(size_t)k * c + j]);
+            gam[j] = cum[(size_t)n * c + j] + a;
+        }
+        for (int to = 0; to < c; ++to) {
+            double bt = -INFINITY;
+            for (int j = 0; j < c; ++j) bt = dmax(bt, gam[j] + trans[(size_t)to * c + j]);
+            h[(size_t)n * c + to] = bt - cum[(size_t)n * c + to];
+        }
+    }
+    const int khi = (kp - 1 < 127) ? kp - 1 : 127;
+    for (int j = 0; j < c; ++j)
+        for (int d = 1; d < kp; ++d) {
+            double m = INFINITY;
+            if (khi + d > kp - 1) m = -INFINITY;
+            else
+                for (int k = 9; k <= khi; ++k) {
+                    if (len[(size_t)k * c + j] == -INFINITY) continue;
+                    m = dmin(m, len[(size_t)(k + d) * c + j] - len[(size_t)k * c + j]);
+                }
+            dmn[(size_t)d * c + j] = m > 0 ? m * (1.0 - 0x1p-49) : m * (1.0 + 0x1p-49);
+        }
+    int *anc = (int *)calloc(c, sizeof(int));
+    for (int j0 = 0; j0 * 8 + 1 <= t; ++j0) {
+        int worst1 = 0, worst2 = 0;
+        out[3] += 1.0;
+        for (int j = 0; j < c; ++j) {
+            double x1 = -INFINITY;
+            for (int k = 9; k <= khi; ++k) {
+                if (len[(size_t)k * c + j] == -INFINITY) continue;
+                x1 = dmax(x1, len[(size_t)k * c + j] - len[(size_t)(k - 1) * c + j]);
+            }
+            if (x1 < 0) x1 = 0;
+            int p1 = 0, p2 = 0;
+            for (int i = 0; i < 8; ++i) {
+                const int s = j0 * 8 + 1 + i;
+                if (s > t) break;
+                const int last = (i == 7 || s == t);
+                int dom = 0;
+                if (!last) dom = h[(size_t)(s + 1) * c + j] - h[(size_t)s * c + j] > x1;
+                const int a = anc[j], d = s - a;
+                int adom = 0;
+                if (d >= 1 && d < kp) adom = h[(size_t)s * c + j] - h[(size_t)a * c + j] < dmn[(size_t)d * c + j];
+                if (!adom) { anc[j] = s; out[6] += 1.0; }
+                p1 += last || !dom;
+                p2 += last || (!dom && !adom);
+            }
+            out[0] += 1.0; out[1] += p1; out[2] += p2;
+            if (p1 > worst1) worst1 = p1;
+            if (p2 > worst2) worst2 = p2;
+        }
+        out[4] += worst1; out[5] += worst2;
+    }
+    free(cum); free(h); free(gam); free(dmn); free(anc);
+    return 0;
+}

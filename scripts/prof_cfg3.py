@@ -37,8 +37,8 @@ for tag in sys.argv[1:]:
     tot = sum((ln // (4 if os.environ.get('SMM_BAND_B') == '4' else 8)) * pc.n_states[g] * 8 for ln, g in zip(pc.lengths, pc.group))
     same = '' if ref is None else '  labels equal to the first variant: %s' % bool((lab == ref).all())
     ref = lab.clone() if ref is None else ref
-    print('%s: DP kernel %.3f ms (min %.3f); delayed band-blocks evaluated %d of %d (%.2f %%)%s'
-          % (tag, float(np.mean(ms)), min(ms), raw.view(np.int32)[3], tot, 100.0 * raw.view(np.int32)[3] / tot, same))
+    print('%s: DP kernel %.3f ms (min %.3f); delayed band-blocks evaluated %d of %d (%.2f %%); sources pushed into band 0 per (state, block): %.3f%s'
+          % (tag, float(np.mean(ms)), min(ms), raw.view(np.int32)[3], tot, 100.0 * raw.view(np.int32)[3] / tot, raw.view(np.int32)[2] / (tot / 8.0), same))
     nblk = pp[7]
     if nblk and pp[45]:
         print('   workgroup 0, cycles: prologue %d | forward %d (%.0f per block) | closing + back-trace %d (%d segments; phase A %d, phase B %d, labels %d)'

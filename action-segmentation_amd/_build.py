@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsmmdp.so")
-SOURCES = ["smm_api.hip", "smm_emission.hip", "smm_viterbi.hip", "smm_logz.hip", "smm_logz_bwd.hip", "smm_dense.hip",
+SOURCES = ["smm_api.hip", "smm_emission.hip", "smm_viterbi.hip", "smm_chunk.hip", "smm_logz.hip", "smm_logz_bwd.hip", "smm_dense.hip",
            "smm_eval.hip", "smm_fit.hip", "smm_tables.hip"]
 HEADERS = ["smm_device.h", "smm_launch.h", os.path.join("..", "..", "include", "smmdp.h")]
 # -ffp-contract=off: every a+b in the DP must be ONE IEEE add (bit-exact twin of oracle/smm_oracle.c)

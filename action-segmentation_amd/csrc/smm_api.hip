@@ -30,6 +30,9 @@ struct SmmEnv {
     double split_min_us = 100.0, split_ns = 0.0;     // SMM_SPLIT_MIN_US, SMM_SPLIT_NS (0: from smm_band_frame_ns), SMM_SPLIT_MARGIN: choose_split's model
     int split_margin = 400;
     int plan_cache = 1;       // SMM_PLAN_CACHE=0: no resident plans
+    int chunk = 1;            // SMM_CHUNK=0: no time-split decode of long videos (same results)
+    int chunk_p = 0;          // SMM_CHUNK_P: positions per unit of a time-split decode (0: from the launch's CU-time; tests force small ones)
+    int chunk_wc = 512;       // SMM_CHUNK_WC: warm-up positions of a unit in front of the kp - 1 it is certified on
     int no_bt_window = 0;     // SMM_NO_BT_WINDOW=1: the general back-trace also for kp <= 64 (same results)
     int fit_grid = 0;         // SMM_FIT_GRID: workgroups of the class-sums kernel (tuning aid)
     int verbose = 0;          // SMM_VERBOSE
@@ -54,7 +57,8 @@ void env_read()
     const Item items[] = {
         {"SMM_SPEC", &e.spec, nullptr}, {"SMM_NO_SPLIT", &e.no_split, nullptr}, {"SMM_SPLIT_MIN_US", nullptr, &e.split_min_us},
         {"SMM_SPLIT_NS", nullptr, &e.split_ns}, {"SMM_SPLIT_MARGIN", &e.split_margin, nullptr},
-        {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
+        {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_CHUNK", &e.chunk, nullptr}, {"SMM_CHUNK_P", &e.chunk_p, nullptr},
+        {"SMM_CHUNK_WC", &e.chunk_wc, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
         {"SMM_FIT_GRID", &e.fit_grid, nullptr}, {"SMM_VERBOSE", &e.verbose, nullptr},
 #ifdef SMM_DEV
         {"SMM_DEBUG_FLAGS", &e.debug_flags, nullptr}, {"SMM_SPLIT_DEBUG", &e.split_debug, nullptr},
@@ -193,8 +197,21 @@ struct SmmPlan {
     size_t elp_doubles;    // total_frames*c_max  (smm_decode_f32 / smm_viterbi_f32)
     size_t tab_doubles;    // widened tables       (smm_viterbi_f32)
     size_t band_doubles;   // Viterbi BAND mode: state-major length table + skip-test bounds per (group, state)
+    size_t b;              // videos
+    size_t chunk_bytes;    // Viterbi, time-split videos: redo words | anchors | (not resident: the units' metadata); an upper bound
+    size_t o_chunk;        // ... its offset in the workspace
     size_t total;
 };
+
+// Upper bounds of a time-split plan (the workspace is sized before anything is planned): a unit's own part is never shorter
+// than SMM_CHUNK_LMIN positions, so a video of T frames has at most T / SMM_CHUNK_LMIN + 1 units
+constexpr int SMM_CHUNK_LMIN = 512;
+static size_t chunk_units_max(const smm_shape *s) { return (size_t)(s->total_frames / SMM_CHUNK_LMIN) + 2 * (size_t)s->b; }
+static size_t chunk_ext_meta_bytes(size_t b, size_t units, size_t n_cv)
+{
+    return align_up(sizeof(SmmVideo) * (b + units), 256) + align_up(sizeof(int32_t) * (b + units), 256) +
+           align_up(sizeof(SmmChunkVideo) * n_cv, 256) + align_up(sizeof(int32_t) * n_cv, 256);
+}
 
 static bool shape_ok(const smm_shape *s)
 {
@@ -204,6 +221,7 @@ static bool shape_ok(const smm_shape *s)
 static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
 {
     SmmPlan p{};
+    p.b = (size_t)s->b;
     p.o_order = align_up(sizeof(SmmVideo) * s->b, 256);
     p.o_nstates = p.o_order + align_up(sizeof(int32_t) * s->b, 256);
     p.o_emcum = p.o_nstates + align_up(sizeof(int32_t) * s->n_groups, 256);
@@ -215,7 +233,13 @@ static SmmPlan make_plan(const smm_shape *s, const int64_t *lengths)
     p.elp_doubles = (size_t)s->total_frames * s->c_max;
     p.tab_doubles = (size_t)s->n_groups * s->c_max * ((size_t)s->c_max + 1 + s->k_rows) + (size_t)s->b * s->c_max;
     p.band_doubles = (size_t)s->n_groups * s->c_max * ((size_t)SMM_BAND_ROW + SMM_BAND_TAB + 64);   // len_t | band_tab | dmin_t
-    p.total = p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles + p.band_doubles) + 1024;
+    {
+        const size_t um = chunk_units_max(s);
+        p.chunk_bytes = align_up(sizeof(int32_t) * s->b, 256) + align_up(sizeof(double) * um * s->c_max, 256) +
+                        chunk_ext_meta_bytes(s->b, um, s->b);
+    }
+    p.o_chunk = align_up(p.meta_bytes + 8 * (p.hist_doubles + p.elp_doubles + p.tab_doubles + p.band_doubles), 256);
+    p.total = p.o_chunk + p.chunk_bytes + 1024;
     return p;
 }
 
@@ -249,6 +273,14 @@ struct Staged {
     int em_tpw, em_blocks;
     int kp_max, c_need;
     int n_split;           // decode only: the first n_split videos of `order` are the launch's critical path (0: no split)
+    // time-split videos (Viterbi; smm_chunk.hip).  n_cv = 0: none.  uvideos = [the b videos | the units]; uorder = the DP
+    // launch's order over [unsplit videos, units] -- the units first (u_part1 of them: with a stream split they are its first part)
+    SmmVideo *uvideos;
+    int32_t *uorder, *porder;     // porder: the split videos, for the repair launch
+    SmmChunkVideo *cvs;
+    int32_t *redo;
+    double *anchors;
+    int n_cv, n_units, u_part1;
 };
 
 static bool band_mode(int kp_max, int c_need);
@@ -415,12 +447,17 @@ void plan_point(const SmmPlan &p, void *ws, Staged *out)
     out->elp = out->hist + p.hist_doubles;
     out->tabs = out->elp + p.elp_doubles;
     out->band = out->tabs + p.tab_doubles;
+    out->redo = reinterpret_cast<int32_t *>(base + p.o_chunk);
+    out->anchors = reinterpret_cast<double *>(base + p.o_chunk + align_up(sizeof(int32_t) * p.b, 256));
 }
 }  // namespace
 
+// meta_alloc(bytes): where the IMMUTABLE metadata of this call goes when it is to be kept as a resident plan (called once,
+// with the exact size, after the host-side planning); nullptr result / no function: into the workspace
 static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                           const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                          bool for_viterbi, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out);
+                          bool for_viterbi, int cum_chunk, bool want_split, const std::function<char *(size_t)> *meta_alloc,
+                          SmmPlan *plan_out);
 
 static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                  const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
@@ -461,7 +498,6 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
     }
     // miss: stage, and keep the plan unless this is a capture (no allocation there) or the cache is full
     char *dev_meta = nullptr;
-    const SmmPlan p0 = make_plan(s, lengths);
     bool keep = !capturing;
     if (keep) {
         std::lock_guard<std::mutex> lock(g_plans.mu);
@@ -472,17 +508,20 @@ static int stage(const smm_shape *s, const int64_t *lengths, const int64_t *fram
             g_plans.seen_once.emplace(hk, 1u);
             keep = false;
         }
-        keep = keep && g_plans.bytes + p0.o_err <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES &&
-               g_plans.key_bytes + key.size() <= SMM_PLAN_MAX_BYTES;
-        if (keep) {
-            dev_meta = plan_alloc(p0.o_err, dev);
-            keep = dev_meta != nullptr;
-            if (keep) g_plans.bytes += align_up(p0.o_err, 256);
-        }
     }
+    // (called by stage_uncached once the size of the immutable metadata is known: the videos, and the units of a time-split plan)
+    const std::function<char *(size_t)> alloc = [&](size_t bytes) -> char * {
+        std::lock_guard<std::mutex> lock(g_plans.mu);
+        if (!(g_plans.bytes + bytes <= SMM_PLAN_MAX_BYTES && g_plans.n < SMM_PLAN_MAX_ENTRIES &&
+              g_plans.key_bytes + key.size() <= SMM_PLAN_MAX_BYTES)) return nullptr;
+        dev_meta = plan_alloc(bytes, dev);
+        if (dev_meta) g_plans.bytes += align_up(bytes, 256);
+        return dev_meta;
+    };
     SmmPlan plan{};
     const int rc = stage_uncached(s, lengths, frame_off, group, kp, n_states, ws, ws_bytes, stream, out, for_viterbi, cum_chunk, want_split,
-                                  keep ? dev_meta : nullptr, &plan);
+                                  keep ? &alloc : nullptr, &plan);
+    keep = keep && dev_meta != nullptr;
     if (rc != SMM_OK || !keep) return rc;          // (a buffer cut for a call that failed stays cut: 64 MB bound the total)
     PlanEntry *e = new PlanEntry;
     e->key = key;
@@ -544,9 +583,85 @@ extern "C" size_t smm_cached_plan_bytes(void)
     return n;
 }
 
+// Time-split plan of a Viterbi launch (smm_chunk.hip).  A launch lasts as long as its longest video -- one serial chain -- while
+// its CU-time may be a fraction of that: videos longer than P positions are cut into units of about P positions each (unit
+// 0: the video's first P'; the others: OV = warm-up + kp - 1 positions in front of an own part of L' = P' - OV), P from the
+// launch's CU-time (SMM_CHUNK_P overrides).  An own part is at least kp - 1 positions (the window a unit is certified on
+// must lie inside the previous unit's own part) and at least SMM_CHUNK_LMIN; the units' histories live in the video's own
+// history block (8 c_max (T + 1) doubles: a unit needs 3 C (T_u + 1)).
+struct ChunkPlan {
+    std::vector<SmmVideo> units;
+    std::vector<SmmChunkVideo> cvs;
+};
+
+static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out)
+{
+    const SmmEnv &ev = env();
+    if (!ev.chunk || (s->flags & SMM_SHAPE_NO_EOS) || !band) return;             // (BAND-mode launches: the span limits long videos come with, and the repair launch's kernel)
+    const int n_cu = device_cus();
+    if (n_cu <= 0) return;
+    auto ns = [&](int c) { return smm_band_frame_ns(c); };
+    double t_cu = 0.0, t_long = 0.0;
+    for (int i = 0; i < s->b; ++i) {
+        const double t = (double)hv[i].T * ns(n_states[hv[i].group]);
+        t_cu += t;
+        t_long = std::max(t_long, t);
+    }
+    // the launch's CU-time: the DP's share per CU + what the emission pass in front of it (or beside it) takes of the chip
+    t_cu = t_cu / n_cu + (s->d > 0 ? (double)s->total_frames * (4.0 * s->d + 8.0 * s->c_max) / 4.0e3 : 0.0);
+    // Only a launch that is bound by its longest video is split.  Measured on cfg3 (360 videos, CU-time 2.3 ms against 2.3 ms
+    // for its longest video; profiles/round5_time_split.txt): cutting its 46 longest videos shortens the critical launch from
+    // 2.3 to 1.5 ms and the step not at all -- the other 314 videos keep 256 CUs busy for 2.1 ms either way -- while every
+    // video that has to be repaired (2..4 per launch there: runs of one class decoded as two spans, whose (a, b) / (b, a) orders
+    // tie to within rounding) costs a whole one-piece decode on top.  One long video on an idle GPU (cfg1) is the other end:
+    // 1.70 -> 0.92 ms.  SMM_CHUNK_P forces the split (tests).
+    if (ev.chunk_p <= 0 && t_long < 1.5 * t_cu) return;
+    const size_t units_cap = chunk_units_max(s);
+    for (int i = 0; i < s->b; ++i) {
+        const int T = hv[i].T, C = n_states[hv[i].group], kpv = hv[i].kp;
+        const int ov = std::max(ev.chunk_wc, 16) + kpv - 1;
+        const int lmin = std::max(kpv - 1, SMM_CHUNK_LMIN);
+        const int pmin = ov + lmin;
+        // positions per unit: what the launch's CU-time lasts on this video's state count (+ 10 %), at least pmin
+        int P = ev.chunk_p > 0 ? ev.chunk_p : (int)(1.1 * t_cu / ns(C));
+        P = std::max(P, pmin);
+        if ((double)T < 1.05 * P || T < pmin + lmin) continue;                   // (not worth a second unit)
+        int n_rest = (T - P + (P - ov) - 1) / (P - ov);
+        int Pq = 0;
+        for (; n_rest >= 1; --n_rest) {                                          // equal shares: P' + n_rest (P' - OV) = T
+            Pq = (int)(((int64_t)T + (int64_t)n_rest * ov + n_rest) / (n_rest + 1));
+            if (Pq - ov >= lmin) break;
+        }
+        if (n_rest < 1 || n_rest + 1 > SMM_CHUNK_MAX_UNITS) continue;
+        const int L = Pq - ov;
+        // unit j >= 1: own part (r_j, e_j], r_j = Pq + (j - 1) L, first position a_j = r_j - OV; the last one ends at T
+        size_t need = (size_t)3 * C * ((size_t)Pq + 1);
+        for (int j = 1; j <= n_rest; ++j) {
+            const int r = Pq + (j - 1) * L, e = (j == n_rest) ? T : r + L;
+            need += (size_t)3 * C * ((size_t)(e - (r - ov)) + 1);
+        }
+        if (need > (size_t)8 * s->c_max * ((size_t)T + 1) || Pq + (n_rest - 1) * L >= T) continue;
+        if (out.units.size() + n_rest + 1 > units_cap) break;
+        SmmChunkVideo cv{i, (int32_t)out.units.size(), n_rest + 1, ov};           // (first_unit: made absolute by the caller)
+        size_t hoff = (size_t)hv[i].hist_off;
+        for (int j = 0; j <= n_rest; ++j) {
+            const int r = j ? Pq + (j - 1) * L : 0, a0 = j ? r - ov : 0, e = (j == n_rest) ? T : Pq + j * L;
+            SmmVideo u = hv[i];
+            u.frame_off = hv[i].frame_off + a0;
+            u.hist_off = (int64_t)hoff;
+            u.T = e - a0;
+            u.pad = 1 | (j ? 2 : 0) | (a0 << 2);
+            hoff += (size_t)3 * C * ((size_t)u.T + 1);
+            out.units.push_back(u);
+        }
+        out.cvs.push_back(cv);
+    }
+}
+
 static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,
                           const int32_t *kp, const int32_t *n_states, void *ws, size_t ws_bytes, hipStream_t stream, Staged *out,
-                          bool for_viterbi, int cum_chunk, bool want_split, char *meta_dst, SmmPlan *plan_out)
+                          bool for_viterbi, int cum_chunk, bool want_split, const std::function<char *(size_t)> *meta_alloc,
+                          SmmPlan *plan_out)
 {
     if (!shape_ok(s) || !lengths || !frame_off || !n_states || !ws) return SMM_ERR_ARG;
     if (s->c_max > SMM_MAX_STATES || s->k_rows > SMM_MAX_K_ROWS) return SMM_ERR_UNSUPPORTED;
@@ -593,7 +708,27 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     if (cum_chunk > 0) std::stable_sort(ho, ho + s->b, [&](int a, int b) { return hv[a].group < hv[b].group; });
     std::memcpy(hn, n_states, sizeof(int32_t) * s->n_groups);
     out->band_mode = band_mode(kp_max, c_need);
-    out->n_split = want_split ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
+    // time-split plan (Viterbi launches only): the split videos come FIRST in `order` -- with a stream split they are its
+    // first part (their emission, the prefix sums at their units' starts and their units' DP on the caller's stream, the
+    // rest beside them)
+    ChunkPlan cp;
+    if (for_viterbi && cum_chunk == 0) plan_chunks(s, hv, n_states, kp_max, out->band_mode, cp);
+    const int n_cv = (int)cp.cvs.size(), n_un = (int)cp.units.size();
+    out->n_cv = n_cv;
+    out->n_units = s->b - n_cv + n_un;
+    out->u_part1 = n_un;
+    out->n_split = 0;
+    if (n_cv > 0) {
+        std::vector<char> is_cv(s->b, 0);
+        for (const SmmChunkVideo &cv : cp.cvs) is_cv[cv.vid] = 1;
+        std::stable_partition(ho, ho + s->b, [&](int32_t v) { return is_cv[v] != 0; });
+        // the stream split of a decode: the split videos are its critical part, if there is enough beside them to be worth a second stream
+        const SmmEnv &ev = env();
+        const double em_us = (double)s->total_frames * (4.0 * s->d + 8.0 * s->c_max) / 4.0e6;
+        if (want_split && !ev.no_split && s->b - n_cv >= 16 && em_us >= ev.split_min_us) out->n_split = n_cv;
+    } else {
+        out->n_split = want_split ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
+    }
     {
         // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
         int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
@@ -609,11 +744,38 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
         out->em_blocks = (int)cum;
         if (out->n_split > 0) out->em_cum_host.assign(hc, hc + s->b + 1);
     }
+    // the units' metadata: [videos | units], the DP launch's order over [units (most work first) | unsplit videos (as in `order`)],
+    // the split videos' table and -- for the repair launch -- their list
+    std::vector<char> ext;
+    size_t x_order = 0, x_cvs = 0, x_porder = 0;
+    if (n_cv > 0) {
+        x_order = align_up(sizeof(SmmVideo) * ((size_t)s->b + n_un), 256);
+        x_cvs = x_order + align_up(sizeof(int32_t) * ((size_t)s->b + n_un), 256);
+        x_porder = x_cvs + align_up(sizeof(SmmChunkVideo) * n_cv, 256);
+        ext.assign(x_porder + align_up(sizeof(int32_t) * n_cv, 256), 0);
+        SmmVideo *xv = reinterpret_cast<SmmVideo *>(ext.data());
+        int32_t *xo = reinterpret_cast<int32_t *>(ext.data() + x_order);
+        SmmChunkVideo *xc = reinterpret_cast<SmmChunkVideo *>(ext.data() + x_cvs);
+        int32_t *xp = reinterpret_cast<int32_t *>(ext.data() + x_porder);
+        std::memcpy(xv, hv, sizeof(SmmVideo) * s->b);
+        std::memcpy(xv + s->b, cp.units.data(), sizeof(SmmVideo) * n_un);
+        for (int i = 0; i < n_un; ++i) xo[i] = s->b + i;
+        std::stable_sort(xo, xo + n_un, [&](int a, int b) {
+            return (int64_t)xv[a].T * n_states[xv[a].group] > (int64_t)xv[b].T * n_states[xv[b].group];
+        });
+        for (int i = n_cv; i < s->b; ++i) xo[n_un + i - n_cv] = ho[i];
+        for (int i = 0; i < n_cv; ++i) {
+            xc[i] = cp.cvs[i];
+            xc[i].first_unit += s->b;
+            xp[i] = cp.cvs[i].vid;
+        }
+    }
 
     char *base = static_cast<char *>(ws);
     // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream) -- into
-    // the workspace, or into the resident plan's own buffer (meta_dst); the error words behind them (always in the
-    // workspace) start at zero
+    // the workspace, or into the resident plan's own buffer; the error words behind them (always in the workspace) start at zero
+    const size_t o_ext = align_up(p.o_err, 256);
+    char *meta_dst = meta_alloc ? (*meta_alloc)(o_ext + ext.size()) : nullptr;
     char *meta = meta_dst ? meta_dst : base;
     SMM_HIP((hipError_t)smm_upload_meta(meta, host.data(), p.o_err, stream));
     SMM_HIP((hipError_t)smm_zero_async(base + p.o_err, p.meta_bytes - p.o_err, stream));
@@ -622,6 +784,17 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     out->n_states = reinterpret_cast<int32_t *>(meta + p.o_nstates);
     out->em_cum = reinterpret_cast<int32_t *>(meta + p.o_emcum);
     plan_point(p, ws, out);
+    out->uvideos = nullptr; out->uorder = nullptr; out->porder = nullptr; out->cvs = nullptr;
+    if (n_cv > 0) {
+        // (workspace: behind the redo words and the anchors of the chunk region, whose size bounds every plan of this shape)
+        char *xdst = meta_dst ? meta_dst + o_ext
+                              : base + p.o_chunk + align_up(sizeof(int32_t) * s->b, 256) + align_up(sizeof(double) * chunk_units_max(s) * s->c_max, 256);
+        SMM_HIP((hipError_t)smm_upload_meta(xdst, ext.data(), ext.size(), stream));
+        out->uvideos = reinterpret_cast<SmmVideo *>(xdst);
+        out->uorder = reinterpret_cast<int32_t *>(xdst + x_order);
+        out->cvs = reinterpret_cast<SmmChunkVideo *>(xdst + x_cvs);
+        out->porder = reinterpret_cast<int32_t *>(xdst + x_porder);
+    }
     out->kp_max = kp_max;
     out->c_need = c_need;
     if (plan_out) *plan_out = p;
@@ -732,6 +905,17 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     a.hist = st.hist; a.spans = spans; a.labels = labels; a.best = best; a.n_segs = n_segs; a.err = st.err;
     a.c_max = s->c_max; a.k_rows = s->k_rows; a.t_max = s->t_max; a.b = s->b;
     if (count >= 0) { a.order = st.order + first; a.b = count; }
+    // time-split videos (smm_chunk.hip): the launch runs over UNITS -- [the split videos' units | the unsplit videos]; a stream
+    // split's first part is exactly the units
+    const bool with_units = st.n_cv > 0 && (count < 0 || first == 0);
+    if (st.n_cv > 0) {
+        a.videos = st.uvideos;
+        a.b_videos = s->b;
+        a.chunk_anchor = st.anchors;
+        if (count < 0) { a.order = st.uorder; a.b = st.n_units; }
+        else if (first == 0) { a.order = st.uorder; a.b = st.u_part1; }
+        else { a.order = st.uorder + st.u_part1; a.b = st.n_units - st.u_part1; }
+    }
     a.flags = 0;
 #ifdef SMM_DEV
     a.flags = env().debug_flags;                              // (SmmDpArgs::flags bit 0: profiling, outputs undefined)
@@ -756,11 +940,23 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         if (bytes <= 126 * 1024) { a.bt_window = w; a.bt_dyn_bytes = (int32_t)bytes; }
     }
     if (!launch) { SMM_HIP(hipGetLastError()); return SMM_OK; }      // (prep only)
+    if (with_units) smm_launch_cum_anchors(a, st.cvs, st.n_cv, st.anchors, stream);   // cumE at the units' first positions, serially
     std::pair<hipEvent_t, hipEvent_t> tev;
     const bool timed = dp_timing_begin(stream, tev);
     const int rc = smm_launch_viterbi(a, st.band_mode ? 16 : ring_regs(st.kp_max), st.c_need, stream);
     if (timed) dp_timing_end(stream, tev, timing_tag);
     if (rc != SMM_OK) return rc;
+    if (with_units) {
+        // certify the cuts, walk the path, write the split videos' outputs -- and decode again, in one piece, the ones that
+        // could not be certified (one workgroup per split video; all but the flagged ones return at once)
+        smm_launch_chunk_stitch(a, st.cvs, st.n_cv, st.redo, stream);
+        SmmDpArgs ar = a;
+        ar.order = st.porder;
+        ar.b = st.n_cv;
+        ar.redo = st.redo;
+        const int rc2 = smm_launch_viterbi_repair(ar, st.c_need, stream);
+        if (rc2 != SMM_OK) return rc2;
+    }
     SMM_HIP(hipGetLastError());
     return SMM_OK;
 }

@@ -1,0 +1,431 @@
+// smm_chunk.hip -- time-split Viterbi decode of long videos (round 5): the kernels either side of the forward pass.
+//
+// Replaces nothing new in the reference: it is the same decode (semimarkov_modules.py:677-679 per video) with the forward
+// pass of ONE video spread over several workgroups.  A video is one serial chain of T positions (smm_viterbi.hip) -- 1.6 ms
+// for 10 000 frames on one of 256 CUs, whatever else the GPU is doing.  The recursion forgets its start within a segment
+// or two (oracle/prune_probe.c: smm_conv_probe, profiles/round5_rank_convergence.txt: <= 407 positions on cfg1 / cfg3's
+// longest videos), so the time axis can be cut into UNITS that run side by side, each warmed up on the positions in front
+// of its own part -- and the result is still the unsplit decode's, bit for bit, because nothing is taken on trust:
+//
+//   units     unit 0 = positions (0, e_0] as in the unsplit decode.  Unit j >= 1 = positions (a_j, e_j], a_j = r_j - OV,
+//             its OWN part is (r_j, e_j] with r_j = e_{j-1}; OV = warm-up (512) + kp - 1.  It starts from the guess
+//             "h[a_j][c] = 0 for every state, nothing older" and from the SERIAL cumE[a_j][.] (smm_cum_anchor_kernel: the
+//             unsplit decode's additions in the unsplit decode's order), so its cumE rows are the unsplit decode's bits.
+//   certify   (smm_chunk_stitch_kernel, per cut) over the kp positions in front of r_j -- every source a target of the
+//             unit's own part can reach -- the unit's h and the previous unit's h must differ by ONE constant (to 2^-32
+//             of their magnitude), state by state and position by position; the previous unit is certified itself (unit 0
+//             is exact), so by induction every value of the unit's own part is the unsplit value + a constant +- noise,
+//             the noise being the rounding of <= 4 additions per position on values of that magnitude.
+//   decide    the back-trace walks the units' histories from T down, re-evaluating the forward pass's expressions as
+//             the unsplit kernel does, and asks MORE of every decision: the winner (state, then length) must beat every
+//             other candidate by tau = 2^-30 of the magnitude in play -- 250 x the noise bound.  Then the unsplit
+//             decode, whose values differ from these by a constant and less than tau / 2, decides the same, tie order
+//             included (there is no tie).  The path is the unsplit decode's path.
+//   score     the best score is re-evaluated along that path in the unsplit decode's association (cumE rows are its
+//             bits; h along the path is add, add, add, sub per segment): the unsplit decode's number.
+//   repair    a cut that does not certify, a decision inside tau (an exact tie on an integer lattice, a boundary that
+//             rounding decides), a NaN: the video's word in `redo` is set and the launch that follows decodes it again
+//             in one piece with the ordinary kernel (one workgroup per split video, all but the flagged ones return at
+//             once).  Correctness never rests on the split; only the time does.
+//
+// HBM traffic: a unit reads and writes what the unsplit video would for its positions (32C + 8 B per position), OV of
+// them twice; the stitch reads (kp + 1) * C * 16 B per cut and what the back-trace reads anyway.
+#include "smm_device.h"
+#include "../../include/smmdp.h"
+#include "smm_launch.h"
+
+// ------------------------------------------------------------------------------------------------ serial prefix sums
+// cumE[a_j][c] for every unit j >= 1 of one split video: cum = 0; cum = cum + elp[n][c], n = 0, 1, ... in THIS order (the
+// unsplit kernel's mover wave and chain wave do exactly these additions).  One workgroup per split video: eight waves
+// stream 64 rows each into LDS (512 rows per round trip -- a single wave would wait ~1.5 us for every 64 rows), wave 0
+// adds them up, one lane per state, while the next 512 rows are in flight.
+#define SMM_ANCH_WAVES 8
+#define SMM_ANCH_ROWS 64                          // rows per wave and round
+__global__ void __launch_bounds__(SMM_ANCH_WAVES * 64)
+smm_cum_anchor_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, double *anchors)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile[];       // TRANSPOSED: [cm][RPT + 2] -- a state's rows of a round are contiguous
+    const SmmChunkVideo cv = cvs[blockIdx.x];
+    const SmmVideo pv = a.videos[cv.vid];
+    const int cm = a.c_max, C = a.n_states[pv.group];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double *elp = a.elp + (size_t)pv.frame_off * cm;
+    const int n_end = a.videos[cv.first_unit + cv.n_chunks - 1].pad >> 2;    // the last unit's first position: nothing is needed beyond
+    constexpr int RPT = SMM_ANCH_WAVES * SMM_ANCH_ROWS;                       // rows per round
+    constexpr int TS = RPT + 2;                                               // doubles per state of the transposed tile (16-byte rows, odd multiple of 16 B: no bank pile-up)
+    const int per_lane = (SMM_ANCH_ROWS * cm + 63) / 64;                      // elements per lane of a wave's slab (<= 32)
+    double reg[32];
+    auto fetch = [&](int row0) {                                              // this wave's slab of the round that starts at row0
+        const int64_t e0 = (int64_t)(row0 + w * SMM_ANCH_ROWS) * cm, e_max = (int64_t)n_end * cm - 1;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            if (q < per_lane) {
+                int64_t e = e0 + lane + 64 * q;
+                reg[q] = elp[e <= e_max ? e : e_max];                         // (clamped: rows beyond n_end are never added)
+            }
+        }
+    };
+    double cum = 0.0;
+    int next_unit = 1;
+    int next_at = a.videos[cv.first_unit + 1].pad >> 2;
+    fetch(0);
+    for (int row0 = 0; row0 < n_end; row0 += RPT) {
+        // (element e of the wave's slab = row e / cm, state e % cm; two rows of a state per 16-byte LDS read in the sum below)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int e = lane + 64 * q;
+            if (q < per_lane && e < SMM_ANCH_ROWS * cm) tile[(size_t)(e % cm) * TS + w * SMM_ANCH_ROWS + e / cm] = reg[q];
+        }
+        __syncthreads();
+        if (row0 + RPT < n_end) fetch(row0 + RPT);                            // in flight while wave 0 adds this round up
+        if (w == 0 && lane < C) {
+            const int rows = (n_end - row0 < RPT) ? n_end - row0 : RPT;
+            const double *col = tile + (size_t)lane * TS;
+            const double2 *col2 = reinterpret_cast<const double2 *>(col);
+            int r = 0;
+            while (r < rows) {
+                // cumE[n] = sum of the rows before n: the anchor of a unit that starts at n is taken BEFORE row n is added
+                if (row0 + r == next_at) {
+                    anchors[(size_t)(cv.first_unit - a.b_videos + next_unit) * cm + lane] = cum;
+                    ++next_unit;
+                    next_at = next_unit < cv.n_chunks ? (a.videos[cv.first_unit + next_unit].pad >> 2) : 0x7fffffff;
+                }
+                // ... then straight on to the next anchor or the end of the round.  The additions are one dependent chain
+                // (~6 cycles each); the LDS reads run ahead of it, sixteen 16-byte reads (32 rows) in flight
+                const int stop = (next_at - row0 < rows) ? next_at - row0 : rows;
+                if (r & 1) { cum = cum + col[r]; ++r; if (r >= stop) continue; }
+                if (r + 32 <= stop) {
+                    double2 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = col2[(r >> 1) + u];
+                    for (; r + 64 <= stop; r += 32) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            cum = cum + v[u].x;
+                            cum = cum + v[u].y;
+                            v[u] = col2[((r + 32) >> 1) + u];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        cum = cum + v[u].x;
+                        cum = cum + v[u].y;
+                    }
+                    r += 32;
+                }
+                for (; r + 2 <= stop; r += 2) {
+                    const double2 v = col2[r >> 1];
+                    cum = cum + v.x;
+                    cum = cum + v.y;
+                }
+                if (r < stop) { cum = cum + col[r]; ++r; }
+            }
+        }
+        __syncthreads();
+    }
+    // (a unit that starts exactly at n_end: the loop above ends before row n_end)
+    if (w == 0 && lane < C && next_unit < cv.n_chunks && next_at == n_end)
+        anchors[(size_t)(cv.first_unit - a.b_videos + next_unit) * cm + lane] = cum;
+}
+
+// ------------------------------------------------------------------------------------------------ stitch
+#define SMM_STITCH_THREADS 1024
+#define SMM_STITCH_MAXSEG 1024
+
+__device__ __forceinline__ bool smm_finite_bits(double x)
+{
+    int hi = __double2hiint(x);
+    asm volatile("" : "+v"(hi));
+    return (hi & 0x7ff00000) != 0x7ff00000;
+}
+
+// one workgroup per split video (see the head of this file).  Error block word 4 counts the split videos, word 5 the ones
+// handed to the repair launch (ops.error_words).
+__global__ void __launch_bounds__(SMM_STITCH_THREADS)
+smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
+{
+    const SmmChunkVideo cv = cvs[blockIdx.x];
+    const int vid = cv.vid;
+    const SmmVideo pv = a.videos[vid];
+    const int T = pv.T, g = pv.group, C = a.n_states[g], cm = a.c_max, kp = pv.kp;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int NW = SMM_STITCH_THREADS / 64;
+    const double *trans = a.trans + (size_t)g * cm * cm;
+    const double *init = a.init + (size_t)g * cm;
+    const double *len = a.len + (size_t)g * a.k_rows * cm;
+    const double *endpen = a.endpen ? a.endpen + (size_t)vid * cm : nullptr;
+    const int64_t *cmap = a.class_map ? a.class_map + (size_t)g * (cm + 1) : nullptr;
+    int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
+    int64_t *labels = a.labels ? a.labels + pv.frame_off : nullptr;
+    const SmmVideo *units = a.videos + cv.first_unit;
+    const int nu = cv.n_chunks;
+
+    __shared__ int sh_bad;
+    __shared__ double sh_dref;
+    __shared__ unsigned sh_kmin, sh_near;
+    __shared__ int sh_guess[SMM_MAX_STATES_DEV + 1];
+    __shared__ int sh_ua[SMM_CHUNK_MAX_UNITS], sh_ut[SMM_CHUNK_MAX_UNITS];
+    __shared__ long long sh_uoff[SMM_CHUNK_MAX_UNITS];
+    __shared__ int sh_seg_s[SMM_STITCH_MAXSEG];
+    __shared__ int sh_seg_c[SMM_STITCH_MAXSEG];
+    __shared__ double sh_cn[SMM_STITCH_MAXSEG], sh_ct[SMM_STITCH_MAXSEG];     // cumE[n][c], cumE[n][to] at the segments' ends
+    __shared__ double sh_ln[SMM_STITCH_MAXSEG], sh_tr[SMM_STITCH_MAXSEG];   // ... their length scores and the transitions behind them
+    __shared__ double sh_h0;
+
+    if (threadIdx.x == 0) { sh_bad = 0; sh_kmin = 0xffffffffu; sh_near = 0; }
+    // (sh_bad: WHY the video goes to the repair launch -- 1 a cut does not certify, 2 the closing step, 4 two states within tau,
+    // 8 two lengths within tau / none attains the maximum, 16 NaN or too many segments; OR-ed into error block word 6)
+    if (spans)
+        for (int i = threadIdx.x; i <= a.t_max; i += blockDim.x) spans[i] = -1;
+    __syncthreads();
+
+    // unit j: positions a_j .. a_j + T_j, history rows by LOCAL position n - a_j (the units' table in LDS: the back-trace asks
+    // for it once per segment)
+    for (int j = threadIdx.x; j < nu; j += blockDim.x) {
+        sh_ua[j] = units[j].pad >> 2;
+        sh_ut[j] = units[j].T;
+        sh_uoff[j] = units[j].hist_off;
+    }
+    __syncthreads();
+    auto u_a = [&](int j) { return sh_ua[j]; };
+    auto u_t = [&](int j) { return sh_ut[j]; };
+    auto u_cum = [&](int j) { return a.hist + sh_uoff[j]; };
+    auto u_h = [&](int j) { return a.hist + sh_uoff[j] + (size_t)C * (sh_ut[j] + 1); };
+    auto u_gam = [&](int j) { return a.hist + sh_uoff[j] + (size_t)2 * C * (sh_ut[j] + 1); };
+
+    // ---------------------------------------------------------------------------------------------- certify the cuts
+    for (int j = 1; j < nu; ++j) {
+        const int r = u_a(j) + cv.ov;                             // unit j's own part begins behind r = the end of unit j-1
+        const int a1 = u_a(j), a0 = u_a(j - 1), t1 = u_t(j), t0 = u_t(j - 1);
+        const double *h1 = u_h(j), *h0 = u_h(j - 1);
+        const double *c1 = u_cum(j), *c0 = u_cum(j - 1);
+        if (r != a0 + t0 || r - (kp - 1) - a1 < 1) { if (threadIdx.x == 0) sh_bad = 16; break; }   // (the host's layout: never)
+        // the reference difference: the state that leads h at r in unit j
+        if (w == 0) {
+            double v = (lane < C) ? h1[(size_t)lane * (t1 + 1) + (r - a1)] : SMM_NEG_INF;
+            const double v0 = (lane < C) ? h0[(size_t)lane * (t0 + 1) + (r - a0)] : SMM_NEG_INF;
+            if (!(smm_finite_bits(v) && smm_finite_bits(v0))) v = SMM_NEG_INF;
+            double m = v;
+            int mc = lane;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double m2 = __shfl_xor(m, off);
+                const int c2 = __shfl_xor(mc, off);
+                if (m2 > m || (m2 == m && c2 < mc)) { m = m2; mc = c2; }
+            }
+            const double d = smm_readlane(v, mc) - smm_readlane(v0, mc);
+            if (lane == 0) { sh_dref = d; if (!smm_finite_bits(d) || m == SMM_NEG_INF) sh_bad = 1; }
+        }
+        __syncthreads();
+        const double dref = sh_dref;
+        const double cscale = fabs(c1[(size_t)(r - a1) * C]);     // the magnitude of the prefix sums there
+        int bad = 0;
+        // positions r - (kp - 1) .. r: one per thread (kp <= 1024 = the workgroup), the states in batches of eight with all
+        // sixteen loads of a batch in flight (h is state-major: consecutive threads read consecutive doubles)
+        const int s = r - (kp - 1) + (int)threadIdx.x;
+        if ((int)threadIdx.x < kp) {
+            for (int cb = 0; cb < C; cb += 8) {
+                double x1[8], x0[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = cb + q < C ? cb + q : C - 1;
+                    x1[q] = h1[(size_t)c * (t1 + 1) + (s - a1)];
+                    x0[q] = h0[(size_t)c * (t0 + 1) + (s - a0)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool f1 = smm_finite_bits(x1[q]), f0 = smm_finite_bits(x0[q]);
+                    if (f1 != f0) { bad = 1; continue; }              // -inf on one side only (or a NaN)
+                    if (!f1) { if (smm_nan_bits(x1[q]) || smm_nan_bits(x0[q]) || x1[q] != x0[q]) bad = 1; continue; }
+                    const double tol = 0x1p-32 * (fabs(x1[q]) + fabs(x0[q]) + cscale + 1.0);
+                    if (!(fabs((x1[q] - x0[q]) - dref) <= tol)) bad = 1;
+                }
+            }
+        }
+        // the prefix sums of the two units are the same additions: the same bits
+        for (int e = threadIdx.x; e < C; e += blockDim.x)
+            if (__double_as_longlong(c1[(size_t)(r - a1) * C + e]) != __double_as_longlong(c0[(size_t)(r - a0) * C + e])) bad = 1;
+        if (bad) sh_bad = 1;
+        __syncthreads();
+        if (sh_bad) break;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------------------------------------- closing step (n = T)
+    // as in smm_viterbi_kernel: candidates fin[to], to = 0..C (C = EOS); here the winner must win by tau
+    int n = T, to = 0, nseg = 0;
+    int ju = nu - 1;                                              // the unit whose own part holds n
+    if (!sh_bad) {
+        const double *gT = u_gam(ju) + (size_t)(T - u_a(ju)) * C;
+        double f = SMM_NEG_INF;
+        if (lane <= C) {
+            for (int c = 0; c < C; ++c) {
+                const double wgt = (lane == C) ? (endpen ? endpen[c] : 0.0) : trans[(size_t)lane * cm + c];
+                f = fmax(f, gT[c] + wgt);
+            }
+            if (lane < C) f = f + SMM_BIG_NEG;
+        }
+        double m = f;
+        int mc = (lane <= C) ? lane : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double m2 = __shfl_xor(m, off);
+            const int c2 = __shfl_xor(mc, off);
+            if (m2 > m || (m2 == m && c2 < mc)) { m = m2; mc = c2; }
+        }
+        const double tau = 0x1p-30 * (fabs(m) + 1.0);
+        const bool near = lane <= C && lane != mc && !(f < m - tau);
+        // (a winner other than EOS -- every end penalised -- goes to the repair launch as well: the score below assumes EOS)
+        if ((__ballot(near) != 0 || !smm_finite_bits(m) || mc != C) && threadIdx.x == 0) sh_bad = 2;
+        to = mc;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------------------------------------- back-trace
+    // (n, to): the segment that ends at n in front of label `to`.  One thread per candidate length (kp - 1 <= 1023 of
+    // them); lane c of every wave holds state c's row entries.  As in smm_viterbi_kernel a segment is ONE trip to the
+    // history when the predecessor state is the one seen the last time (sh_guess; at first the arg-max of the transition
+    // row): that state's column travels with the row, and the next segment's trip is issued in front of this one's stores.
+    if (threadIdx.x <= (unsigned)C) {
+        const int t2 = threadIdx.x;
+        int bi = C - 1;
+        if (t2 < C) {
+            double bv = SMM_NEG_INF;
+            bi = 0;
+            for (int c2 = 0; c2 < C; ++c2) {
+                const double v2 = trans[(size_t)t2 * cm + c2];
+                if (v2 > bv) { bv = v2; bi = c2; }
+            }
+        } else if (endpen) {
+            for (int c2 = 0; c2 < C; ++c2)
+                if (endpen[c2] == 0.0) bi = c2;
+        }
+        sh_guess[t2] = bi;
+    }
+    __syncthreads();
+    const double *lcol0 = a.len_t + (size_t)g * cm * SMM_BAND_ROW + 1;        // [c][k + 1] = len[k][c]: a state's lengths contiguous
+    int fg = 0, kmax = 0, aj = 0, tj = 0;
+    const double *hc = nullptr, *hh = nullptr;
+    double g0 = SMM_NEG_INF, cnl = 0.0, wgt = 0.0, sp_h = 0.0, sp_l = 0.0;
+    auto trip = [&](int n_, int to_) {
+        while (ju > 0 && n_ <= u_a(ju) + cv.ov) --ju;             // own parts: (a_j + OV, a_j + T_j], unit 0: (0, T_0]
+        aj = u_a(ju); tj = u_t(ju);
+        hc = u_cum(ju); hh = u_h(ju);
+        const double *hg = u_gam(ju);
+        fg = sh_guess[to_];
+        kmax = (kp - 1 < n_) ? kp - 1 : n_;
+        if (lane < C) {
+            g0 = hg[(size_t)(n_ - aj) * C + lane];
+            cnl = hc[(size_t)(n_ - aj) * C + lane];
+            wgt = (to_ == C) ? (endpen ? endpen[lane] : 0.0) : trans[(size_t)to_ * cm + lane];
+        }
+        const int kk0 = threadIdx.x + 1, kc = kk0 <= kmax ? kk0 : kmax;
+        sp_h = hh[(size_t)fg * (tj + 1) + (n_ - aj - kc)];
+        sp_l = lcol0[(size_t)fg * SMM_BAND_ROW + kc];
+    };
+    // (lane c keeps the global id of state c: a load of cmap[c] behind a trip's loads would wait for all of them)
+    const int64_t gid_l = cmap ? cmap[lane < C ? lane : C] : (int64_t)lane;
+    if (!sh_bad && n > 0) trip(n, to);
+    while (!sh_bad && n > 0) {
+        const double gmv = (lane < C) ? g0 + wgt : SMM_NEG_INF;
+        const bool nan_row = __ballot(lane < C && smm_nan_bits(gmv)) != 0;
+        const double rmax = smm_row_max16(gmv);
+        const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
+        double cmag = (lane < C) ? fabs(cnl) : 0.0;               // the magnitude of the prefix sums at n
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) cmag = fmax(cmag, __shfl_xor(cmag, off));
+        cmag = fmax(smm_readlane(cmag, 0), smm_readlane(cmag, 16));
+        const double tau = 0x1p-30 * (fabs(best) + cmag + 1.0);
+        // ONE state within tau of the maximum
+        const unsigned long long nearm = __ballot(lane < C && !(gmv < best - tau));
+        if (nan_row || __builtin_popcountll(nearm) != 1 || !smm_finite_bits(best)) { if (threadIdx.x == 0) sh_bad = (nan_row || !smm_finite_bits(best)) ? 16 : 4; break; }
+        const int c = __ffsll(nearm) - 1;
+        const double cn = smm_readlane(cnl, c), wf = smm_readlane(wgt, c);
+        // ... and ONE length: the candidate that equals the maximum, every other one below it by tau
+        const int kk = threadIdx.x + 1;
+        if (kk <= kmax) {
+            const double hv = (c == fg) ? sp_h : hh[(size_t)c * (tj + 1) + (n - aj - kk)];
+            const double lv = (c == fg) ? sp_l : lcol0[(size_t)c * SMM_BAND_ROW + kk];
+            const double cand = (cn + (hv + lv)) + wf;
+            if (cand == best) atomicMin(&sh_kmin, (unsigned)kk);
+            if (!(cand < best - tau)) atomicAdd(&sh_near, 1u);
+        }
+        __syncthreads();
+        const unsigned kf = sh_kmin, nn = sh_near;
+        __syncthreads();
+        if (threadIdx.x == 0) { sh_kmin = 0xffffffffu; sh_near = 0; }
+        if (kf == 0xffffffffu || nn != 1 || nseg >= SMM_STITCH_MAXSEG) { if (threadIdx.x == 0) sh_bad = nseg >= SMM_STITCH_MAXSEG ? 16 : 8; break; }
+        const int k = (int)kf, s = n - k;
+        if (threadIdx.x == 0) {
+            sh_seg_s[nseg] = s;
+            sh_seg_c[nseg] = c;
+            sh_guess[to] = c;
+        }
+        // what the score along the path needs of position n: cumE[n][c] (this segment's state) and cumE[n][to] (the next one's)
+        if (threadIdx.x == 1) { sh_cn[nseg] = cn; sh_ct[nseg] = (to < C) ? hc[(size_t)(n - aj) * C + to] : 0.0; }
+        const int n0 = n;
+        ++nseg;
+        n = s;
+        to = c;
+        __syncthreads();                                          // (the guess table: written by thread 0, read by every thread's trip)
+        if (n > 0) trip(n, to);                                   // the next segment's trip goes out in front of the stores
+        const int64_t gid = ((int64_t)__builtin_amdgcn_readlane((int)(gid_l >> 32), c) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)gid_l, c);
+        if (labels)
+            for (int f = s + threadIdx.x; f < n0; f += blockDim.x) labels[f] = gid;
+        if (threadIdx.x == 0 && spans) spans[s] = gid;
+    }
+    __syncthreads();
+    const bool bad = sh_bad != 0;
+
+    // ---------------------------------------------------------------------------------------------- the score, along the path
+    // segments were recorded last to first: segment i = (sh_seg_s[i], end = the start of segment i-1 or T, state sh_seg_c[i]).
+    // gamma[n][c] = cumE[n][c] + (h[s][c] + len[n-s][c]);  beta[n][to] = gamma[n][c] + trans[to][c];  h[n][to] = beta - cumE[n][to]
+    // (the table entries of every segment are fetched by as many threads at once; the chain itself is one thread's ~4 nseg
+    // dependent additions on LDS operands)
+    if (!bad) {
+        for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
+            const int s = sh_seg_s[i], c = sh_seg_c[i];
+            const int ne = (i == 0) ? T : sh_seg_s[i - 1];
+            sh_ln[i] = len[(size_t)(ne - s) * cm + c];
+            sh_tr[i] = (i > 0) ? trans[(size_t)sh_seg_c[i - 1] * cm + c] : (endpen ? endpen[c] : 0.0);
+        }
+        if (threadIdx.x == 0) sh_h0 = init[sh_seg_c[nseg - 1]];
+    }
+    __syncthreads();
+    if (!bad && threadIdx.x == 0) {
+        double h = sh_h0;
+        double gam = 0.0;
+        for (int i = nseg - 1; i >= 0; --i) {
+            gam = sh_cn[i] + (h + sh_ln[i]);
+            if (i > 0) h = (gam + sh_tr[i]) - sh_ct[i];
+        }
+        const double f = gam + sh_tr[0];
+        if (a.best) a.best[vid] = f;
+        if (spans) spans[T] = cmap ? cmap[C] : (int64_t)C;
+        if (a.n_segs) a.n_segs[vid] = nseg;
+    }
+    if (threadIdx.x == 0) {
+        redo[blockIdx.x] = bad ? 1 : 0;
+        atomicAdd(a.err + 4, 1);
+        if (bad) { atomicAdd(a.err + 5, 1); atomicOr(a.err + 6, sh_bad); }
+    }
+}
+
+void smm_launch_cum_anchors(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, double *anchors, hipStream_t stream)
+{
+    const size_t lds = sizeof(double) * (SMM_ANCH_WAVES * SMM_ANCH_ROWS + 2) * (size_t)a.c_max;
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_cum_anchor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(smm_cum_anchor_kernel, dim3(n_split), dim3(SMM_ANCH_WAVES * 64), lds, stream, a, cvs, anchors);
+}
+
+void smm_launch_chunk_stitch(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, int32_t *redo, hipStream_t stream)
+{
+    hipLaunchKernelGGL(smm_chunk_stitch_kernel, dim3(n_split), dim3(SMM_STITCH_THREADS), 0, stream, a, cvs, redo);
+}

@@ -24,7 +24,18 @@ struct SmmVideo {
     int32_t T;           // frames
     int32_t group;       // parameter group
     int32_t kp;          // usable segment lengths are 1..kp-1   (min(K, Tmax of the reference batch))
-    int32_t pad;         // (rounds 1-3: follower workgroups of a Viterbi gang)
+    int32_t pad;         // Viterbi, time-split videos (round 5, smm_viterbi.hip: CHUNK units): bit 0 = this entry is a unit (a
+                         // forward pass over part of a video: no closing step, no outputs), bit 1 = it starts from the guess
+                         // (not the video's first unit), bits 2.. = its first position within the parent video
+};
+
+#define SMM_CHUNK_MAX_UNITS 64   // units per time-split video (smm_chunk.hip)
+// One per time-split video: its units are videos[first_unit .. first_unit + n_chunks) of the extended array, in time order
+struct SmmChunkVideo {
+    int32_t vid;         // the parent video
+    int32_t first_unit;  // index into the extended SmmVideo array (>= b)
+    int32_t n_chunks;
+    int32_t ov;          // positions a unit runs before its own part begins (warm-up + kp - 1)
 };
 
 struct SmmDpArgs {
@@ -54,6 +65,9 @@ struct SmmDpArgs {
     const double *len_t;       // Viterbi BAND mode (flags bit 7, 128): [g][c_max][k_rows] state-major length table ...
     const double *band_tab;    // ... and [g][c_max][16] bounds of the band skip test (smm_viterbi.hip: smm_band_tables_kernel)
     const double *dmin_t;      // ... and [g][c_max][64] thresholds of the anchor test, minima over buckets of 16 distances (round 5: ANCHOR in the BAND pushers, -DSMM_ANCHOR=1 builds only)
+    const int32_t *redo;       // Viterbi, the repair launch of a time-split decode: [grid] 0 = this workgroup has nothing to do
+    const double *chunk_anchor;// Viterbi, time-split videos: [units][c_max] cumE at each unit's first position (smm_cum_anchor_kernel)
+    int32_t b_videos;          // ... and the number of real videos (units are entries b_videos.. of `videos`)
     int32_t bt_window;         // Viterbi, kp <= 64: positions per LDS window of the back-trace (0: the general back-trace) ...
     int32_t bt_dyn_bytes;      // ... and the dynamic LDS it needs: (3 W + c + kp) c doubles for the launch's largest c, kp
 };

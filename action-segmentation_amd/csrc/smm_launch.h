@@ -48,9 +48,14 @@ int smm_emission_bwd_chunk();
 void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
+int smm_launch_viterbi_repair(const SmmDpArgs &a, int c_need, hipStream_t stream);   // BAND mode (time-split decode: smm_chunk.hip)
 // Viterbi BAND mode: the state-major length table and the skip-test bounds of every (group, state) (smm_viterbi.hip)
 void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, double *dmin_t,
                             int n_groups, int cm, int k_rows, hipStream_t stream);
+// time-split Viterbi decode (smm_chunk.hip): serial prefix sums at the units' first positions; certification, back-trace and
+// outputs of the split videos (redo[i] = 1: video i of `cvs` has to be decoded again in one piece)
+void smm_launch_cum_anchors(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, double *anchors, hipStream_t stream);
+void smm_launch_chunk_stitch(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, int32_t *redo, hipStream_t stream);
 // tuning switches other translation units read (smm_api.hip: SmmEnv; read once, see smm_env_reload)
 int smm_env_fit_grid();        // SMM_FIT_GRID (0: default)
 int smm_env_emission_v2();     // SMM_EMISSION_V2 (-DSMM_DEV builds only)

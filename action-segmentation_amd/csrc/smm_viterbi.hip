@@ -347,7 +347,9 @@ __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double 
 // B   positions per hand-over block; D = 1: pushers lag one more source (see smm_ring_block); the chain wave evaluates
 //     lengths 1..2B+D-1 itself
 // BAND  BAND mode (above): one workgroup per video at K > 512, 128-slot rings, SPW = states per state-owning pusher wave (3..6)
-template <int R, int SPW, int NW, int HF, int B, int D = SMM_D, bool BAND = false>
+// TAG  1: the same kernel under a second name -- the repair launch of a time-split decode (smm_chunk.hip), kept apart from the
+//      launch it repairs in per-kernel statistics (it nearly always returns at once)
+template <int R, int SPW, int NW, int HF, int B, int D = SMM_D, bool BAND = false, int TAG = 0>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
@@ -384,9 +386,21 @@ smm_viterbi_kernel(SmmDpArgs a)
 #ifdef SMM_PROFILE
     const unsigned long long p_kern0 = __builtin_readcyclecounter();   // (diagnostic: phases of workgroup 0 -> slots 44..46)
 #endif
+    // (the repair launch of a time-split decode, smm_chunk_stitch_kernel below: one workgroup per split video, at work only
+    // where the stitch asked for the video to be decoded again in one piece)
+    if (a.redo && a.redo[blockIdx.x] == 0) return;
     const int vid = a.order[blockIdx.x];
     SmmVideo mv = a.videos[vid];
     if (a.flags & 8) mv.T -= 1;               // no EOS: the DP covers the frames before the last one (smmdp.h)
+    // CHUNK units (round 5; see smm_chunk_stitch_kernel): a long video cut along the TIME axis.  A unit is the forward pass
+    // over positions a0 .. a0 + T of its parent video, with its own history block; nothing else -- closing step, back-trace
+    // and every per-video output belong to the stitch kernel.  The first unit of a video starts like the video (a0 = 0);
+    // the others start from a GUESS, "a segment boundary at a0, every state equally good" (h[a0][c] = 0), which the
+    // recursion forgets within a segment or two (profiles/round5_rank_convergence.txt), and carry the SERIAL prefix sums on:
+    // cumE[a0][c] comes from smm_cum_anchor_kernel (the same additions in the same order as an unsplit decode makes), so the
+    // unit's cumE rows are the unsplit decode's, bit for bit.
+    const bool chunk = (mv.pad & 1) != 0, chunk_flat = (mv.pad & 2) != 0;
+    const double *anchor = chunk_flat ? a.chunk_anchor + (size_t)(vid - a.b_videos) * a.c_max : nullptr;
     const int T = mv.T;
     const int g = mv.group;
     const int C = a.n_states[g];
@@ -407,8 +421,8 @@ smm_viterbi_kernel(SmmDpArgs a)
     double *hh = hcum + (size_t)C * (T + 1);              // [C][T+1]  h[n][c], STATE-major: the back-trace scans one
                                                           // state's column over up to kp-1 positions per segment
     double *hgam = hh + (size_t)C * (T + 1);              // [T+1][C]  gamma[n][c]
-    int64_t *spans = a.spans ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
-    int64_t *labels = a.labels ? a.labels + mv.frame_off : nullptr;
+    int64_t *spans = (a.spans && !chunk) ? a.spans + (size_t)vid * (a.t_max + 1) : nullptr;
+    int64_t *labels = (a.labels && !chunk) ? a.labels + mv.frame_off : nullptr;
 
     // block q = positions qB+1 .. (q+1)B, buffer q & 1
     __shared__ __attribute__((aligned(16))) double sh_apart[2][B][SMM_MAX_STATES_DEV];   // A'[n][c]   pushers -> chain
@@ -448,15 +462,15 @@ smm_viterbi_kernel(SmmDpArgs a)
             sh_apart[1][i][c] = SMM_NEG_INF;
             sh_gh[0][i][c][0] = SMM_NEG_INF; sh_gh[0][i][c][1] = SMM_NEG_INF;
             sh_gh[1][i][c][0] = SMM_NEG_INF;
-            sh_gh[1][i][c][1] = (i == B - 1 && c < C) ? init[c] : SMM_NEG_INF;   // "block -1": only position 0 exists
+            sh_gh[1][i][c][1] = (i == B - 1 && c < C) ? (chunk_flat ? 0.0 : init[c]) : SMM_NEG_INF;   // "block -1": only position 0 exists
             sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)i * cm + c] : 0.0;    // block 0
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again; dead lanes of the chain wave read them)
         }
         sh_gam[c] = SMM_NEG_INF;
         sh_gfin[c] = SMM_NEG_INF;
         if (c < C) {                                                               // history of n = 0
-            hcum[c] = 0.0;
-            hh[(size_t)c * (T + 1)] = init[c];
+            hcum[c] = chunk_flat ? anchor[c] : 0.0;
+            hh[(size_t)c * (T + 1)] = chunk_flat ? 0.0 : init[c];
         }
     }
     constexpr bool SPEC = SMM_SPEC != 0;
@@ -541,7 +555,7 @@ smm_viterbi_kernel(SmmDpArgs a)
     //   * BAND mode: returns max h over the block's sources per state (lane = state, both halves), for the skip test.
     constexpr int PB = B / 2;                              // positions per half of the mover wave
     int mv_lo[NE];                                         // elp block element e = lane + 64 q  ->  LDS offset (row e / cm, column e % cm), -1: none
-    double mv_pre[NE], mv_cum = 0.0;
+    double mv_pre[NE], mv_cum = (chunk_flat && (lane & (SMM_MAX_STATES_DEV - 1)) < C) ? anchor[lane & (SMM_MAX_STATES_DEV - 1)] : 0.0;
     const int64_t e_last = (int64_t)T * cm - 1;
     if (w == MW) {
 #pragma unroll
@@ -630,8 +644,8 @@ smm_viterbi_kernel(SmmDpArgs a)
             double hq[M];                                     // h[n][to], slot n mod M
     #pragma unroll
             for (int i = 0; i < M; ++i) hq[i] = SMM_NEG_INF;
-            hq[0] = live ? init[to] : SMM_NEG_INF;
-            double cum = 0.0;
+            hq[0] = live ? (chunk_flat ? 0.0 : init[to]) : SMM_NEG_INF;
+            double cum = (chunk_flat && live) ? anchor[to] : 0.0;
             // every lane group computes every position; only group 0's results are wanted in LDS.  The other groups store
             // to a junk array of the same shape instead of being masked off: no exec juggling on the serial path (masking
             // measured slower: round 4, +8 % of the wave's busy time)
@@ -1408,6 +1422,7 @@ smm_viterbi_kernel(SmmDpArgs a)
         if (w == MW) (void)mover_step(J, J & 1, false);                       // the last block's history
     }
 
+    if (chunk) return;                        // a unit of a time-split video ends with its history (every wave gets here: no barrier follows)
     // -------------------------------------------------------------------------------- last position
     // sh_gfin holds gamma[T][.]; candidates fin[to], to = 0..C (C = EOS): first maximal entry wins.
     __syncthreads();
@@ -1787,6 +1802,7 @@ static int launch_if(const SmmDpArgs &a, int spw, int nw, int c_need, hipStream_
 
 // BAND mode (K > 512): 8 waves, six state-owning pusher waves with 3 states each up to 18 states, 4 up to 24, 5 up to 30,
 // 6 up to 32; HF = source states per lane group of the chain wave
+template <int TAG>
 static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 {
     const dim3 grid(a.b), block(512);
@@ -1796,14 +1812,14 @@ static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 #define SMM_DEV_BAND_SPW 4
 #define SMM_DEV_BAND_HF 12
 #endif
-    hipLaunchKernelGGL((smm_viterbi_kernel<16, SMM_DEV_BAND_SPW, 8, SMM_DEV_BAND_HF, 8, 0, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, SMM_DEV_BAND_SPW, 8, SMM_DEV_BAND_HF, 8, 0, true, TAG>), grid, block, 0, stream, a);
     return SMM_OK;
 #else
-    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 8, 0, true>), grid, block, 0, stream, a);
-    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 8, 0, true>), grid, block, 0, stream, a);
-    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 8, 0, true>), grid, block, 0, stream, a);
-    else if (c_need <= 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 8, 0, true>), grid, block, 0, stream, a);
-    else if (c_need <= 32) hipLaunchKernelGGL((smm_viterbi_kernel<16, 6, 8, 16, 8, 0, true>), grid, block, 0, stream, a);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 8, 0, true, TAG>), grid, block, 0, stream, a);
+    else if (c_need <= 18) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 12, 8, 0, true, TAG>), grid, block, 0, stream, a);
+    else if (c_need <= 24) hipLaunchKernelGGL((smm_viterbi_kernel<16, 4, 8, 12, 8, 0, true, TAG>), grid, block, 0, stream, a);
+    else if (c_need <= 30) hipLaunchKernelGGL((smm_viterbi_kernel<16, 5, 8, 16, 8, 0, true, TAG>), grid, block, 0, stream, a);
+    else if (c_need <= 32) hipLaunchKernelGGL((smm_viterbi_kernel<16, 6, 8, 16, 8, 0, true, TAG>), grid, block, 0, stream, a);
     else return SMM_ERR_UNSUPPORTED;
     return SMM_OK;
 #endif
@@ -1829,11 +1845,18 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
 }
 
+// The repair launch of a time-split decode (smm_chunk.hip): one workgroup per split video, at work only for the videos the
+// stitch could not certify -- the launch's own BAND configuration under its second name (TAG = 1)
+int smm_launch_viterbi_repair(const SmmDpArgs &a, int c_need, hipStream_t stream)
+{
+    return launch_band<1>(a, c_need, stream);
+}
+
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream)
 {
 #ifdef SMM_DEV_BAND_ONLY   // development builds: instantiate the BAND kernels only (quick compile-measure cycles)
     (void)r;
-    return launch_band(a, c_need, stream);
+    return launch_band<0>(a, c_need, stream);
 #else
     // SMM_DEV_R (development builds only): instantiate one ring size, for quick compile-measure cycles
 #ifndef SMM_DEV_R
@@ -1845,7 +1868,7 @@ int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream
     SMM_CASE_R(2)
     SMM_CASE_R(4)
     SMM_CASE_R(8)
-    case 16: if constexpr (SMM_DEV_R == 0 || SMM_DEV_R == 16) return launch_band(a, c_need, stream); else break;
+    case 16: if constexpr (SMM_DEV_R == 0 || SMM_DEV_R == 16) return launch_band<0>(a, c_need, stream); else break;
     default: break;
     }
 #undef SMM_CASE_R

@@ -340,7 +340,7 @@ def decode(batch, x, w, cst, inv_var, trans, init, len_scores, cons=None, endpen
         _dev(labels, torch.int64, 'labels'), _dev(best, f64, 'best'), _dev(n_segs, torch.int32, 'n_segs'),
         _dev(elp32, torch.float32, 'elp32'), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream()))
     if spans_on_host:
-        err = _pinned_small(('err', host_slot), dev, 4, torch.int32)
+        err = _pinned_small(('err', host_slot), dev, 8, torch.int32)
         err.copy_(_err_view(batch, ws), non_blocking=True)
     else:
         err = _err_copy(batch, ws)
@@ -419,11 +419,11 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 16].view(torch.int32)      # [error, 0, band-0 sources pushed, band-blocks evaluated]
+    return ws[off:off + 32].view(torch.int32)      # [error, 0, band-0 sources pushed, band-blocks evaluated, videos split in time, of those decoded again in one piece, 0, 0]
 
 
 def _err_copy(batch, ws):
-    """The launch's error words COPIED out of the workspace (12 bytes, stream-ordered behind the kernels, graph-capturable):
+    """The launch's error words COPIED out of the workspace (32 bytes, stream-ordered behind the kernels, graph-capturable):
     the per-stream workspace is shared, and the next launch on the stream re-stages it and zeroes these words."""
     # (an elementwise kernel, not clone(): torch copies device -> device with hipMemcpyAsync, and memset / memcpy nodes are
     # what replayed wrongly from a captured hipGraph on ROCm 7.2 -- tests/test_gpu_graph.py; kernel nodes replay correctly)
@@ -440,8 +440,9 @@ def error_flag(batch, out=None, ws=None):
 
 def error_words(batch, out=None, ws=None):
     """[error word, 0, sources pushed into band 0, delayed band-blocks evaluated (words 2 and 3: diagnostics of the Viterbi
-    kernel's BAND mode, smm_viterbi.hip: DOM and the band skip test)] of a decode (synchronises).  (Words 1 and 2 counted gang
-    time-outs in rounds 1-3.)"""
+    kernel's BAND mode, smm_viterbi.hip: DOM and the band skip test), videos decoded as several units along the time axis, of
+    those the ones that were decoded again in one piece (words 4 and 5: csrc/smm_chunk.hip), 0, 0] of a decode (synchronises).
+    (Words 1 and 2 counted gang time-outs in rounds 1-3.)"""
     if out is not None and out.get('_err') is not None:
         return [int(v) for v in out['_err'].tolist()]
     if ws is None:

@@ -349,6 +349,13 @@ def timed_decode(a, pc, world, want_events=True):
     if not empty:
         ops.check_decoded(pc.batch, last.get('out'))
         labels = labels.clone()       # (the pinned staging buffer is reused by the next decode)
+        # long videos decoded as several units along the time axis (csrc/smm_chunk.hip), and how many of them had to be decoded
+        # again in one piece, in the LAST timed step: error block words 4 and 5
+        words = ops.error_words(pc.batch, last.get('out'))
+        if dp is not None and len(words) > 5:
+            dp["time_split"] = {"videos_split": words[4], "of_those_decoded_again_in_one_piece": words[5],
+                                "why": [n for bit, n in ((1, "a cut did not certify"), (2, "closing step"), (4, "two states within the margin"),
+                                                         (8, "two lengths within the margin"), (16, "NaN / too many segments")) if words[6] & bit]}
     return dt, dp, labels
 
 
@@ -884,6 +891,7 @@ def main():
                          "note": "the DP is latency-bound, not HBM-bound: one serial chain per video (a few hundred cycles per "
                                  "position), and the launch lasts as long as its longest video; %.3g lattice cells per step, "
                                  "of which the BAND kernel evaluates the part its bound tests cannot exclude" % cells},
+            "time_split": dp.get("time_split"),
             "mof": float(counters[0] / counters[1]),
             "weak_scaling": dict(weak, scaling="weak", n_gpus=world,
                                  note="every rank decodes its own corpus of this size (seed + rank)"),

@@ -103,8 +103,21 @@ size_t smm_workspace_bytes(const smm_shape *shape, const int64_t *lengths_host);
  * some video and its decode stopped early.  It is cleared at the start of every call.  Returns 0 on invalid shape.
  * (The int32 word behind it is always 0: rounds 1-3 counted the time-outs of multi-workgroup "gangs" there, which no
  * longer exist; the third and fourth words are diagnostics of the Viterbi kernel's BAND mode: sources pushed into
- * band 0, delayed band-blocks evaluated.) */
+ * band 0, delayed band-blocks evaluated; the fifth and sixth count the videos a Viterbi call decoded as several units
+ * along the time axis and, of those, the ones it decoded again in one piece because a cut could not be certified or a
+ * decision was closer than rounding can tell -- the outputs are the one-piece decode's either way, see "Long videos"
+ * below.) */
 size_t smm_error_word_offset(const smm_shape *shape);
+
+/*
+ * Long videos (Viterbi entry points, EOS mode, span limit > 64).  The decode of one video is one serial chain over its
+ * frames; a launch whose CU-time is shorter than its longest video cuts that video along the TIME axis into units that
+ * run on different CUs, each warmed up on the frames in front of its own part, and stitches them: the cuts are certified
+ * against each other, every decision of the back-trace has to be clear of rounding, the best score is re-evaluated along
+ * the path in the one-piece decode's association -- and a video that fails any of it is decoded again in one piece by the
+ * same call (csrc/smm_chunk.hip).  spans / labels / best / n_segs are those of the one-piece decode, bit for bit; the
+ * workspace bound of smm_workspace_bytes covers it.  SMM_CHUNK=0 in the environment switches the splitting off.
+ */
 
 /*
  * Measurement aid (bench.py's roofline; not part of the reference's interface): while enabled, every launch of the

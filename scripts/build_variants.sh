@@ -8,7 +8,7 @@ while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   src=${SMM_VARIANT_SRC:-smm_viterbi}     # the translation unit that is recompiled (smm_viterbi, smm_logz, ...)
   ( hipcc $F ${SMM_VARIANT_FULL:--DSMM_DEV_BAND_ONLY} $flags -c -o _obj/${src}_$tag.o $src.hip &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsmmdp_$tag.so $(for u in smm_api smm_emission smm_viterbi smm_logz smm_logz_bwd smm_dense smm_eval smm_fit smm_tables; do [ $u != $src ] && echo _obj/$u.o; done) _obj/${src}_$tag.o && echo built $tag ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsmmdp_$tag.so $(for u in smm_api smm_emission smm_viterbi smm_chunk smm_logz smm_logz_bwd smm_dense smm_eval smm_fit smm_tables; do [ $u != $src ] && echo _obj/$u.o; done) _obj/${src}_$tag.o && echo built $tag ) &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done

@@ -32,7 +32,7 @@ struct SmmEnv {
     int plan_cache = 1;       // SMM_PLAN_CACHE=0: no resident plans
     int chunk = 1;            // SMM_CHUNK=0: no time-split decode of long videos (same results)
     int chunk_p = 0;          // SMM_CHUNK_P: positions per unit of a time-split decode (0: from the launch's CU-time; tests force small ones)
-    int chunk_wc = 512;       // SMM_CHUNK_WC: warm-up positions of a unit in front of the kp - 1 it is certified on
+    int chunk_wc = 512;       // SMM_CHUNK_WC: warm-up positions of a unit in front of the kp - 1 it is certified on (at most kp)
     int no_bt_window = 0;     // SMM_NO_BT_WINDOW=1: the general back-trace also for kp <= 64 (same results)
     int fit_grid = 0;         // SMM_FIT_GRID: workgroups of the class-sums kernel (tuning aid)
     int verbose = 0;          // SMM_VERBOSE
@@ -205,8 +205,8 @@ struct SmmPlan {
 
 // Upper bounds of a time-split plan (the workspace is sized before anything is planned): a unit's own part is never shorter
 // than SMM_CHUNK_LMIN positions, so a video of T frames has at most T / SMM_CHUNK_LMIN + 1 units
-constexpr int SMM_CHUNK_LMIN = 512;
-static size_t chunk_units_max(const smm_shape *s) { return (size_t)(s->total_frames / SMM_CHUNK_LMIN) + 2 * (size_t)s->b; }
+constexpr int SMM_CHUNK_LMIN = 512;                 // ... or 2 kp where that is less (kp > 64: at least 130)
+static size_t chunk_units_max(const smm_shape *s) { return (size_t)(s->total_frames / 128) + 2 * (size_t)s->b; }
 static size_t chunk_ext_meta_bytes(size_t b, size_t units, size_t n_cv)
 {
     return align_up(sizeof(SmmVideo) * (b + units), 256) + align_up(sizeof(int32_t) * (b + units), 256) +
@@ -597,10 +597,11 @@ struct ChunkPlan {
 static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out)
 {
     const SmmEnv &ev = env();
-    if (!ev.chunk || (s->flags & SMM_SHAPE_NO_EOS) || !band) return;             // (BAND-mode launches: the span limits long videos come with, and the repair launch's kernel)
+    if (!ev.chunk || (s->flags & SMM_SHAPE_NO_EOS) || kp_max <= 64) return;      // (kp <= 64: the window back-trace's launches are left alone)
     const int n_cu = device_cus();
     if (n_cu <= 0) return;
-    auto ns = [&](int c) { return smm_band_frame_ns(c); };
+    // (the ring kernels, span limits up to 512: cfg2's 16 states at K = 256 take 199 ns per frame; BAND mode: the library's model)
+    auto ns = [&](int c) { return band ? smm_band_frame_ns(c) : 150.0 + 3.0 * c; };
     double t_cu = 0.0, t_long = 0.0;
     for (int i = 0; i < s->b; ++i) {
         const double t = (double)hv[i].T * ns(n_states[hv[i].group]);
@@ -619,8 +620,9 @@ static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n
     const size_t units_cap = chunk_units_max(s);
     for (int i = 0; i < s->b; ++i) {
         const int T = hv[i].T, C = n_states[hv[i].group], kpv = hv[i].kp;
-        const int ov = std::max(ev.chunk_wc, 16) + kpv - 1;
-        const int lmin = std::max(kpv - 1, SMM_CHUNK_LMIN);
+        // warm-up: the recursion forgets its start behind the next segment boundary, and a segment is shorter than kp
+        const int ov = std::max(std::min(ev.chunk_wc, kpv), 16) + kpv - 1;
+        const int lmin = std::max(kpv - 1, std::min(SMM_CHUNK_LMIN, 2 * kpv));
         const int pmin = ov + lmin;
         // positions per unit: what the launch's CU-time lasts on this video's state count (+ 10 %), at least pmin
         int P = ev.chunk_p > 0 ? ev.chunk_p : (int)(1.1 * t_cu / ns(C));
@@ -954,7 +956,10 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
         ar.order = st.porder;
         ar.b = st.n_cv;
         ar.redo = st.redo;
-        const int rc2 = smm_launch_viterbi_repair(ar, st.c_need, stream);
+        // (BAND mode: the launch's own kernel under its second name, so that per-kernel statistics of the DP launch are not
+        // diluted by a launch that nearly always returns at once; the ring kernels repair with themselves)
+        const int rc2 = st.band_mode ? smm_launch_viterbi_repair(ar, st.c_need, stream)
+                                     : smm_launch_viterbi(ar, ring_regs(st.kp_max), st.c_need, stream);
         if (rc2 != SMM_OK) return rc2;
     }
     SMM_HIP(hipGetLastError());

@@ -303,7 +303,11 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         sh_guess[t2] = bi;
     }
     __syncthreads();
-    const double *lcol0 = a.len_t + (size_t)g * cm * SMM_BAND_ROW + 1;        // [c][k + 1] = len[k][c]: a state's lengths contiguous
+    // BAND-mode launches carry the state-major length table ([c][k + 1] = len[k][c]: a state's lengths contiguous); the ring
+    // kernels' launches (span limits up to 512) read the [k][c] table, one cache line per candidate
+    const bool band = (a.flags & 128) != 0;
+    const double *lcol0 = band ? a.len_t + (size_t)g * cm * SMM_BAND_ROW + 1 : nullptr;
+    auto len_of = [&](int c_, int k_) { return band ? lcol0[(size_t)c_ * SMM_BAND_ROW + k_] : len[(size_t)k_ * cm + c_]; };
     int fg = 0, kmax = 0, aj = 0, tj = 0;
     const double *hc = nullptr, *hh = nullptr;
     double g0 = SMM_NEG_INF, cnl = 0.0, wgt = 0.0, sp_h = 0.0, sp_l = 0.0;
@@ -321,7 +325,7 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         }
         const int kk0 = threadIdx.x + 1, kc = kk0 <= kmax ? kk0 : kmax;
         sp_h = hh[(size_t)fg * (tj + 1) + (n_ - aj - kc)];
-        sp_l = lcol0[(size_t)fg * SMM_BAND_ROW + kc];
+        sp_l = len_of(fg, kc);
     };
     // (lane c keeps the global id of state c: a load of cmap[c] behind a trip's loads would wait for all of them)
     const int64_t gid_l = cmap ? cmap[lane < C ? lane : C] : (int64_t)lane;
@@ -345,7 +349,7 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         const int kk = threadIdx.x + 1;
         if (kk <= kmax) {
             const double hv = (c == fg) ? sp_h : hh[(size_t)c * (tj + 1) + (n - aj - kk)];
-            const double lv = (c == fg) ? sp_l : lcol0[(size_t)c * SMM_BAND_ROW + kk];
+            const double lv = (c == fg) ? sp_l : len_of(c, kk);
             const double cand = (cn + (hv + lv)) + wf;
             if (cand == best) atomicMin(&sh_kmin, (unsigned)kk);
             if (!(cand < best - tau)) atomicAdd(&sh_near, 1u);

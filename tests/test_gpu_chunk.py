@@ -77,11 +77,30 @@ def test_time_split_decode_repairs_what_it_cannot_certify(kind, monkeypatch):
         assert out['_err'][5] == 2, out['_err']          # exact ties everywhere: never clear of the margin
 
 
-def test_span_limits_up_to_512_are_not_split(monkeypatch):
-    """The ring kernels (span limits up to 512) are left alone: the split and its repair launch live in BAND mode."""
+def test_time_split_decode_on_the_ring_kernels(monkeypatch):
+    """Span limits up to 512 (the ring kernels, no BAND mode): the same units, the same stitch, the [k][c] length table;
+    span limits up to 64 (the window back-trace's launches) are left alone."""
     p = tv.structured_problem(21, [3000, 2900, 700], 16, 256, rate=(10, 120))
     out = decode_split_and_whole(p, monkeypatch, unit=1)
+    assert out['_err'][4] == 2 and out['_err'][5] == 0, out['_err']
+    p = tv.structured_problem(22, [2500, 2400], 9, 400, rate=(10, 200))
+    out = decode_split_and_whole(p, monkeypatch, unit=1)
+    assert out['_err'][4] == 2, out['_err']
+    p = tv.structured_problem(23, [1500, 1400], 12, 40, rate=(4, 20))
+    out = decode_split_and_whole(p, monkeypatch, unit=1)
     assert out['_err'][4] == 0 and out['_err'][5] == 0, out['_err']
+
+
+def test_cfg2_batch_of_64_is_split_by_default(monkeypatch):
+    """BASELINE configs[1] (64 videos x 2048 frames, 16 states, K = 256): 64 one-CU videos on 256 CUs -- the planner cuts each
+    into units and the outputs stay the C twin's."""
+    monkeypatch.delenv('SMM_CHUNK', raising=False)
+    monkeypatch.delenv('SMM_CHUNK_P', raising=False)
+    cp = make_corpus(2, [2048] * 64, 16, 256, rate=(20, 200))
+    res = decode_both(cp)
+    check_equivalent(cp, *res)
+    err = res[0]['_err'].cpu().numpy()
+    assert err[4] == 64, err
 
 
 def test_a_short_warm_up_fails_the_certificate_not_the_decode(monkeypatch):

@@ -60,6 +60,19 @@ def padding_colate(samples):
     return batch
 
 
+def ragged_colate(samples):
+    """``padding_colate`` without the padding: ``features_list`` (and ``gt_single_list``) keep the per-video tensors as they
+    are -- what ``SemiMarkovModel.predict(fused=False)`` hands to ``SemiMarkovModule.decode_ragged_launch`` (the decode
+    kernels take a packed frame axis: the zero-padded b x Tmax x D layout is a copy the reference's torch ops needed, not
+    the DP).  Single-task batches without narration constraints only."""
+    samples = [s for s in samples if s is not None]
+    keys = samples[0].keys()
+    batch = {k: [s[k] for s in samples] for k in keys if k in NOPAD_KEYS}
+    batch['lengths'] = torch.LongTensor([s['features'].size(0) for s in samples])
+    batch['features_list'] = [s['features'] for s in samples]
+    return batch
+
+
 class BatchSampler(Sampler):
     """Consecutive chunks of the name-sorted videos of one task (corpus.py:613-644)."""
 
@@ -108,7 +121,7 @@ def batch_cost(datasplit, keys, max_k):
     return cost
 
 
-def make_data_loader(args, datasplit, shuffle, batch_by_task, batch_size=1, shard=None):
+def make_data_loader(args, datasplit, shuffle, batch_by_task, batch_size=1, shard=None, ragged=False):
     """``shard=(rank, world)``: keep only this rank's share of the batches (whole single-task batches, so the one
     batch-dependent quantity of the reference -- K clipped to the batch's padded length -- is unchanged; greedy
     longest-processing-time assignment on the DP work, the same on every rank without communication)."""
@@ -119,7 +132,7 @@ def make_data_loader(args, datasplit, shuffle, batch_by_task, batch_size=1, shar
         max_k = getattr(args, 'sm_max_span_length', None) or 1
         costs = [batch_cost(datasplit, keys, max_k) for keys in sampler.batches]
         sampler.batches = [sampler.batches[i] for i in shard_batches(sampler.batches, costs, shard[0], shard[1])]
-    return DataLoader(datasplit, num_workers=getattr(args, 'workers', 0), collate_fn=padding_colate,
+    return DataLoader(datasplit, num_workers=getattr(args, 'workers', 0), collate_fn=ragged_colate if ragged else padding_colate,
                       batch_sampler=sampler)
 
 

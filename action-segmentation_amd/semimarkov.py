@@ -344,6 +344,7 @@ class SemiMarkovModel(object):
         # buffer that is OURS until the caller drops the result (ops.lease_host_labels): no copy out of a staging buffer ...
         dev = pc.device or pc.x.device
         lease = ops.lease_host_labels(pc.batch, dev) if dev.type == 'cuda' else None   # (no GPU: decode_packed says so, loudly)
+        self.last_predict_path = 'fused: ' + ('leased pinned label buffer' if lease is not None else 'shared staging buffer + copy')
         if lease is not None:
             out = self.model.decode_packed(pc, want_spans=False, want_labels=True, labels_out=lease)
             torch.cuda.current_stream().synchronize()
@@ -480,9 +481,14 @@ class SemiMarkovModel(object):
         if fused:
             return self.predict_packed(self.prepare(test_data, shard=shard))
         predictions = {}
-        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
-                                  shard=shard)
         cons_fn = self._test_constraints(test_data)
+        # round 5: without narration constraints the loop skips the padded layout and the span encoding altogether -- the
+        # videos' own feature tensors are concatenated (one gather) and the kernel's frame labels are the predictions
+        # (SemiMarkovModule.decode_ragged_launch); with constraints it is the reference's padded batch and viterbi()
+        ragged = cons_fn is None and torch.device(self.device).type == 'cuda'
+        loader = make_data_loader(self.args, test_data, shuffle=False, batch_by_task=True, batch_size=self.args.batch_size,
+                                  shard=shard, ragged=ragged)
+        self.last_predict_path = 'per batch, ragged: kernel labels in pinned memory' if ragged else 'per batch, padded: viterbi() spans'
 
         depth = max(1, int(getattr(self.args, 'decode_depth', self.DECODE_DEPTH)))
         streams = self.__dict__.setdefault('_decode_streams', {})
@@ -494,6 +500,12 @@ class SemiMarkovModel(object):
         def launch(batch, slot):
             tasks = batch['task_name']
             assert len(set(tasks)) == 1
+            if ragged:
+                feats = [f.to(self.device) for f in batch['features_list']]
+                lengths = batch['lengths']
+                addl = self.make_additional_allowed_ends(tasks, lengths)
+                return self.model.decode_ragged_launch(feats, lengths, batch['task_indices'], addl, slot=slot,
+                                                       stream=streams[key][slot] if int(lengths.max()) >= self.STREAM_MIN_FRAMES else None)
             features, lengths = batch['features'].to(self.device), batch['lengths']
             cons = cons_fn(batch) if cons_fn else None
             addl = self.make_additional_allowed_ends(tasks, lengths)
@@ -502,6 +514,11 @@ class SemiMarkovModel(object):
                                              stream=streams[key][slot] if features.size(1) >= self.STREAM_MIN_FRAMES else None)
 
         def finish(batch, pending):
+            if ragged:
+                for video, seq in zip(batch['video_name'], pending()):
+                    predictions[video] = seq.copy()               # (the pinned slot is reused by a later launch)
+                    assert predictions[video].size == 0 or predictions[video].max() < self.model.n_classes, "predictions should not contain EOS"
+                return
             pred_labels = semimarkov_utils.spans_to_labels(pending())
             for video, seq in zip(batch['video_name'], self.model.trim(pred_labels, batch['lengths'], check_eos=True)):
                 predictions[video] = seq.numpy()

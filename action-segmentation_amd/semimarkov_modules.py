@@ -557,6 +557,56 @@ class SemiMarkovModule(nn.Module):
 
     viterbi_decode = viterbi   # name used by BASELINE.json's north star
 
+    def decode_ragged_launch(self, feature_list, lengths, valid_classes_per_instance, additional_allowed_ends_per_instance=None,
+                             slot=0, stream=None):
+        """One single-task batch of the reference's call pattern WITHOUT its padded layout (round 5): ``feature_list`` holds
+        the videos' own T_i x D device tensors, the decode runs on their concatenation (one gather instead of ``pad_sequence``'s
+        zero fill + b copies) and hands back FRAME LABELS -- what ``predict`` makes of ``viterbi``'s spans with
+        ``spans_to_labels`` + ``trim`` (reference semimarkov.py:397-409) is what the DP kernel writes anyway.  The batch keeps
+        its one batch-dependent quantity, K clipped to its longest video (:450-452).  Returns at once; calling the result
+        waits and gives the list of int64 numpy label arrays (views of a pinned buffer that the next launch with the same
+        ``slot`` reuses: copy what you keep).  ``stream``: as in ``viterbi_launch``."""
+        x0 = feature_list[0]
+        self._require_device(x0, 'decode_ragged_launch')
+        valid_classes = self._check_valid_classes(valid_classes_per_instance)
+        dev = x0.device
+        lengths_host = lengths.detach().cpu().numpy().astype(np.int64)
+        b, d, tmax, total = len(feature_list), x0.size(1), int(lengths_host.max()), int(lengths_host.sum())
+        ctx = contextlib.nullcontext()
+        if stream is not None:
+            self._decode_tables(valid_classes, dev)           # (built on the caller's stream: see viterbi_launch)
+            stream.wait_stream(torch.cuda.current_stream(dev))
+            ctx = torch.cuda.stream(stream)
+        with ctx:
+            self.kl = torch.zeros(b, device=dev)
+            tab = self._decode_tables(valid_classes, dev)
+            c = tab['init'].numel()
+            off = np.concatenate([[0], np.cumsum(lengths_host)[:-1]])
+            batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=total, d=d,
+                              frame_offset=off, kp=[min(tab['len'].size(0), tmax)] * b)
+            x = torch.cat([f.detach().to(torch.float32) for f in feature_list]) if b > 1 else x0.detach().to(torch.float32).contiguous()
+            endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
+            g1 = tab.get('_one_group')
+            if g1 is None:
+                g1 = tab['_one_group'] = tuple(tab[k].unsqueeze(0).contiguous() for k in ('w', 'cst', 'trans', 'init', 'len')) \
+                    + (tab['class_map'].view(1, -1),)
+            labels = ops.pinned_labels(('ragged', slot), dev, total)
+            out = ops.decode(batch, x, g1[0], g1[1], tab['inv_var'], g1[2], g1[3], g1[4], endpen=endpen, class_map=g1[5],
+                             want_spans=False, want_labels=True, labels_out=labels, spans_on_host=True, host_slot=('ragged', slot))
+            out['_keep'] = (tab, g1, endpen, x)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        if stream is not None:
+            for f in feature_list:
+                f.record_stream(stream)
+
+        def result():
+            done.synchronize()
+            ops.check_decoded(batch, out)
+            lab = labels.numpy()
+            return [lab[o:o + t] for o, t in zip(off.tolist(), lengths_host.tolist())]
+        return result
+
     @staticmethod
     def _check_no_eos_lengths(lengths_host, no_eos):
         if no_eos and int(lengths_host.min()) < 2:
@@ -749,6 +799,18 @@ class SemiMarkovModule(nn.Module):
         if pc.tables is None:
             self.prepare_packed(pc)
         t = pc.tables
+        if want_labels and not want_spans and not want_elp:
+            # the common call -- frame labels of a resident corpus -- with its arguments marshalled once (ops.ResidentDecode);
+            # rebuilt when the tables were (a parameter update) or the features moved (predict_host's device buffers)
+            args = (x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'], pc.cons, pc.endpen, t['class_map'])
+            key = tuple(None if a is None else (a.data_ptr(), a._version) for a in args)
+            calls = pc.__dict__.setdefault('_resident_calls', {})
+            call = calls.get(x.data_ptr())
+            if call is None or call.key != key:
+                if len(calls) > 4:
+                    calls.clear()
+                call = calls[x.data_ptr()] = ops.ResidentDecode(pc.batch, *args[:7], cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'])
+            return call(labels_on_host=labels_on_host, labels_out=labels_out)
         return ops.decode(pc.batch, x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
                           cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'], want_spans=want_spans,
                           want_labels=want_labels, want_elp=want_elp, labels_on_host=labels_on_host, labels_out=labels_out)

@@ -298,9 +298,13 @@ def timed_decode(a, pc, world, want_events=True):
         """One decode pass through the product's entry point (smm_decode_f32): emission -> DP -> labels on the host."""
         if empty:
             return torch.zeros(0, dtype=torch.int64)
-        out = ops.decode(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'], cons=pc.cons,
-                         endpen=pc.endpen, class_map=t['class_map'], want_spans=False, want_labels=True,
-                         labels_on_host=not a.labels_via_copy)
+        # (smm_decode_f32 through ops.ResidentDecode, as SemiMarkovModule.decode_packed calls it: the fixed arguments of the
+        # call are marshalled once per corpus)
+        call = last.get('call')
+        if call is None:
+            call = last['call'] = ops.ResidentDecode(pc.batch, pc.x, t['w'], t['cst'], t['inv_var'], t['trans'], t['init'], t['len'],
+                                                     cons=pc.cons, endpen=pc.endpen, class_map=t['class_map'])
+        out = call(labels_on_host=not a.labels_via_copy)
         last['out'] = out
         if a.labels_via_copy:
             return ops.to_host(out['labels'])
@@ -444,7 +448,7 @@ def predict_end_to_end(model, data):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         frames = sum(len(v) for v in preds.values())
-        return {"ms": best * 1e3, "frames_per_s": frames / best}
+        return {"ms": best * 1e3, "frames_per_s": frames / best, "label_path": getattr(model, 'last_predict_path', None)}
 
     model.__dict__.pop('_prepared', None)
     model.predict(data.subset(1))                        # warm-up of workspaces / table cache on another datasplit
@@ -454,8 +458,10 @@ def predict_end_to_end(model, data):
     out['per_batch'] = timed(False)
     out["what"] = ("SemiMarkovModel.predict(test_data) wall time, all host work included: 'fused_first_call' collates, "
                    "packs and uploads the datasplit, 'fused' finds it resident (the per-epoch decode of the training "
-                   "loop, main.py:207-244); 'per_batch' = the reference's call pattern, one viterbi() per single-task "
-                   "batch (semimarkov.py:318-410)")
+                   "loop, main.py:207-244); 'per_batch' = the reference's call pattern, one decode per single-task "
+                   "batch (semimarkov.py:318-410); label_path: which way the labels took (fused: a leased pinned buffer or "
+                   "the shared staging buffer + a copy; per batch: the ragged launch's kernel labels, or -- with narration "
+                   "constraints -- the padded batch through viterbi() and spans_to_labels on the host)")
     return out
 
 

@@ -30,6 +30,7 @@ class SmmTablesShape(ctypes.Structure):
 
 SHAPE_NO_EOS = 1
 SHAPE_LOGZ_BOTH = 2
+SHAPE_NO_TIME_SPLIT = 4
 
 
 class SmmEvalShape(ctypes.Structure):

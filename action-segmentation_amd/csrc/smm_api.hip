@@ -597,7 +597,7 @@ struct ChunkPlan {
 static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out)
 {
     const SmmEnv &ev = env();
-    if (!ev.chunk || (s->flags & SMM_SHAPE_NO_EOS) || kp_max <= 64) return;      // (kp <= 64: the window back-trace's launches are left alone)
+    if (!ev.chunk || (s->flags & (SMM_SHAPE_NO_EOS | SMM_SHAPE_NO_TIME_SPLIT)) || kp_max <= 64) return;      // (kp <= 64: the window back-trace's launches are left alone)
     const int n_cu = device_cus();
     if (n_cu <= 0) return;
     // (the ring kernels, span limits up to 512: cfg2's 16 states at K = 256 take 199 ns per frame; BAND mode: the library's model)

@@ -21,10 +21,12 @@ class Batch:
     kp             per-video min(K, Tmax of its reference batch) (reference semimarkov_modules.py:450-452)
     n_states       states per group
     no_eos         add_eos=False of the reference: no EOS label, the last frame's label only emits
+    no_time_split  the tables carry hard masks (ordering constraints): long videos are decoded in one piece
+                   (include/smmdp.h: SMM_SHAPE_NO_TIME_SPLIT)
     """
 
     def __init__(self, lengths, n_states, k_rows, c_max=None, frame_offset=None, group=None, kp=None, d=0,
-                 t_max=None, total_frames=None, no_eos=False):
+                 t_max=None, total_frames=None, no_eos=False, no_time_split=False):
         self.lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64).reshape(-1))
         self.b = int(self.lengths.shape[0])
         self.n_states = np.ascontiguousarray(np.asarray(n_states, dtype=np.int32).reshape(-1))
@@ -43,7 +45,8 @@ class Batch:
         self.d = int(d)
         self.no_eos = bool(no_eos)     # add_eos=False of the reference (include/smmdp.h: SMM_SHAPE_NO_EOS)
         self.shape = SmmShape(self.b, self.d, self.n_groups, self.c_max, self.k_rows, self.t_max,
-                              _lib.SHAPE_NO_EOS if self.no_eos else 0, self.total_frames)
+                              (_lib.SHAPE_NO_EOS if self.no_eos else 0) | (_lib.SHAPE_NO_TIME_SPLIT if no_time_split else 0),
+                              self.total_frames)
 
     def workspace_bytes(self):
         n = _lib.load().smm_workspace_bytes(ctypes.byref(self.shape), self.lengths.ctypes.data)

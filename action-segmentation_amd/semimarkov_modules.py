@@ -452,6 +452,13 @@ class SemiMarkovModule(nn.Module):
             cache[key] = tab
         return tab
 
+    def _hard_masks(self):
+        """The tables carry -1e9 masks (--sm_constrain_transitions: allowed starts / transitions / ends): decodes ask the library
+        not to split long videos along the time axis -- a unit that starts mid-video from a uniform guess ignores the masks'
+        history and would not certify against the one-piece decode (profiles/round5_time_split.txt: cfg4)."""
+        return (getattr(self, 'init_constraints', None) is not None or getattr(self, 'transition_constraints', None) is not None
+                or self.allowed_ends is not None)
+
     def _param_key(self):
         """Identity + version of the five parameters: any in-place update changes it."""
         return tuple((p.data_ptr(), p._version) for p in (self.poisson_log_rates, self.gaussian_means, self.gaussian_cov,
@@ -583,7 +590,7 @@ class SemiMarkovModule(nn.Module):
             c = tab['init'].numel()
             off = np.concatenate([[0], np.cumsum(lengths_host)[:-1]])
             batch = ops.Batch(lengths_host, [c], tab['len'].size(0), c_max=c, t_max=tmax, total_frames=total, d=d,
-                              frame_offset=off, kp=[min(tab['len'].size(0), tmax)] * b)
+                              frame_offset=off, kp=[min(tab['len'].size(0), tmax)] * b, no_time_split=self._hard_masks())
             x = torch.cat([f.detach().to(torch.float32) for f in feature_list]) if b > 1 else x0.detach().to(torch.float32).contiguous()
             endpen = self._endpen(valid_classes, additional_allowed_ends_per_instance, b, c, dev)
             g1 = tab.get('_one_group')
@@ -623,7 +630,8 @@ class SemiMarkovModule(nn.Module):
         tab = self._decode_tables(valid_classes, dev)
         c = tab['init'].numel()
         k_rows = tab['len'].size(0)
-        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos)
+        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos,
+                          no_time_split=self._hard_masks())
         x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
         cons = None
         if constraints is not None:
@@ -784,7 +792,7 @@ class SemiMarkovModule(nn.Module):
                     cons[o:o + pc.lengths[i], :cl.size(1)] = cl.to(device=dev, dtype=torch.float32)
             pc.cons = cons
         pc.batch = ops.Batch(pc.lengths, n_states, k_rows, c_max=cm, frame_offset=pc.frame_offset, group=pc.group,
-                             kp=pc.kp, d=d, total_frames=pc.x.size(0))
+                             kp=pc.kp, d=d, total_frames=pc.x.size(0), no_time_split=self._hard_masks())
         pc._static = (cm, k_rows, id(self))
         return pc
 
@@ -901,7 +909,8 @@ class SemiMarkovModule(nn.Module):
             c, k_rows = tab['init'].numel(), tab['len'].size(0)
             st = {n: tab[n].unsqueeze(0).contiguous() for n in ('w', 'cst', 'trans', 'init', 'len')}
             st['inv_var'] = tab['inv_var'].contiguous()
-        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos)
+        batch = ops.Batch(lengths_host, [c], k_rows, c_max=c, t_max=tmax, total_frames=b * tmax, d=d, no_eos=no_eos,
+                          no_time_split=self._hard_masks())
         x = features.detach().to(torch.float32).contiguous().view(b * tmax, d)
         cons = None
         if constraints is not None:

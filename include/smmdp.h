@@ -87,6 +87,11 @@ typedef struct smm_shape {
  * launch, one extra workgroup per video.  The two directions are independent, so a batch that does not fill the GPU
  * gets its gradient's DP for free; pass the same flag to smm_logz_bwd_f64, which then skips its own reversed run. */
 #define SMM_SHAPE_LOGZ_BOTH 2
+/* Viterbi entry points: never split a video along the time axis ("Long videos" below).  For callers that know their tables
+ * carry hard masks (ordering constraints: transitions / initial states / ends at -1e9): a unit that starts in the middle of
+ * such a video from "every state equally good" reaches states the masks forbid there, its cuts do not certify, and every
+ * split video would be decoded a second time in one piece -- correct as ever, and slower than not splitting. */
+#define SMM_SHAPE_NO_TIME_SPLIT 4
 
 const char *smm_strerror(int status);
 int smm_last_hip_error(void);

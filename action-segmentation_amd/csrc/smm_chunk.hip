@@ -23,8 +23,12 @@
 //             included (there is no tie).  The path is the unsplit decode's path.
 //   score     the best score is re-evaluated along that path in the unsplit decode's association (cumE rows are its
 //             bits; h along the path is add, add, add, sub per segment): the unsplit decode's number.
-//   repair    a cut that does not certify, a decision inside tau (an exact tie on an integer lattice, a boundary that
-//             rounding decides), a NaN: the video's word in `redo` is set and the launch that follows decodes it again
+//   ties      two lengths within tau at the end of a run of ONE class that is decoded as two spans -- the (k2, k1) / (k1, k2)
+//             orders of the same run, equal up to rounding -- are resolved, not repaired: both orders are verified, and the
+//             score pass, which has the exact h in front of the run, evaluates both rounded candidates and takes the
+//             one-piece decode's choice.
+//   repair    a cut that does not certify, any other decision inside tau (an exact tie on an integer lattice, a boundary
+//             that rounding decides), a NaN: the video's word in `redo` is set and the launch that follows decodes it again
 //             in one piece with the ordinary kernel (one workgroup per split video, all but the flagged ones return at
 //             once).  Correctness never rests on the split; only the time does.
 //
@@ -140,7 +144,7 @@ __device__ __forceinline__ bool smm_finite_bits(double x)
 }
 
 // one workgroup per split video (see the head of this file).  Error block word 4 counts the split videos, word 5 the ones
-// handed to the repair launch (ops.error_words).
+// handed to the repair launch, word 6 ORs the reasons, word 7 counts the one-class-run ties resolved (ops.error_words).
 __global__ void __launch_bounds__(SMM_STITCH_THREADS)
 smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
 {
@@ -162,7 +166,9 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
 
     __shared__ int sh_bad;
     __shared__ double sh_dref;
-    __shared__ unsigned sh_kmin, sh_near;
+    __shared__ unsigned sh_kmin, sh_near, sh_nlo, sh_nhi;
+    __shared__ int sh_tie_s2[SMM_STITCH_MAXSEG];
+    __shared__ double sh_tie_c2[SMM_STITCH_MAXSEG];
     __shared__ int sh_guess[SMM_MAX_STATES_DEV + 1];
     __shared__ int sh_ua[SMM_CHUNK_MAX_UNITS], sh_ut[SMM_CHUNK_MAX_UNITS];
     __shared__ long long sh_uoff[SMM_CHUNK_MAX_UNITS];
@@ -172,7 +178,7 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
     __shared__ double sh_ln[SMM_STITCH_MAXSEG], sh_tr[SMM_STITCH_MAXSEG];   // ... their length scores and the transitions behind them
     __shared__ double sh_h0;
 
-    if (threadIdx.x == 0) { sh_bad = 0; sh_kmin = 0xffffffffu; sh_near = 0; }
+    if (threadIdx.x == 0) { sh_bad = 0; sh_kmin = 0xffffffffu; sh_near = 0; sh_nlo = 0xffffffffu; sh_nhi = 0; }
     // (sh_bad: WHY the video goes to the repair launch -- 1 a cut does not certify, 2 the closing step, 4 two states within tau,
     // 8 two lengths within tau / none attains the maximum, 16 NaN or too many segments; OR-ed into error block word 6)
     if (spans)
@@ -312,7 +318,10 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
     const double *hc = nullptr, *hh = nullptr;
     double g0 = SMM_NEG_INF, cnl = 0.0, wgt = 0.0, sp_h = 0.0, sp_l = 0.0;
     auto trip = [&](int n_, int to_) {
-        while (ju > 0 && n_ <= u_a(ju) + cv.ov) --ju;             // own parts: (a_j + OV, a_j + T_j], unit 0: (0, T_0]
+        // the unit whose own part holds n_: (a_j + OV, a_j + T_j], unit 0: (0, T_0]  (the walk goes down; the look-aside of a
+        // tie, below, may have left ju too low)
+        while (ju < nu - 1 && n_ > u_a(ju) + u_t(ju)) ++ju;
+        while (ju > 0 && n_ <= u_a(ju) + cv.ov) --ju;
         aj = u_a(ju); tj = u_t(ju);
         hc = u_cum(ju); hh = u_h(ju);
         const double *hg = u_gam(ju);
@@ -327,42 +336,95 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         sp_h = hh[(size_t)fg * (tj + 1) + (n_ - aj - kc)];
         sp_l = len_of(fg, kc);
     };
-    // (lane c keeps the global id of state c: a load of cmap[c] behind a trip's loads would wait for all of them)
-    const int64_t gid_l = cmap ? cmap[lane < C ? lane : C] : (int64_t)lane;
-    if (!sh_bad && n > 0) trip(n, to);
-    while (!sh_bad && n > 0) {
+    // One decision from what the last trip brought: the state and the length(s) within tau of the maximum.
+    //   status 1  one state, ONE length: the one-piece decode decides the same
+    //   status 2  one state, TWO lengths k1 < k2 within tau (one of them equals the maximum): a tie candidate, see below
+    //   status 0  anything else (reason in sh_bad)
+    int d_c = 0, d_k1 = 0, d_k2 = 0;
+    double d_cn = 0.0;
+    auto decide = [&](int n_) -> int {
         const double gmv = (lane < C) ? g0 + wgt : SMM_NEG_INF;
         const bool nan_row = __ballot(lane < C && smm_nan_bits(gmv)) != 0;
         const double rmax = smm_row_max16(gmv);
         const double best = fmax(smm_readlane(rmax, 0), smm_readlane(rmax, 16));
-        double cmag = (lane < C) ? fabs(cnl) : 0.0;               // the magnitude of the prefix sums at n
+        double cmag = (lane < C) ? fabs(cnl) : 0.0;               // the magnitude of the prefix sums at n_
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) cmag = fmax(cmag, __shfl_xor(cmag, off));
         cmag = fmax(smm_readlane(cmag, 0), smm_readlane(cmag, 16));
         const double tau = 0x1p-30 * (fabs(best) + cmag + 1.0);
         // ONE state within tau of the maximum
         const unsigned long long nearm = __ballot(lane < C && !(gmv < best - tau));
-        if (nan_row || __builtin_popcountll(nearm) != 1 || !smm_finite_bits(best)) { if (threadIdx.x == 0) sh_bad = (nan_row || !smm_finite_bits(best)) ? 16 : 4; break; }
+        if (nan_row || __builtin_popcountll(nearm) != 1 || !smm_finite_bits(best)) {
+            if (threadIdx.x == 0) sh_bad = (nan_row || !smm_finite_bits(best)) ? 16 : 4;
+            __syncthreads();
+            return 0;
+        }
         const int c = __ffsll(nearm) - 1;
         const double cn = smm_readlane(cnl, c), wf = smm_readlane(wgt, c);
-        // ... and ONE length: the candidate that equals the maximum, every other one below it by tau
+        // ... and the lengths: the candidate that EQUALS the maximum, and every candidate within tau of it
         const int kk = threadIdx.x + 1;
         if (kk <= kmax) {
-            const double hv = (c == fg) ? sp_h : hh[(size_t)c * (tj + 1) + (n - aj - kk)];
+            const double hv = (c == fg) ? sp_h : hh[(size_t)c * (tj + 1) + (n_ - aj - kk)];
             const double lv = (c == fg) ? sp_l : len_of(c, kk);
             const double cand = (cn + (hv + lv)) + wf;
             if (cand == best) atomicMin(&sh_kmin, (unsigned)kk);
-            if (!(cand < best - tau)) atomicAdd(&sh_near, 1u);
+            if (!(cand < best - tau)) { atomicAdd(&sh_near, 1u); atomicMin(&sh_nlo, (unsigned)kk); atomicMax(&sh_nhi, (unsigned)kk); }
         }
         __syncthreads();
-        const unsigned kf = sh_kmin, nn = sh_near;
+        const unsigned kf = sh_kmin, nn = sh_near, nlo = sh_nlo, nhi = sh_nhi;
         __syncthreads();
-        if (threadIdx.x == 0) { sh_kmin = 0xffffffffu; sh_near = 0; }
-        if (kf == 0xffffffffu || nn != 1 || nseg >= SMM_STITCH_MAXSEG) { if (threadIdx.x == 0) sh_bad = nseg >= SMM_STITCH_MAXSEG ? 16 : 8; break; }
-        const int k = (int)kf, s = n - k;
+        if (threadIdx.x == 0) { sh_kmin = 0xffffffffu; sh_near = 0; sh_nlo = 0xffffffffu; sh_nhi = 0; }
+        d_c = c; d_cn = cn;
+        if (kf == 0xffffffffu || nn < 1 || nn > 2) { if (threadIdx.x == 0) sh_bad = 8; __syncthreads(); return 0; }
+        d_k1 = (int)nlo; d_k2 = (int)nhi;
+        __syncthreads();
+        return (int)nn;
+    };
+    // (lane c keeps the global id of state c: a load of cmap[c] behind a trip's loads would wait for all of them)
+    const int64_t gid_l = cmap ? cmap[lane < C ? lane : C] : (int64_t)lane;
+    // TIES.  A run of one class that the model prefers to decode as TWO spans (its length an outlier of the class's Poisson)
+    // can be cut (k2, k1) or (k1, k2): the two orders share everything in front of the run and tie to within rounding (DESIGN
+    // 2), so at the run's end two lengths sit within tau, time and again on real corpora.  That tie is RESOLVED instead of
+    // repaired: both orders are verified to be what they seem -- behind the cut at n - k1 the decision must be (c, k2), behind
+    // the cut at n - k2 it must be (c, k1), both clear of tau -- and when the path is re-scored from the video's start the
+    // exact h in front of the run is at hand: the two rounded candidates are evaluated in the one-piece association, compared,
+    // and the one-piece decode's choice (the larger; the shorter last span when equal) is taken.  Per segment i (as recorded,
+    // last segment first): sh_tie_s2[i] = the other order's cut n - k2, or -1; sh_tie_c2[i] = cumE[n - k2][c].
+    int expect_c = -1, expect_k = 0;                              // the decision the previous segment's tie asked for
+    if (!sh_bad && n > 0) trip(n, to);
+    while (!sh_bad && n > 0) {
+        if (nseg >= SMM_STITCH_MAXSEG) { if (threadIdx.x == 0) sh_bad = 16; break; }
+        int st = decide(n);
+        if (st == 0) break;
+        int c = d_c, k = d_k1;
+        const double cn = d_cn;
+        int tie_s2 = -1;
+        double tie_c2 = 0.0;
+        if (expect_c >= 0) {
+            // the second half of a tie's first order: must be exactly (expect_c, expect_k), clear
+            if (st != 1 || c != expect_c || k != expect_k) { if (threadIdx.x == 0) sh_bad = 8; break; }
+            expect_c = -1;
+        } else if (st == 2) {
+            const int k1 = d_k1, k2 = d_k2, s2 = n - k2;
+            if (n - k1 - k2 < 0) { if (threadIdx.x == 0) sh_bad = 8; break; }
+            // look aside: the other order's cut -- behind n - k2 the decision must be (c, k1), clear
+            __syncthreads();
+            trip(s2, c);
+            const int st2 = decide(s2);
+            if (st2 != 1 || d_c != c || d_k1 != k1) { if (threadIdx.x == 0 && !sh_bad) sh_bad = 8; break; }
+            tie_s2 = s2;
+            tie_c2 = d_cn;                                        // cumE[s2][c]
+            expect_c = c; expect_k = k2;                          // ... and behind n - k1 it must be (c, k2): the next iteration
+            k = k1;                                               // tentatively the shorter last span; the score pass decides
+            // (this segment's own row: cumE[n][to] below needs hc of n's unit again)
+            trip(n, to);
+        }
+        const int s = n - k;
         if (threadIdx.x == 0) {
             sh_seg_s[nseg] = s;
             sh_seg_c[nseg] = c;
+            sh_tie_s2[nseg] = tie_s2;
+            sh_tie_c2[nseg] = tie_c2;
             sh_guess[to] = c;
         }
         // what the score along the path needs of position n: cumE[n][c] (this segment's state) and cumE[n][to] (the next one's)
@@ -379,6 +441,7 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
             for (int f = s + threadIdx.x; f < n0; f += blockDim.x) labels[f] = gid;
         if (threadIdx.x == 0 && spans) spans[s] = gid;
     }
+    if (expect_c >= 0 && threadIdx.x == 0 && !sh_bad) sh_bad = 8;   // (a tie whose first order ran into the video's start)
     __syncthreads();
     const bool bad = sh_bad != 0;
 
@@ -401,6 +464,23 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         double h = sh_h0;
         double gam = 0.0;
         for (int i = nseg - 1; i >= 0; --i) {
+            if (i >= 1 && sh_tie_s2[i - 1] >= 0) {
+                // segments i (earlier) and i - 1 (later) are one run of class c cut at s1 = n - k1; the other order cuts it at
+                // s2 = n - k2.  h = the exact h in front of the run.  Both candidates of the decision at n, in the one-piece
+                // decode's association; it takes the larger, and the shorter last span (k1: as recorded) when they are equal
+                const double ts = sh_tr[i], wf = sh_tr[i - 1], ln2 = sh_ln[i], ln1 = sh_ln[i - 1];   // trans[c][c], w(to_n, c), len[k2], len[k1]
+                const double c_s1 = sh_cn[i], c_n = sh_cn[i - 1], c_s2 = sh_tie_c2[i - 1];
+                const double g1 = c_s1 + (h + ln2), h1 = (g1 + ts) - c_s1, cand1 = (c_n + (h1 + ln1)) + wf;
+                const double g2 = c_s2 + (h + ln1), h2 = (g2 + ts) - c_s2, cand2 = (c_n + (h2 + ln2)) + wf;
+                if (cand2 > cand1) {
+                    // the other order: [p, s2) of length k1, then [s2, n) of length k2
+                    const int s1 = sh_seg_s[i - 1], s2 = sh_tie_s2[i - 1];
+                    sh_seg_s[i - 1] = s2;
+                    sh_ln[i] = ln1; sh_ln[i - 1] = ln2;
+                    sh_cn[i] = c_s2; sh_ct[i] = c_s2;
+                    if (spans) { spans[s1] = -1; spans[s2] = cmap ? cmap[sh_seg_c[i]] : (int64_t)sh_seg_c[i]; }
+                }
+            }
             gam = sh_cn[i] + (h + sh_ln[i]);
             if (i > 0) h = (gam + sh_tr[i]) - sh_ct[i];
         }
@@ -413,6 +493,11 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
         redo[blockIdx.x] = bad ? 1 : 0;
         atomicAdd(a.err + 4, 1);
         if (bad) { atomicAdd(a.err + 5, 1); atomicOr(a.err + 6, sh_bad); }
+        else {
+            int nt = 0;
+            for (int i = 0; i < nseg; ++i) nt += sh_tie_s2[i] >= 0;
+            if (nt) atomicAdd(a.err + 7, nt);                     // one-class-run ties resolved
+        }
     }
 }
 

@@ -469,7 +469,7 @@ def to_host(t):
 def _err_view(batch, ws):
     """int32 view of the error word inside the workspace a launch was given (the kernels of that launch write it)."""
     off = _lib.load().smm_error_word_offset(ctypes.byref(batch.shape))
-    return ws[off:off + 32].view(torch.int32)      # [error, 0, band-0 sources pushed, band-blocks evaluated, videos split in time, of those decoded again in one piece, 0, 0]
+    return ws[off:off + 32].view(torch.int32)      # [error, 0, band-0 sources pushed, band-blocks evaluated, videos split in time, of those decoded again in one piece, why (bits), one-class-run ties resolved]
 
 
 def _err_copy(batch, ws):
@@ -491,7 +491,8 @@ def error_flag(batch, out=None, ws=None):
 def error_words(batch, out=None, ws=None):
     """[error word, 0, sources pushed into band 0, delayed band-blocks evaluated (words 2 and 3: diagnostics of the Viterbi
     kernel's BAND mode, smm_viterbi.hip: DOM and the band skip test), videos decoded as several units along the time axis, of
-    those the ones that were decoded again in one piece (words 4 and 5: csrc/smm_chunk.hip), 0, 0] of a decode (synchronises).
+    those the ones that were decoded again in one piece, why (a bit mask), one-class-run ties the stitch resolved (words 4..7:
+    csrc/smm_chunk.hip)] of a decode (synchronises).
     (Words 1 and 2 counted gang time-outs in rounds 1-3.)"""
     if out is not None and out.get('_err') is not None:
         return [int(v) for v in out['_err'].tolist()]

@@ -356,8 +356,8 @@ def timed_decode(a, pc, world, want_events=True):
         # long videos decoded as several units along the time axis (csrc/smm_chunk.hip), and how many of them had to be decoded
         # again in one piece, in the LAST timed step: error block words 4 and 5
         words = ops.error_words(pc.batch, last.get('out'))
-        if dp is not None and len(words) > 5:
-            dp["time_split"] = {"videos_split": words[4], "of_those_decoded_again_in_one_piece": words[5],
+        if dp is not None and len(words) > 7:
+            dp["time_split"] = {"videos_split": words[4], "of_those_decoded_again_in_one_piece": words[5], "one_class_run_ties_resolved": words[7],
                                 "why": [n for bit, n in ((1, "a cut did not certify"), (2, "closing step"), (4, "two states within the margin"),
                                                          (8, "two lengths within the margin"), (16, "NaN / too many segments")) if words[6] & bit]}
     return dt, dp, labels

@@ -103,6 +103,37 @@ def test_cfg2_batch_of_64_is_split_by_default(monkeypatch):
     assert err[4] == 64, err
 
 
+def test_one_class_run_ties_are_resolved_not_repaired(monkeypatch):
+    """Runs that last about TWICE what their class's Poisson length table expects are decoded as two spans of one class, and the
+    two orders of the pair -- (k2, k1) and (k1, k2) -- tie to within rounding: two lengths inside the stitch's margin.
+    The stitch verifies both orders and lets the exact score pass choose as the one-piece decode does; the outputs are the
+    one-piece decode's and the twin's, span starts included, and (nearly) nothing goes to the repair launch."""
+    from scipy.special import gammaln
+    lengths, c, k = [7000, 6500, 6800, 7200], 9, 1024
+    seed = 31
+    p = tv.structured_problem(seed, lengths, c, k, rate=(150, 260))
+    # structured_problem's own length tables (the rates its runs were drawn with), except for ONE class whose table expects
+    # 0.55 of what its runs last: that class's runs -- one in nine -- are worth cutting in two, the others are not
+    g0 = np.random.default_rng(seed)
+    rates = g0.uniform(150, 260, size=c)                        # (the generator's first draw: the true rates)
+    rates[3] *= 0.55
+    kk = np.arange(k)[:, None]
+    p['lens'] = kk * np.log(rates) - rates - gammaln(kk + 1)
+    g = np.random.default_rng(4)
+    tr = np.full((c, c), -6.0) + g.uniform(-0.5, 0.5, size=(c, c))
+    np.fill_diagonal(tr, -1.5)                                  # a self transition is affordable
+    p['trans'] = tr - np.log(np.exp(tr).sum(0, keepdims=True))
+    out = decode_split_and_whole(p, monkeypatch, unit=1)
+    spans, _ = tv.run_oracle(p)
+    same_class_pairs = 0
+    for i, t in enumerate(lengths):
+        labs = spans[i, :t][spans[i, :t] >= 0]
+        same_class_pairs += int((labs[1:] == labs[:-1]).sum())
+    assert same_class_pairs >= 4, same_class_pairs               # the lattice does what it was built for
+    assert out['_err'][4] == 4 and out['_err'][7] >= 8, out['_err']   # (the twin shows four two-span runs per video)
+    assert out['_err'][5] == 0, out['_err']
+
+
 def test_a_short_warm_up_fails_the_certificate_not_the_decode(monkeypatch):
     """With a warm-up of 16 positions the units have not forgotten their start when their certified window begins: the cut
     does not certify, the video is repaired -- the outputs never depend on the split having worked."""

@@ -30,6 +30,7 @@ struct SmmEnv {
     double split_min_us = 100.0, split_ns = 0.0;     // SMM_SPLIT_MIN_US, SMM_SPLIT_NS (0: from smm_band_frame_ns), SMM_SPLIT_MARGIN: choose_split's model
     int split_margin = 400;
     int plan_cache = 1;       // SMM_PLAN_CACHE=0: no resident plans
+    int small_wg = 1;         // SMM_SMALL_WG=0: no four-wave workgroups for <= 16-state videos; 2: wherever they apply, whatever the part's size (tests; same results)
     int chunk = 1;            // SMM_CHUNK=0: no time-split decode of long videos (same results)
     int chunk_p = 0;          // SMM_CHUNK_P: positions per unit of a time-split decode (0: from the launch's CU-time; tests force small ones)
     int chunk_wc = 512;       // SMM_CHUNK_WC: warm-up positions of a unit in front of the kp - 1 it is certified on (at most kp)
@@ -57,7 +58,7 @@ void env_read()
     const Item items[] = {
         {"SMM_SPEC", &e.spec, nullptr}, {"SMM_NO_SPLIT", &e.no_split, nullptr}, {"SMM_SPLIT_MIN_US", nullptr, &e.split_min_us},
         {"SMM_SPLIT_NS", nullptr, &e.split_ns}, {"SMM_SPLIT_MARGIN", &e.split_margin, nullptr},
-        {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_CHUNK", &e.chunk, nullptr}, {"SMM_CHUNK_P", &e.chunk_p, nullptr},
+        {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_SMALL_WG", &e.small_wg, nullptr}, {"SMM_CHUNK", &e.chunk, nullptr}, {"SMM_CHUNK_P", &e.chunk_p, nullptr},
         {"SMM_CHUNK_WC", &e.chunk_wc, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
         {"SMM_FIT_GRID", &e.fit_grid, nullptr}, {"SMM_VERBOSE", &e.verbose, nullptr},
 #ifdef SMM_DEV
@@ -281,6 +282,9 @@ struct Staged {
     int32_t *redo;
     double *anchors;
     int n_cv, n_units, u_part1;
+    // the LAST part of the DP launch order (the rest of a stream split, or the whole launch) ends with small_count units of <= 16
+    // states that run in four-wave workgroups, two per CU, beside the others (smm_viterbi.hip: smm_launch_viterbi_small); 0: none
+    int small_first, small_count;
 };
 
 static bool band_mode(int kp_max, int c_need);
@@ -731,6 +735,31 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     } else {
         out->n_split = want_split ? choose_split(hv, ho, s->b, s->d, s->c_max, s->total_frames) : 0;
     }
+    // SMALL workgroups: the last part of the launch -- the rest of a stream split, or everything that is not a unit of a
+    // time-split video -- when it is bound by CU-time through and through: at least three videos per CU (cfg3's rest, 340 videos
+    // on 256 CUs, lost 15 % to them: its <= 16-state videos of up to 11 800 frames run 25..60 % longer in four waves and became
+    // the part's critical path; cfg5's 2754 videos gained 11 %), and only videos that stay well inside the part's CU-time at the
+    // four-wave speed.  Those go to the part's END (work order kept on both sides).
+    out->small_first = out->small_count = 0;
+    if (for_viterbi && cum_chunk == 0 && out->band_mode && env().small_wg && !(s->flags & SMM_SHAPE_NO_EOS)) {
+        const bool force = env().small_wg >= 2;
+        const int n_cu = device_cus();
+        const int t0 = out->n_split > 0 ? out->n_split : n_cv;              // first video of the last part, in `order`
+        const int n_tail = s->b - t0;
+        if (n_cu > 0 && (force || n_tail >= 3 * n_cu)) {
+            double t_cu = 0.0;                                              // the part's CU-time at the eight-wave speed, ns
+            for (int i = t0; i < s->b; ++i) t_cu += (double)hv[ho[i]].T * smm_band_frame_ns(n_states[hv[ho[i]].group]);
+            t_cu /= n_cu;
+            auto small = [&](int32_t v) {
+                return n_states[hv[v].group] <= 16 && (force || (double)hv[v].T * 1.6 * smm_band_frame_ns(n_states[hv[v].group]) <= 0.5 * t_cu);
+            };
+            const int n_small = (int)std::count_if(ho + t0, ho + s->b, small);
+            if (n_small >= (force ? 1 : 64)) {
+                std::stable_partition(ho + t0, ho + s->b, [&](int32_t v) { return !small(v); });
+                out->small_count = n_small;
+            }
+        }
+    }
     {
         // emission grid (flat): video order[i] gets smm_emission_blocks(T) workgroups; in the DP's final order
         int32_t *hc = reinterpret_cast<int32_t *>(host.data() + p.o_emcum);
@@ -772,6 +801,10 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
             xp[i] = cp.cvs[i].vid;
         }
     }
+
+    // (in the DP launch's order -- `order`, or with time-split videos [units | unsplit videos in `order`'s order] -- the small videos
+    // are the last small_count entries)
+    if (out->small_count > 0) out->small_first = out->n_units - out->small_count;
 
     char *base = static_cast<char *>(ws);
     // videos | order | n_states travel as kernel arguments (no pageable copy: the host never waits for the stream) -- into
@@ -894,6 +927,13 @@ extern "C" int smm_dp_timing_read_tagged(float *ms, int32_t *tags, int cap)
 
 extern "C" int smm_dp_timing_read(float *ms, int cap) { return smm_dp_timing_read_tagged(ms, nullptr, cap); }
 
+namespace {
+// (defined with the split decode below) per device: second streams and pooled event pairs
+hipStream_t aux_stream_n(int dev, int which);
+bool aux_events_get(int dev, std::pair<hipEvent_t, hipEvent_t> &ev);
+void aux_events_put(int dev, const std::pair<hipEvent_t, hipEvent_t> &ev);
+}  // namespace
+
 static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, const double *trans, const double *init,
                        const double *len_scores, const double *endpen, const int64_t *class_map, int64_t *spans,
                        int64_t *labels, double *best, int32_t *n_segs, hipStream_t stream, int first = 0, int count = -1,
@@ -943,11 +983,51 @@ static int run_viterbi(const smm_shape *s, const Staged &st, const double *elp, 
     }
     if (!launch) { SMM_HIP(hipGetLastError()); return SMM_OK; }      // (prep only)
     if (with_units) smm_launch_cum_anchors(a, st.cvs, st.n_cv, st.anchors, stream);   // cumE at the units' first positions, serially
+    // SMALL workgroups (smm_viterbi.hip: smm_launch_viterbi_small): when this range of the launch order ends with the part's
+    // <= 16-state videos (stage_uncached put them there), those run in four-wave workgroups, two per CU, on a side stream
+    // BESIDE the eight-wave launch of the others -- forked behind everything this stream has queued so far (band tables,
+    // this part's emission) and joined before the call goes on.  Not under stream capture (the side stream is shared).
+    const int lo = (int)(a.order - (st.n_cv > 0 ? st.uorder : st.order));
+    int n_small = (st.small_count > 0 && lo <= st.small_first && lo + a.b == st.small_first + st.small_count) ? st.small_count : 0;
+    hipStream_t side = nullptr;
+    std::pair<hipEvent_t, hipEvent_t> fj{nullptr, nullptr};
+    int dev = 0;
+    if (n_small > 0) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipStreamIsCapturing(stream, &cap) == hipSuccess &&
+            cap == hipStreamCaptureStatusNone)
+            side = aux_stream_n(dev, 1);
+        if (side && !aux_events_get(dev, fj)) side = nullptr;
+        if (!side) n_small = 0;
+    }
+    int rc_small = SMM_OK;
+    if (n_small > 0) {
+        SmmDpArgs as = a;
+        as.order = a.order + (a.b - n_small);
+        as.b = n_small;
+        a.b -= n_small;
+        if (hipEventRecord(fj.first, stream) != hipSuccess || hipStreamWaitEvent(side, fj.first, 0) != hipSuccess) rc_small = SMM_ERR_HIP;
+        if (rc_small == SMM_OK) {
+            std::pair<hipEvent_t, hipEvent_t> tev2;
+            const bool timed2 = dp_timing_begin(side, tev2);
+            rc_small = smm_launch_viterbi_small(as, side);
+            if (timed2) dp_timing_end(side, tev2, 3);
+        }
+    }
     std::pair<hipEvent_t, hipEvent_t> tev;
-    const bool timed = dp_timing_begin(stream, tev);
-    const int rc = smm_launch_viterbi(a, st.band_mode ? 16 : ring_regs(st.kp_max), st.c_need, stream);
-    if (timed) dp_timing_end(stream, tev, timing_tag);
+    int rc = SMM_OK;
+    if (a.b > 0) {
+        const bool timed = dp_timing_begin(stream, tev);
+        rc = smm_launch_viterbi(a, st.band_mode ? 16 : ring_regs(st.kp_max), st.c_need, stream);
+        if (timed) dp_timing_end(stream, tev, timing_tag);
+    }
+    if (side) {
+        // the join is made even after an error on the way, so that this stream never runs ahead of the side stream
+        if (hipEventRecord(fj.second, side) != hipSuccess || hipStreamWaitEvent(stream, fj.second, 0) != hipSuccess) rc_small = SMM_ERR_HIP;
+        aux_events_put(dev, fj);
+    }
     if (rc != SMM_OK) return rc;
+    if (rc_small != SMM_OK) return rc_small;
     if (with_units) {
         // certify the cuts, walk the path, write the split videos' outputs -- and decode again, in one piece, the ones that
         // could not be certified (one workgroup per split video; all but the flagged ones return at once)
@@ -1045,24 +1125,26 @@ extern "C" int smm_viterbi_f32(const smm_shape *shape, const int64_t *lengths_ho
 // made under stream capture does NOT split (the one shared second stream would be pulled into the capture and a
 // concurrent call from another thread would then enqueue onto a capturing stream): it runs as one launch pair.
 namespace {
-struct AuxDev {                       // per device: the second stream of a split decode and the event pair that brackets it
-    hipStream_t stream = nullptr;
+struct AuxDev {                       // per device: the second stream of a split decode, the side stream of the small workgroups,
+    hipStream_t stream = nullptr, stream1 = nullptr;             // and the event pairs that bracket them
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;     // idle (fork, join) pairs
 };
 std::mutex g_aux_mu;
 AuxDev g_aux[64];
 
-hipStream_t aux_stream(int dev)
+hipStream_t aux_stream_n(int dev, int which)
 {
     std::lock_guard<std::mutex> lock(g_aux_mu);
     AuxDev &d = g_aux[dev];
-    if (!d.stream) {
+    hipStream_t &st = which ? d.stream1 : d.stream;
+    if (!st) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&d.stream, hipStreamNonBlocking, least) != hipSuccess) d.stream = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) st = nullptr;
     }
-    return d.stream;
+    return st;
 }
+hipStream_t aux_stream(int dev) { return aux_stream_n(dev, 0); }
 
 bool aux_events_get(int dev, std::pair<hipEvent_t, hipEvent_t> &ev)
 {
@@ -1093,6 +1175,7 @@ static void release_aux()
         for (auto &ev : g_aux[d].events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         g_aux[d].events.clear();
         if (g_aux[d].stream) { (void)hipStreamDestroy(g_aux[d].stream); g_aux[d].stream = nullptr; }
+        if (g_aux[d].stream1) { (void)hipStreamDestroy(g_aux[d].stream1); g_aux[d].stream1 = nullptr; }
     }
     std::lock_guard<std::mutex> lock2(g_dp_timing.mu);
     for (auto &ev : g_dp_timing.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

@@ -48,6 +48,7 @@ int smm_emission_bwd_chunk();
 void smm_launch_emission_bwd(const SmmEmBwdArgs &a, int c_need, hipStream_t stream);
 // returns an smm_status; r = ring registers per lane (1,2,4,..,64), c_need = max states of any group
 int smm_launch_viterbi(const SmmDpArgs &a, int r, int c_need, hipStream_t stream);
+int smm_launch_viterbi_small(const SmmDpArgs &a, hipStream_t stream);   // BAND mode, <= 16 states, four-wave workgroups (two per CU)
 int smm_launch_viterbi_repair(const SmmDpArgs &a, int c_need, hipStream_t stream);   // BAND mode (time-split decode: smm_chunk.hip)
 // Viterbi BAND mode: the state-major length table and the skip-test bounds of every (group, state) (smm_viterbi.hip)
 void smm_launch_band_tables(const double *len, const int32_t *n_states, double *len_t, double *band_tab, double *dmin_t,

@@ -350,10 +350,10 @@ __device__ __forceinline__ void smm_band_ring_load(double (&L)[2], const double 
 // TAG  1: the same kernel under a second name -- the repair launch of a time-split decode (smm_chunk.hip), kept apart from the
 //      launch it repairs in per-kernel statistics (it nearly always returns at once)
 template <int R, int SPW, int NW, int HF, int B, int D = SMM_D, bool BAND = false, int TAG = 0>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, (NW + 3) / 4)))
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((BAND && NW == 4) ? 2 : 1, (BAND && NW == 4) ? 2 : (NW + 3) / 4)))
 smm_viterbi_kernel(SmmDpArgs a)
 {
-    static_assert(!BAND || (R == 16 && NW == 8 && B == 8 && D == 0),
+    static_assert(!BAND || (R == 16 && (NW == 8 || NW == 4) && B == 8 && D == 0),
                   "band mode: K <= 1024, 8 waves, blocks of 8 positions, the pushers push the block's own sources");
     static_assert(BAND || R < 16, "rings of 1024 slots exist in BAND mode only");
 #ifndef SMM_TRI
@@ -1812,7 +1812,10 @@ static int launch_band(const SmmDpArgs &a, int c_need, hipStream_t stream)
 #define SMM_DEV_BAND_SPW 4
 #define SMM_DEV_BAND_HF 12
 #endif
-    hipLaunchKernelGGL((smm_viterbi_kernel<16, SMM_DEV_BAND_SPW, 8, SMM_DEV_BAND_HF, 8, 0, true, TAG>), grid, block, 0, stream, a);
+#ifndef SMM_DEV_BAND_NW
+#define SMM_DEV_BAND_NW 8
+#endif
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, SMM_DEV_BAND_SPW, SMM_DEV_BAND_NW, SMM_DEV_BAND_HF, 8, 0, true, TAG>), grid, dim3(SMM_DEV_BAND_NW * 64), 0, stream, a);
     return SMM_OK;
 #else
     if (c_need <= 16) hipLaunchKernelGGL((smm_viterbi_kernel<16, 3, 8, 4, 8, 0, true, TAG>), grid, block, 0, stream, a);
@@ -1843,6 +1846,17 @@ static int launch_r(const SmmDpArgs &a, int c_need, hipStream_t stream)
               launch_if<R, 3, 8>(a, spw, nw, c_need, stream) || launch_if<R, 4, 8>(a, spw, nw, c_need, stream);
     }
     return hit ? SMM_OK : SMM_ERR_UNSUPPORTED;
+}
+
+// SMALL workgroups (round 5): chain wave, mover wave and TWO pusher waves with up to 8 states each -- four waves, <= 16 states,
+// 238 VGPRs at two waves per SIMD and 54 KB of LDS, so that a CU holds TWO of them.  One video on its own CU runs 25..35 %
+// slower this way (the pushers' per-state work doubles; four waves wait for each other as eight did), a launch part with
+// more videos than CUs 1.2..1.3 x faster (profiles/round5_two_per_cu.txt): the host uses it for the <= 16-state videos of
+// such parts only (smm_api.hip: run_viterbi), beside the eight-wave launch of the others.  Same code, same bits.
+int smm_launch_viterbi_small(const SmmDpArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((smm_viterbi_kernel<16, 8, 4, 4, 8, 0, true, 0>), dim3(a.b), dim3(256), 0, stream, a);
+    return SMM_OK;
 }
 
 // The repair launch of a time-split decode (smm_chunk.hip): one workgroup per split video, at work only for the videos the

@@ -617,7 +617,8 @@ def dp_timing(on):
 def dp_timing_read(cap=4096, tagged=False):
     """Durations (ms, launch order) of the DP kernel launches recorded since the last read; waits for them.
     ``tagged``: (ms, tag) pairs -- tag 0: the only DP launch of its call, 1: the critical videos of a split decode
-    (caller's stream), 2: the rest of a split decode (the library's second stream)."""
+    (caller's stream), 2: the rest of a split decode (the library's second stream), 3: the <= 16-state videos of a CU-time-bound
+    part in four-wave workgroups, two per CU, on the library's side stream (beside a launch of tag 0 or 2)."""
     buf = (ctypes.c_float * cap)()
     tags = (ctypes.c_int32 * cap)()
     n = _lib.load().smm_dp_timing_read_tagged(buf, tags, cap)

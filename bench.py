@@ -347,7 +347,8 @@ def timed_decode(a, pc, world, want_events=True):
             # decode on the library's second stream, tag 0: the only DP launch of an unsplit call
             crit = [m for m, t in rec if t in (0, 1)]
             rest = [m for m, t in rec if t == 2]
-            dp = {"launch_ms": float(np.mean(ms)), "launches_per_step": len(ms) / a.steps, "per_step_sum_ms": float(np.sum(ms)) / a.steps,
+            small = [m for m, t in rec if t == 3]             # <= 16-state videos in four-wave workgroups (two per CU), beside tag 0 / 2
+            dp = {"small_wg_launch_ms": float(np.mean(small)) if small else None, "launch_ms": float(np.mean(ms)), "launches_per_step": len(ms) / a.steps, "per_step_sum_ms": float(np.sum(ms)) / a.steps,
                   "max_launch_ms": float(np.max(ms)), "critical_launch_ms": float(np.mean(crit)) if crit else None,
                   "rest_launch_ms": float(np.mean(rest)) if rest else None}
     if not empty:
@@ -883,6 +884,7 @@ def main():
                          "kernel": "smm_viterbi_kernel", "kernel_ms": dp["launch_ms"], "launches_per_step": dp["launches_per_step"],
                          "kernel_ms_per_step": dp_ms, "kernel_ms_longest_launch": dp["max_launch_ms"],
                          "critical_launch_ms": dp["critical_launch_ms"], "rest_launch_ms": dp["rest_launch_ms"],
+                         "small_wg_launch_ms": dp.get("small_wg_launch_ms"),
                          "frac_wall": dp_bytes / (weak["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_source": "HIP events recorded by the library (smm_dp_timing_*) around every DP kernel launch "
                                              "of the K timed steps, on the stream each launch runs on: smm_decode_f32 launches "

@@ -136,7 +136,8 @@ void smm_dp_timing_enable(int on);
 int smm_dp_timing_read(float *ms, int cap);
 /* as smm_dp_timing_read, plus which launch each one was: tags[i] = 0 the only DP launch of its call, 1 the launch of the
  * critical (longest) videos of a split smm_decode_f32 on the caller's stream, 2 the rest of that call on the library's
- * second stream (either array may be NULL) */
+ * second stream, 3 the <= 16-state videos of a launch part that holds more videos than the GPU has CUs, decoded in four-wave
+ * workgroups (two per CU) on a side stream beside the launch of tag 0 / 2 (either array may be NULL) */
 int smm_dp_timing_read_tagged(float *ms, int32_t *tags, int cap);
 
 /*

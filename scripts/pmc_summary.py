@@ -13,7 +13,9 @@ if not os.path.exists(calib_path):
     calib_path = os.path.join(here, 'profiles', 'pmc_calibration.json')
 calib = json.load(open(calib_path)) if os.path.exists(calib_path) else {}
 # which calibrated shape each kernel's reads have
-SHAPE = {'smm_viterbi_kernel': 'b8_coalesced', 'smm_emission_pair_kernel': 'emission_alone', 'smm_emission_kernel': 'emission_alone',
+# (the emission kernels: the SHAPE's factor, 16-byte loads in 64-byte row pieces -- not the factor of the kernel's own known-bytes run,
+# which would make its traffic equal its algorithmic bytes by construction; that run is the cross-check in pmc_calibration.json)
+SHAPE = {'smm_viterbi_kernel': 'b8_coalesced', 'smm_emission_pair_kernel': 'b16_rowpieces', 'smm_emission_kernel': 'b16_rowpieces',
          'smm_class_sums_kernel': 'b16_coalesced', 'smm_chunk_stitch_kernel': 'b8_coalesced', 'smm_cum_anchor_kernel': 'b8_coalesced'}
 res = {}
 for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):

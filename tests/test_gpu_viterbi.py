@@ -745,6 +745,43 @@ def test_viterbi_band_mode_bit_exact(shape, kind, monkeypatch):
         np.testing.assert_array_equal(out[key], full[key])
 
 
+@pytest.mark.parametrize('shape', [([2300, 1029, 700, 64], 16, 1024), ([3000, 2000], 11, 1024), ([1500, 1400, 900], 5, 700), ([1200, 800], 13, 520)])
+@pytest.mark.parametrize('kind', ['structured', 'integer', 'flat'])
+def test_small_workgroups_bit_exact(shape, kind, monkeypatch):
+    """The four-wave BAND workgroup for videos of at most 16 states (chain, mover, two pushers with up to 8 states each; two fit
+    a CU: the host uses it where a launch part holds more videos than the GPU has CUs) decodes to the C twin's bits and to the
+    eight-wave launch's.  SMM_SMALL_WG=2 forces it on these few videos; the library's launch tags tell that it ran."""
+    lengths, c, k = shape
+    ops = _ops()
+    if kind == 'structured':
+        p = structured_problem(hash((tuple(lengths), c)) % 1000 + 9, lengths, c, k)
+    else:
+        p = make_problem(hash((tuple(lengths), c)) % 1000 + 2, len(lengths), max(lengths), c, k, integer=(kind == 'integer'))
+        p['lengths'] = np.asarray(lengths)
+        if kind == 'flat':
+            g = np.random.default_rng(17)
+            p['elp'] = p['elp'][:, :, :1] + 1e-3 * g.standard_normal(p['elp'].shape)
+            p['lens'] = -np.log(k) - 0.05 * g.random(p['lens'].shape)
+            tr = g.standard_normal(p['trans'].shape)
+            p['trans'] = tr - np.log(np.exp(tr).sum(0, keepdims=True))
+            p['init'] = np.full_like(p['init'], -np.log(c))
+    monkeypatch.setenv('SMM_CHUNK', '0')
+    monkeypatch.setenv('SMM_SMALL_WG', '2')
+    ops.dp_timing_read()
+    ops.dp_timing(True)
+    out = run_gpu(p)
+    ops.dp_timing(False)
+    tags = [t for _, t in ops.dp_timing_read(tagged=True)]
+    assert tags == [3], tags                                       # every video had <= 16 states: one launch, the small one
+    spans, v = run_oracle(p)
+    check(p, out, spans, v)
+    assert out['_err'][0] == 0
+    monkeypatch.setenv('SMM_SMALL_WG', '0')
+    full = run_gpu(p)
+    for key in ('best', 'spans', 'labels', 'n_segs'):
+        np.testing.assert_array_equal(out[key], full[key])
+
+
 RAMP_SHAPES = [([1700, 900], 7, 1024), ([2500], 23, 1024), ([1300, 1290, 140], 14, 700)]
 
 

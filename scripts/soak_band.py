@@ -1,7 +1,7 @@
 """Randomised soak of the Viterbi kernels against the C twin: random / structured / integer lattices, ragged batches, lengths from
 1 frame to a few thousand.  Default: the BAND kernel (K 513..1024, 1..32 states); round 4 added flat and ramp lattices.
 usage: soak_band.py [seconds] [seed] [kmin kmax cmax]     (e.g. 120 2 2 512 32: the ring kernels of every size)"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 import test_gpu_viterbi as tv
@@ -12,12 +12,13 @@ g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 KMIN, KMAX, CMAX = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (513, 1024, 32)
 ops = tv._ops()
 t0, n, frames = time.time(), 0, 0
+modes, split = [0, 0, 0, 0], [0, 0, 0]
 while time.time() - t0 < budget:
     c = int(g.integers(1, CMAX + 1))
     k = int(g.integers(KMIN, KMAX + 1))
     b = int(g.integers(1, 5))
     kind = ('random', 'structured', 'integer', 'masked', 'masked_inf', 'flat', 'ramp')[int(g.integers(0, 7))]
-    tmax = int(g.choice([700, 1100, 1600, 2600]))
+    tmax = int(g.choice([700, 1100, 1600, 2600, 4200, 6500]))
     lengths = [int(x) for x in g.integers(1, tmax + 1, size=b)]
     lengths[int(g.integers(0, b))] = tmax
     if b > 1 and g.random() < 0.3:
@@ -50,7 +51,18 @@ while time.time() - t0 < budget:
             tr = gg.standard_normal(p['trans'].shape)
             p['trans'] = tr - np.log(np.exp(tr).sum(0, keepdims=True))
             p['init'] = np.full_like(p['init'], -np.log(c))
+    # round 5: the launch's shape is drawn too -- long videos cut along the time axis into the smallest units the planner makes
+    # (SMM_CHUNK_P=1; with a short warm-up now and then, so that cuts fail to certify and the repair launch runs), <= 16-state
+    # videos in four-wave workgroups (SMM_SMALL_WG=2), or the plain launch
+    mode = int(g.integers(0, 4))
+    os.environ['SMM_CHUNK'] = '1' if mode in (1, 2) else '0'
+    os.environ['SMM_CHUNK_P'] = '1' if mode in (1, 2) else '0'
+    os.environ['SMM_CHUNK_WC'] = '64' if mode == 2 else '512'
+    os.environ['SMM_SMALL_WG'] = '2' if mode == 3 else '0'
+    ops.reload_env()
+    modes[mode] += 1
     out = tv.run_gpu(p)
+    split[0] += int(out['_err'][4]); split[1] += int(out['_err'][5]); split[2] += int(out['_err'][7])
     try:
         spans, v = tv.run_oracle(p)
     except AssertionError as e:
@@ -61,7 +73,8 @@ while time.time() - t0 < budget:
         tv.check(p, out, spans, v)
         assert out['_err'][0] == 0
     except AssertionError as e:
-        print('MISMATCH', dict(c=c, k=k, lengths=lengths, kind=kind, seed=seed), str(e)[:300])
+        print('MISMATCH', dict(c=c, k=k, lengths=lengths, kind=kind, seed=seed, mode=mode), str(e)[:300])
         sys.exit(1)
     n += 1; frames += sum(lengths)
-print('soak ok: %d launches, %d frames, %.0f s' % (n, frames, time.time() - t0))
+print('soak ok: %d launches, %d frames, %.0f s; launches plain / time-split / time-split with a 64-position warm-up / small workgroups: %s; videos split %d, repaired %d, ties resolved %d'
+      % (n, frames, time.time() - t0, modes, split[0], split[1], split[2]))

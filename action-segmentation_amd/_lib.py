@@ -7,7 +7,7 @@ LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(HERE, "libsmmdp.so")  
 
 SYMBOLS = [
     "smm_strerror", "smm_last_hip_error", "smm_version", "smm_device_count", "smm_workspace_bytes",
-    "smm_error_word_offset", "smm_dp_timing_enable", "smm_dp_timing_read", "smm_dp_timing_read_tagged", "smm_band_frame_ns",
+    "smm_error_word_offset", "smm_dp_timing_enable", "smm_dp_timing_read", "smm_dp_timing_read_tagged", "smm_band_frame_ns", "smm_time_split_plan",
     "smm_env_reload", "smm_release_cached_plans", "smm_cached_plan_bytes",
     "smm_emission_f64", "smm_emission_bwd_f64", "smm_viterbi_f64", "smm_viterbi_f32", "smm_decode_f32", "smm_logz_f64", "smm_logz_bwd_f64",
     "smm_factor_tables_f64", "smm_factor_tables_bwd_f64",
@@ -88,6 +88,8 @@ def load():
     lib.smm_dp_timing_read_tagged.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
     lib.smm_band_frame_ns.restype = ctypes.c_double
     lib.smm_band_frame_ns.argtypes = [ctypes.c_int]
+    lib.smm_time_split_plan.restype = ctypes.c_int
+    lib.smm_time_split_plan.argtypes = [ctypes.POINTER(SmmShape)] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int]
     lib.smm_env_reload.restype = None
     lib.smm_env_reload.argtypes = []
     lib.smm_release_cached_plans.restype = ctypes.c_size_t

@@ -598,11 +598,11 @@ struct ChunkPlan {
     std::vector<SmmChunkVideo> cvs;
 };
 
-static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out)
+static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out, int n_cu_given = 0)
 {
     const SmmEnv &ev = env();
     if (!ev.chunk || (s->flags & (SMM_SHAPE_NO_EOS | SMM_SHAPE_NO_TIME_SPLIT)) || kp_max <= 64) return;      // (kp <= 64: the window back-trace's launches are left alone)
-    const int n_cu = device_cus();
+    const int n_cu = n_cu_given > 0 ? n_cu_given : device_cus();
     if (n_cu <= 0) return;
     // (the ring kernels, span limits up to 512: cfg2's 16 states at K = 256 take 199 ns per frame; BAND mode: the library's model)
     auto ns = [&](int c) { return band ? smm_band_frame_ns(c) : 150.0 + 3.0 * c; };
@@ -834,6 +834,39 @@ static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int6
     out->c_need = c_need;
     if (plan_out) *plan_out = p;
     return SMM_OK;
+}
+
+// The time-split plan of a Viterbi launch as the library would make it on a GPU of n_cu compute units (include/smmdp.h): host
+// logic only, no device needed -- what the CPU tests look at.
+extern "C" int smm_time_split_plan(const smm_shape *s, const int64_t *lengths, const int32_t *group, const int32_t *kp,
+                                   const int32_t *n_states, int n_cu, int32_t *unit_video, int32_t *unit_first, int32_t *unit_len,
+                                   int32_t *unit_overlap, int cap)
+{
+    if (!shape_ok(s) || !lengths || !n_states || n_cu < 1) return SMM_ERR_ARG;
+    std::vector<SmmVideo> hv(s->b);
+    size_t hoff = 0;
+    int kp_max = 2, c_need = 0;
+    for (int g = 0; g < s->n_groups; ++g) c_need = std::max(c_need, n_states[g]);
+    for (int i = 0; i < s->b; ++i) {
+        const int g = group ? group[i] : 0;
+        if (g < 0 || g >= s->n_groups || lengths[i] < 1) return SMM_ERR_ARG;
+        hv[i] = SmmVideo{0, (int64_t)hoff, (int32_t)lengths[i], g, kp ? kp[i] : std::min<int>(s->k_rows, s->t_max), 0};
+        hoff += 8 * (size_t)s->c_max * (size_t)(lengths[i] + 1);
+        kp_max = std::max(kp_max, hv[i].kp);
+    }
+    ChunkPlan cp;
+    plan_chunks(s, hv.data(), n_states, kp_max, band_mode(kp_max, c_need), cp, n_cu);
+    int n = 0;
+    for (const SmmChunkVideo &cv : cp.cvs)
+        for (int j = 0; j < cv.n_chunks; ++j, ++n) {
+            if (n >= cap) continue;
+            const SmmVideo &u = cp.units[cv.first_unit + j];
+            if (unit_video) unit_video[n] = cv.vid;
+            if (unit_first) unit_first[n] = u.pad >> 2;
+            if (unit_len) unit_len[n] = u.T;
+            if (unit_overlap) unit_overlap[n] = j ? cv.ov : 0;
+        }
+    return n;
 }
 
 // Viterbi at K > 512: BAND mode (smm_viterbi.hip), up to SMM_MAX_STATES states on one CU; also 29..32 states at K > 256

@@ -627,6 +627,21 @@ def dp_timing_read(cap=4096, tagged=False):
     return [float(buf[i]) for i in range(min(n, cap))]
 
 
+def time_split_plan(batch, n_cu=256):
+    """The time-split plan the library would make for this batch's Viterbi launch on a GPU of ``n_cu`` compute units (host logic
+    only: include/smmdp.h, smm_time_split_plan) -> list of (video, first position, positions, positions in front of its own part)."""
+    import numpy as np
+    lib = _lib.load()
+    ln, fo, gr, kp, ns = batch.host_ptrs()
+    cap = int(batch.total_frames // 128 + 2 * batch.b + 8)
+    arrs = [np.zeros(cap, dtype=np.int32) for _ in range(4)]
+    n = lib.smm_time_split_plan(ctypes.byref(batch.shape), ctypes.c_void_p(ln), ctypes.c_void_p(gr), ctypes.c_void_p(kp), ctypes.c_void_p(ns),
+                                int(n_cu), *[ctypes.c_void_p(a.ctypes.data) for a in arrs], cap)
+    if n < 0:
+        raise _lib.SmmError("smm_time_split_plan: %s" % lib.smm_strerror(n).decode())
+    return [tuple(int(a[i]) for a in arrs) for i in range(min(n, cap))]
+
+
 def reload_env():
     """Make the library read its SMM_* tuning switches again (it reads them once, at first use)."""
     _lib.reload_env()

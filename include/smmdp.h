@@ -124,6 +124,15 @@ size_t smm_error_word_offset(const smm_shape *shape);
  * workspace bound of smm_workspace_bytes covers it.  SMM_CHUNK=0 in the environment switches the splitting off.
  */
 
+/* The plan "Long videos" would make for this launch on a GPU of n_cu compute units -- host logic only, no device needed (tests;
+ * capacity planning): for every unit of every video that would be split, in time order per video: its video, its first
+ * position, its length in positions, and how many of those it runs in front of its own part (0 for a video's first unit).
+ * Arrays of `cap` entries (any may be NULL); returns the number of units (may exceed cap), 0 when nothing would be split,
+ * or a negative smm_status.  group / kp may be NULL as in the decode entry points. */
+int smm_time_split_plan(const smm_shape *shape, const int64_t *lengths_host, const int32_t *group_host, const int32_t *kp_host,
+                        const int32_t *n_states_host, int n_cu, int32_t *unit_video, int32_t *unit_first, int32_t *unit_len,
+                        int32_t *unit_overlap, int cap);
+
 /*
  * Measurement aid (bench.py's roofline; not part of the reference's interface): while enabled, every launch of the
  * Viterbi DP kernel made by smm_viterbi_* / smm_decode_f32 is bracketed by a pair of HIP events on the stream it is

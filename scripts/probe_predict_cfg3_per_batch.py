@@ -20,3 +20,15 @@ for depth in (1, 2, 4, 8, 16):
         ts.append((time.perf_counter() - t0) * 1e3)
     same = all(np.array_equal(p[k], ref[k]) for k in ref)
     print('depth %2d: %.1f ms (min of 3) for %d batches; equal to the fused decode: %s' % (depth, min(ts), len(data._videos) // 5, same))
+# where the host's time per batch goes at the shipped depth (cProfile, one pass)
+import cProfile, pstats, io
+model.args.decode_depth = 8
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+pr.enable()
+model.predict(data, fused=False)
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(22)
+print(s.getvalue()[:6000])

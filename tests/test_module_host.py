@@ -159,3 +159,41 @@ def test_no_viterbi_kernel_has_a_private_segment():
     assert len(vit) >= 40, sorted(res)[:5]
     bad = {k: v for k, v in vit.items() if v.get('private_segment_fixed_size', 0) != 0 or v.get('vgpr_spill_count', 0) != 0}
     assert not bad, bad
+
+
+def test_time_split_plan_layout(monkeypatch):
+    """The planner of the time-split decode (csrc/smm_api.hip: plan_chunks, through smm_time_split_plan -- host logic, no GPU):
+    only launches bound by their longest video are split; a video's units tile it, every unit but the first runs warm-up + kp - 1
+    positions in front of an own part of at least kp - 1 positions, and the first starts at position 0."""
+    from action_segmentation_amd import ops, _lib
+    for name in ('SMM_CHUNK', 'SMM_CHUNK_P', 'SMM_CHUNK_WC'):
+        monkeypatch.delenv(name, raising=False)
+    _lib.reload_env()
+
+    def units_of(lengths, c, k, **kw):
+        b = ops.Batch(lengths, [c], k, c_max=c, kp=[min(k, max(lengths))] * len(lengths), d=200, **kw)
+        return ops.time_split_plan(b, n_cu=256)
+
+    # cfg1: one 10 000-frame video on an idle GPU -> 8 units of equal size
+    u = units_of([10000], 20, 1024)
+    assert len(u) == 8 and [v for v, _, _, _ in u] == [0] * 8
+    assert u[0][1] == 0 and u[0][3] == 0
+    ov = 512 + 1023
+    ends = [first + n for _, first, n, _ in u]
+    assert ends[-1] == 10000 and all(o == ov for _, _, _, o in u[1:])
+    for (_, f0, n0, _), (_, f1, n1, o1), e0 in zip(u, u[1:], ends):
+        assert f1 + o1 == e0                                  # a unit's own part begins where the previous unit ends
+        assert n1 - o1 >= 1 and (f1 + n1 == 10000 or n1 - o1 >= 1023)
+    assert max(n for _, _, n, _ in u) - min(n for _, _, n, _ in u[:-1]) <= 1
+    # cfg2: 64 x 2048 at K = 256 -> three units each; a launch with three videos per CU: none; hard masks: none; K <= 64: none
+    u = units_of([2048] * 64, 16, 256)
+    assert len(u) == 3 * 64 and all(o in (0, 256 + 255) for _, _, _, o in u)
+    assert units_of([6000] * 800, 16, 1024) == []
+    assert units_of([10000], 20, 1024, no_time_split=True) == []
+    assert units_of([2048] * 8, 12, 64) == []
+    # a forced unit size (tests): the smallest the overlap allows
+    monkeypatch.setenv('SMM_CHUNK_P', '1')
+    u = units_of([6000, 2500, 5200], 13, 1024)
+    assert sorted({v for v, _, _, _ in u}) == [0, 2] and all(n >= ov + 1023 or f + n in (6000, 5200) for _, f, n, _ in u if f)
+    monkeypatch.setenv('SMM_CHUNK', '0')
+    assert units_of([10000], 20, 1024) == []

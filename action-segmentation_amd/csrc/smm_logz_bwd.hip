@@ -86,21 +86,23 @@ __global__ void __launch_bounds__(1024) smm_marginals_kernel(SmmBwdArgs a)
     const int c = tid & 31, j = tid >> 5, nj = nth >> 5;
     const int cs = (T + nj - 1) / nj;
     const int t0 = j * cs, t1 = (t0 + cs < T) ? t0 + cs : T;
-    // Pass 1 leaves delta(t) in g_elp and the chunk sums in LDS; pass 2 turns them into running sums.  Eight positions
-    // per round, their 6 x 8 loads issued before the first exp: one trip to the history per round instead of one per
-    // position (the loop was latency-bound: 64 dependent trips per thread at T = 2048).
+    // Pass 1 leaves delta(t) in g_elp and the chunk sums in LDS; pass 2 turns them into running sums.  PB positions
+    // per round, their 6 x PB loads issued before the first exp: one trip to the history per round instead of one per
+    // position (the loop was latency-bound: 64 dependent trips per thread at T = 2048).  PB = 4: with eight, the 48 loads in
+    // flight + the exps' temporaries overflowed the 128 registers a 1024-thread workgroup leaves (21 spilled, 88 B of scratch).
+    constexpr int PB = 4;
     double sum = 0.0;
     if (c < C) {
-        for (int t = t0; t < t1; t += 8) {
-            double fs[8], fe[8];
+        for (int t = t0; t < t1; t += PB) {
+            double fs[PB], fe[PB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PB; ++u) {
                 const int tt = (t + u < t1) ? t + u : t1 - 1;
                 fs[u] = F_h[(size_t)tt * cm + c] + F_cum[(size_t)tt * cm + c] + B_g[(size_t)(T - tt) * cm + c] - lz;
                 fe[u] = F_g[(size_t)tt * cm + c] + B_h[(size_t)(T - tt) * cm + c] + B_cum[(size_t)(T - tt) * cm + c] - lz;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PB; ++u) {
                 if (t + u >= t1) break;
                 const double d = (t + u == 0) ? exp(fs[u]) : exp(fs[u]) - exp(fe[u]);      // O(T C) terms: full fp64 exp
                 sum += d;

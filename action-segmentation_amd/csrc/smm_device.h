@@ -154,6 +154,14 @@ __device__ __forceinline__ double smm_max_halves(double x)
     return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
 }
 
+// x[lane] + x[lane ^ 16] in every lane (fp32): one v_permlane16_swap
+__device__ __forceinline__ float smm_sum_rows16f(float x)
+{
+    const int v = __float_as_int(x);
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __int_as_float(a[0]) + __int_as_float(a[1]);
+}
+
 // max(x[lane], x[lane ^ 16]) in every lane: one v_permlane16_swap per 32-bit half (rows 1 <-> 0 and 3 <-> 2 trade places)
 __device__ __forceinline__ double smm_max_rows16(double x)
 {

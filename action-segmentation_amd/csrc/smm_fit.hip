@@ -276,14 +276,14 @@ extern "C" int smm_fit_stats_f64(int32_t b, const int64_t *lengths, const int64_
 #define SMM_FIT_HIP(call) do { if ((call) != hipSuccess) return SMM_ERR_HIP; } while (0)
     SMM_FIT_HIP((hipError_t)smm_upload_meta(base, hv.data(), sizeof(SmmFitVideo) * b, stream));
     SMM_FIT_HIP((hipError_t)smm_upload_meta(base + fit_off_cum(b), cum.data(), sizeof(int32_t) * ((size_t)b + 1), stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(base + o_err, 64, stream));
     const size_t n = (size_t)n_classes;
-    SMM_FIT_HIP((hipError_t)smm_zero_async(sum_x, sizeof(double) * n * d, stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(sum_x2, sizeof(double) * d, stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(frame_counts, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(span_counts, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(span_start_counts, sizeof(int64_t) * n, stream));
-    SMM_FIT_HIP((hipError_t)smm_zero_async(span_transition_counts, sizeof(int64_t) * n * n, stream));
+    {
+        // (one launch for the seven of them: smm_zero_multi_async)
+        void *const zp[7] = {base + o_err, sum_x, sum_x2, frame_counts, span_counts, span_start_counts, span_transition_counts};
+        const size_t zb[7] = {64, sizeof(double) * n * d, sizeof(double) * d, sizeof(int64_t) * n, sizeof(int64_t) * n, sizeof(int64_t) * n,
+                              sizeof(int64_t) * n * n};
+        SMM_FIT_HIP((hipError_t)smm_zero_multi_async(zp, zb, 7, stream));
+    }
     SmmFitArgs a{};
     a.videos = reinterpret_cast<const SmmFitVideo *>(base);
     a.x = x;

@@ -22,6 +22,8 @@ struct SmmEmArgs {
 int smm_upload_meta(void *dst_dev, const void *src_host, size_t bytes, hipStream_t stream);
 // zero fill by a kernel (a hipMemsetAsync captured into a hipGraph does not replay reliably: smm_api.hip); hipError_t as int
 int smm_zero_async(void *dst_dev, size_t bytes, hipStream_t stream);
+// ... of up to eight regions in one launch
+int smm_zero_multi_async(void *const *dst_dev, const size_t *bytes, int n, hipStream_t stream);
 
 // flat grid: blk_cum[i] (device, [b + 1]) = workgroups of the videos order[0..i), built by the host from
 // smm_emission_tiles_per_wave / smm_emission_blocks

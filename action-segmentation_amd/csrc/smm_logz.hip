@@ -37,6 +37,11 @@
 
 #define SMM_LOG2E 1.4426950408889634
 #define SMM_LN2 0.6931471805599453
+// Round 5: INSIDE the workgroup every log-weight is kept in log2 units (x log2 e): what the chain wave and the pushers exchange through
+// LDS (h, A', cumE, gamma, elp) and the chain wave's own tables (trans, the short lengths).  v_exp_f32 / v_log_f32 are base 2, so the
+// chain wave's 14 exponentials and 2 logarithms per position lose their conversion multiplies -- 16 of the ~140 instructions of the
+// position's serial stream.  The mover wave converts at the boundary: elp x log2 e on the way into LDS, the histories x ln 2 on the way
+// to HBM (two roundings of 2^-53 relative: nothing at the path's 1e-6).
 #define SMM_M_EMPTY (-1e30f)     // exponent of an empty slot (finite: M - M' must never be inf - inf)
 
 #ifndef SMM_LZ_B
@@ -80,12 +85,12 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
     double hm = src[0];
 #pragma unroll
     for (int i = 1; i < B; ++i) hm = smm_fmax(hm, src[i]);
-    const double nr = smm_fmax(ref, __builtin_ceil(hm * SMM_LOG2E));
+    const double nr = smm_fmax(ref, __builtin_ceil(hm));      // (h_blk is in log2 units)
     const float dlt = (float)(nr - ref);
     ref = nr;
     float c0[B];
 #pragma unroll
-    for (int i = 0; i < B; ++i) c0[i] = (float)(src[i] * SMM_LOG2E - nr);
+    for (int i = 0; i < B; ++i) c0[i] = (float)(src[i] - nr);
     // the length score every slot sees at each of the B steps, and the rotation of the ring
     float Ls[B][R];
 #pragma unroll
@@ -111,14 +116,14 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
         M[r] = mn;
         S[r] = acc;
     }
-    // hand A' of block j+1 to the chain wave (nats, fp64) and clear those slots
+    // hand A' of block j+1 to the chain wave (log2 units, fp64) and clear those slots
     auto hand = [&](int r, double *dst) {
         // (M + log2 S summed in fp64: in fp32 the sum of an exponent of magnitude ~8 and a fraction is rounded to 5e-7 --
         // once per POSITION and state, a random walk that reached 5e-5 in log Z at T = 8192 (round 4:
         // tests/test_gpu_fullsize.py::test_logz_gradient_error_does_not_grow_with_the_lattice); M is integer-valued,
         // log2 S in [0, 10] carries 6e-8)
         const float lg = __builtin_amdgcn_logf(S[r]);      // log2; -inf for an empty slot
-        *dst = (S[r] > 0.f) ? ((ref + (double)M[r]) + (double)lg) * SMM_LN2 : SMM_NEG_INF;
+        *dst = (S[r] > 0.f) ? (ref + (double)M[r]) + (double)lg : SMM_NEG_INF;       // (log2 units)
         M[r] = SMM_M_EMPTY;
         S[r] = 0.f;
     };
@@ -142,7 +147,8 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
 }
 
 // R   ring registers per lane (RING = 64 R >= kp)      SPW  states per pusher wave
-// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per half of the chain wave (8 or 16)
+// NW  waves per workgroup (1 chain + NW-1 pushers)       HF   source states per lane group of the chain wave: 16 (two groups of
+//                                                             32 lanes, up to 32 states) or 4 (four groups of 16 lanes, up to 16 states)
 // B   positions per hand-over block (K0 = 2 B lengths stay with the chain wave): 4 where the pushers bound the frame time
 //     (long rings: the per-block rescaling of a slot amortises over more candidates), 2 where the chain wave does
 //     (short rings: half the candidates folded serially per position)
@@ -220,8 +226,8 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
             sh_apart[0][i][c] = SMM_NEG_INF;              // block 0 needs no pusher source
             sh_apart[1][i][c] = SMM_NEG_INF;
             sh_h[0][i][c] = SMM_NEG_INF;
-            sh_h[1][i][c] = (i == B - 1) ? h0 : SMM_NEG_INF;     // "block -1": only position 0 exists
-            sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)frame_of(i) * cm + c] : 0.0;    // block 0
+            sh_h[1][i][c] = (i == B - 1) ? h0 * SMM_LOG2E : SMM_NEG_INF;     // "block -1": only position 0 exists (log2 units, as everything in LDS)
+            sh_e[0][i][c] = (c < C && i < T) ? elp[(size_t)frame_of(i) * cm + c] * SMM_LOG2E : 0.0;    // block 0
             sh_e[1][i][c] = 0.0;   // (columns >= c_max are never written again: the chain wave's dead lanes must not read LDS garbage)
         }
         sh_gam[c] = SMM_NEG_INF;
@@ -235,23 +241,27 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     if (w == 0) {
         // ============================================================================ chain wave (lane = state)
         __builtin_amdgcn_s_setprio(3);
-        const int to = lane & 31, half = lane >> 5;
+        // lane = (target state `to`, group `half` of source states): two groups of 32 lanes x 16 sources, or -- up to 16 states --
+        // four groups of 16 lanes x 4 sources: a quarter of the transition's exponentials per lane, one more swap in its two reductions
+        constexpr int LPG = (HF == 4) ? 16 : 32;          // lanes per group
+        static_assert(HF == 4 || HF == 16, "lane groups of the chain wave");
+        const int to = lane & (LPG - 1), half = lane / LPG;
         const bool live = to < C;
-        double tr[HF];                                    // trans[to][half*HF + i]
+        double tr[HF];                                    // trans[to][half*HF + i], log2 units
 #pragma unroll
         for (int i = 0; i < HF; ++i) {
             const int f = half * HF + i;
-            tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] : SMM_NEG_INF;
+            tr[i] = (live && f < C) ? trans[(size_t)to * cm + f] * SMM_LOG2E : SMM_NEG_INF;
         }
         double lk[K0 + 1];                                // len[k][to], k = 1..K0
 #pragma unroll
-        for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] : SMM_NEG_INF;
+        for (int k = 1; k <= K0; ++k) lk[k] = (live && k <= kp - 1) ? len[(size_t)k * cm + to] * SMM_LOG2E : SMM_NEG_INF;
         double hq[MQ];                                    // h[n][to], slot n mod MQ
 #pragma unroll
         for (int i = 0; i < MQ; ++i) hq[i] = SMM_NEG_INF;
-        hq[0] = live ? sh_h0[to] : SMM_NEG_INF;
+        hq[0] = live ? sh_h0[to] * SMM_LOG2E : SMM_NEG_INF;
         double cum = 0.0;
-        // both halves compute every position; the upper half stores to a junk array (no exec juggling on the serial path)
+        // every group computes every position; all but the first store to a junk array (no exec juggling on the serial path)
         double *const st_gam = half ? &sh_junk[0][0][to] : &sh_gam[to];
         double *const st_fin = half ? &sh_junk[0][0][to] : &sh_gfin[to];
         constexpr bool TAILFREE = R < 16;                  // no bounds tests inside a block (smm_viterbi.hip, the same loop)
@@ -281,9 +291,9 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
                     for (int k = 2; k <= K0; ++k) pm = smm_fmax(pm, x[k]);
                     const double rf = (pm == SMM_NEG_INF) ? 0.0 : pm;
-                    ps = smm_exp2f((float)(ap[i] - rf) * (float)SMM_LOG2E);
+                    ps = smm_exp2f((float)(ap[i] - rf));
 #pragma unroll
-                    for (int k = 2; k <= K0; ++k) ps += smm_exp2f((float)(x[k] - rf) * (float)SMM_LOG2E);
+                    for (int k = 2; k <= K0; ++k) ps += smm_exp2f((float)(x[k] - rf));
                 };
                 double pm;
                 float ps;
@@ -297,8 +307,8 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     const double x1 = hq[(jj * B + i + 4 * MQ) % MQ] + lk[1];
                     const double mx = smm_fmax(pm, x1);
                     const double rf = (mx == SMM_NEG_INF) ? 0.0 : mx;
-                    const float s = ps * smm_exp2f((float)(pm - rf) * (float)SMM_LOG2E) + smm_exp2f((float)(x1 - rf) * (float)SMM_LOG2E);
-                    const double acc = (mx == SMM_NEG_INF) ? mx : mx + (double)(__builtin_amdgcn_logf(s) * (float)SMM_LN2);
+                    const float s = ps * smm_exp2f((float)(pm - rf)) + smm_exp2f((float)(x1 - rf));
+                    const double acc = (mx == SMM_NEG_INF) ? mx : mx + (double)__builtin_amdgcn_logf(s);
                     cum = cumn;
                     const double gm = cum + acc;
                     st_gam[0] = gm;
@@ -325,13 +335,15 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                             v[2 * q + 1] = gv[q].y + tr[2 * q + 1];
                             vm = smm_fmax(vm, smm_fmax(v[2 * q], v[2 * q + 1]));
                         }
-                        vm = smm_max_halves(vm);                    // common reference of both halves
+                        if constexpr (HF == 4) vm = smm_max_rows16(vm);
+                        vm = smm_max_halves(vm);                    // common reference of all groups
                         const double vr = (vm == SMM_NEG_INF) ? 0.0 : vm;
                         float sv = 0.f;
 #pragma unroll
-                        for (int q = 0; q < HF; ++q) sv += smm_exp2f((float)(v[q] - vr) * (float)SMM_LOG2E);
+                        for (int q = 0; q < HF; ++q) sv += smm_exp2f((float)(v[q] - vr));
+                        if constexpr (HF == 4) sv = smm_sum_rows16f(sv);
                         sv += __shfl_xor(sv, 32);
-                        const double beta = (vm == SMM_NEG_INF) ? vm : vm + (double)(__builtin_amdgcn_logf(sv) * (float)SMM_LN2);
+                        const double beta = (vm == SMM_NEG_INF) ? vm : vm + (double)__builtin_amdgcn_logf(sv);
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % MQ] = hcur;
                         st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;
@@ -390,7 +402,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
 #pragma unroll
             for (int x = 0; x < NE; ++x) {
                 const int e = lane + 64 * x;
-                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]];
+                if (lo[x] >= 0 && q * B + 1 + row[x] <= T) dst[(size_t)(q * B + 1) * cm + e] = src[lo[x]] * SMM_LN2;   // (LDS: log2 units)
             }
         };
         for (int j0 = 0; j0 < J; j0 += UB) {
@@ -403,7 +415,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     double *dst = &sh_e[(jj + 1) & 1][0][0];
 #pragma unroll
                     for (int q = 0; q < NE; ++q)
-                        if (lo[q] >= 0) dst[lo[q]] = pre[q];
+                        if (lo[q] >= 0) dst[lo[q]] = pre[q] * SMM_LOG2E;
                     load_block(pre, j + 2);
                     if (j >= 1) {
                         store_block(&sh_cum[(jj + 1) & 1][0][0], hcum, j - 1);
@@ -429,7 +441,9 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
     }
 
     // -------------------------------------------------------------------------------- last position
-    // sh_gfin holds gamma[T][.]
+    // sh_gfin holds gamma[T][.] (log2 units)
+    __syncthreads();
+    if (threadIdx.x < SMM_MAX_STATES_DEV) sh_gfin[threadIdx.x] *= SMM_LN2;
     __syncthreads();
     if (w == 0) {
         double f = SMM_NEG_INF;
@@ -461,7 +475,7 @@ static int logz_launch_if(const SmmDpArgs &a, double *logz, int spw, int c_need,
     if (spw != SPW) return 0;
     constexpr int B = (R <= SMM_LZ_B2_MAX_R) ? 2 : SMM_LZ_B;
     const dim3 grid((a.flags & 64) ? 2 * a.b : a.b);
-    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 8, B>), grid, dim3(512), 0, stream, a, logz);
+    if (c_need <= 16) hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 4, B>), grid, dim3(512), 0, stream, a, logz);
     else hipLaunchKernelGGL((smm_logz_kernel<R, SPW, 8, 16, B>), grid, dim3(512), 0, stream, a, logz);
     return 1;
 }

@@ -234,11 +234,11 @@ extern "C" int smm_factor_tables_bwd_f64(const smm_tables_shape *s, const float 
         return SMM_ERR_ARG;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const size_t n = s->n_classes;
-    if (smm_zero_async(g_init_logits, sizeof(double) * n, hs) != (int)hipSuccess ||
-        smm_zero_async(g_transition_logits, sizeof(double) * n * n, hs) != (int)hipSuccess ||
-        smm_zero_async(g_poisson_log_rates, sizeof(double) * n, hs) != (int)hipSuccess ||
-        smm_zero_async(g_gaussian_means, sizeof(double) * n * s->d, hs) != (int)hipSuccess)
-        return SMM_ERR_HIP;
+    {
+        void *const zp[4] = {g_init_logits, g_transition_logits, g_poisson_log_rates, g_gaussian_means};
+        const size_t zb[4] = {sizeof(double) * n, sizeof(double) * n * n, sizeof(double) * n, sizeof(double) * n * s->d};
+        if (smm_zero_multi_async(zp, zb, 4, hs) != (int)hipSuccess) return SMM_ERR_HIP;
+    }
     SmmTabArgs a{};
     a.log_rates = poisson_log_rates; a.means = gaussian_means; a.cov = gaussian_cov;
     a.init_cons = init_constraints; a.trans_cons = transition_constraints;

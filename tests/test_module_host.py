@@ -176,7 +176,7 @@ def test_the_only_kernels_with_a_private_segment_are_the_known_logz_ones():
         pytest.skip("libsmmdp.so is not built, or its offload bundle cannot be read (compressed)")
     assert len(res) >= 150, len(res)
     bad = sorted(k for k, v in res.items() if v.get('private_segment_fixed_size', 0) != 0 or v.get('vgpr_spill_count', 0) != 0)
-    known = re.compile(r'^_Z15smm_logz_kernelILi16ELi[45]ELi8ELi(8|16)ELi4E')
+    known = re.compile(r'^_Z15smm_logz_kernelILi16ELi[45]ELi8ELi(4|16)ELi4E')
     assert all(known.match(k) for k in bad), [k for k in bad if not known.match(k)]
     assert len(bad) <= 4, bad
 

@@ -154,6 +154,14 @@ __device__ __forceinline__ double smm_max_halves(double x)
     return smm_fmax(smm_pack(a[0], b[0]), smm_pack(a[1], b[1]));
 }
 
+// x[lane] + x[lane ^ 32] in every lane (fp32): one v_permlane32_swap
+__device__ __forceinline__ float smm_sum_halvesf(float x)
+{
+    const int v = __float_as_int(x);
+    auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __int_as_float(a[0]) + __int_as_float(a[1]);
+}
+
 // x[lane] + x[lane ^ 16] in every lane (fp32): one v_permlane16_swap
 __device__ __forceinline__ float smm_sum_rows16f(float x)
 {

@@ -290,7 +290,10 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     pm = ap[i];
 #pragma unroll
                     for (int k = 2; k <= K0; ++k) pm = smm_fmax(pm, x[k]);
-                    const double rf = (pm == SMM_NEG_INF) ? 0.0 : pm;
+                    // (reference of the exponentials: the maximum, or a huge finite number when everything is -inf -- then every
+                    // difference is -inf, every exp2 is 0 and log2(0) = -inf carries on; one v_max where a compare and two
+                    // selects stood, five times per position)
+                    const double rf = smm_fmax(pm, -1e300);
                     ps = smm_exp2f((float)(ap[i] - rf));
 #pragma unroll
                     for (int k = 2; k <= K0; ++k) ps += smm_exp2f((float)(x[k] - rf));
@@ -306,9 +309,9 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     // A[n] = LSE( (pm, ps), h[n-1] + len[1] )
                     const double x1 = hq[(jj * B + i + 4 * MQ) % MQ] + lk[1];
                     const double mx = smm_fmax(pm, x1);
-                    const double rf = (mx == SMM_NEG_INF) ? 0.0 : mx;
+                    const double rf = smm_fmax(mx, -1e300);
                     const float s = ps * smm_exp2f((float)(pm - rf)) + smm_exp2f((float)(x1 - rf));
-                    const double acc = (mx == SMM_NEG_INF) ? mx : mx + (double)__builtin_amdgcn_logf(s);
+                    const double acc = mx + (double)__builtin_amdgcn_logf(s);          // (-inf + log2(0) = -inf)
                     cum = cumn;
                     const double gm = cum + acc;
                     st_gam[0] = gm;
@@ -337,13 +340,13 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                         }
                         if constexpr (HF == 4) vm = smm_max_rows16(vm);
                         vm = smm_max_halves(vm);                    // common reference of all groups
-                        const double vr = (vm == SMM_NEG_INF) ? 0.0 : vm;
+                        const double vr = smm_fmax(vm, -1e300);
                         float sv = 0.f;
 #pragma unroll
                         for (int q = 0; q < HF; ++q) sv += smm_exp2f((float)(v[q] - vr));
                         if constexpr (HF == 4) sv = smm_sum_rows16f(sv);
-                        sv += __shfl_xor(sv, 32);
-                        const double beta = (vm == SMM_NEG_INF) ? vm : vm + (double)__builtin_amdgcn_logf(sv);
+                        sv = smm_sum_halvesf(sv);                   // (v_permlane32_swap: __shfl_xor(.., 32) is a trip through LDS)
+                        const double beta = vm + (double)__builtin_amdgcn_logf(sv);
                         const double hcur = beta - cum;
                         hq[(jj * B + 1 + i) % MQ] = hcur;
                         st_h[((jj & 1) * B + i) * SMM_MAX_STATES_DEV] = hcur;

@@ -1,0 +1,83 @@
+"""Randomised soak of the log-partition kernels against the C twin (round 5: after the chain wave moved to log2 units, four lane
+groups at <= 16 states and -inf guards by v_max): random / integer / masked (-1e9 and -inf) lattices, ragged batches, 1..32 states,
+span limits 2..1024, end penalties on and off; log Z to the unit tests' bar (rtol 1e-6, atol 1e-4), and for every third problem the
+four gradients to 2e-5 (integer lattices, whose rounding errors repeat instead of averaging out: to the path's 1e-4; a one-state
+integer lattice of 420 frames is 3.4e-5 off before round 5's changes and after).  On the masked lattices the gradients are only REPORTED: these are videos that violate their ordering constraints
+everywhere, every path carries -1e4 narration penalties and -1e9 masks, log Z ~ -1e5, the ring slots' fp32 exponents (relative to a
+per-state reference that only moves up) round coarsely, and the posteriors of kernel and twin differ by up to a few 1e-4 -- the
+kernels before round 5's changes give the same numbers to six digits on those problems (accuracy);
+the worst absolute and relative errors are reported.
+usage: soak_logz.py [seconds] [seed]     (prints a line every ~20 s)"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import test_gpu_viterbi as tv
+from oracle import factored as F
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ops = tv._ops()
+dev = torch.device('cuda:0')
+t64 = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+t0, n, ng, frames, worst_z, worst_g, worst_gm, worst_abs, last = time.time(), 0, 0, 0, 0.0, 0.0, 0.0, 0.0, time.time()
+kinds = [0, 0, 0, 0]
+while time.time() - t0 < budget:
+    c = int(g.integers(1, 33))
+    k = int(g.choice([2, 3, 5, 8, 20, 40, 64, 65, 100, 130, 256, 300, 512, 520, 800, 1024]))
+    b = int(g.integers(1, 5))
+    tmax = int(g.choice([30, 90, 200, 420, 700])) if k <= 256 else int(g.choice([300, 560, 700]))
+    kind = int(g.integers(0, 4))
+    seed = int(g.integers(0, 10 ** 6))
+    ends = bool(g.random() < 0.5)
+    if kind >= 2 and c >= 2 and k >= 20 and tmax > c + 1:
+        lengths = [int(x) for x in g.integers(max(c + 1, tmax // 2), tmax + 1, size=b)]
+        lengths[0] = tmax
+        p = tv.masked_problem(seed, lengths, c, k, neg_inf=(kind == 3))
+    else:
+        kind = min(kind, 1)
+        p = tv.make_problem(seed, b, tmax, c, k, ends=ends, integer=(kind == 1), scale=float(g.choice([1.5, 3.0])))
+    kinds[kind] += 1
+    bb, tm, cm = p['elp'].shape
+    batch = ops.Batch(p['lengths'], [p['c']], p['k'], c_max=cm, t_max=tm, total_frames=bb * tm)
+    args = (t64(p['elp'].reshape(bb * tm, cm)), t64(p['trans'][None]), t64(p['init'][None]), t64(p['lens'][None]))
+    with_grad = n % 3 == 0 and k <= 600 and tm <= 420
+    z = ops.logz(batch, *args, endpen=t64(p['endpen']), with_backward=with_grad)
+    if with_grad:
+        up = np.linspace(0.5, 1.5, bb)
+        gr = ops.logz_bwd(batch, *args, z, grad_logz=t64(up), endpen=t64(p['endpen']), with_backward=True)
+    torch.cuda.synchronize()
+    if with_grad:
+        ref_z, ref = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'], grad=True, upstream=up)
+    else:
+        ref_z = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'])
+    zz = z.cpu().numpy()
+    fin = np.isfinite(ref_z)
+    assert (np.isfinite(zz) == fin).all(), (c, k, kind, seed, zz, ref_z)
+    ae = np.abs(zz[fin] - ref_z[fin])
+    if ae.size:
+        worst_abs = max(worst_abs, float(ae.max()))
+        worst_z = max(worst_z, float((ae / np.maximum(1.0, np.abs(ref_z[fin]))).max()))
+        assert (ae <= 1e-4 + 1e-6 * np.abs(ref_z[fin])).all(), (c, k, kind, seed, float(ae.max()))
+    if with_grad and fin.all():
+        gbar = float('inf') if kind >= 2 else (1e-4 if kind == 1 else 2e-5)    # (integer lattices: the path's 1e-4 -- their rounding errors do not average out)
+        ge = gr['elp'].cpu().numpy().reshape(bb, tm, cm)
+        kp = min(k, tm)
+        for got, want in ((ge[i, :t], ref['elp'][i, :t]) for i, t in enumerate(p['lengths'])):
+            e = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+            if kind < 2: worst_g = max(worst_g, float(e.max()))
+            else: worst_gm = max(worst_gm, float(e.max()))
+            assert e.max() <= gbar, (c, k, kind, seed, 'elp', float(e.max()))
+        for name, got in (('trans', gr['trans'].cpu().numpy()[0]), ('init', gr['init'].cpu().numpy()[0]), ('len', gr['len'].cpu().numpy()[0, :kp])):
+            e = np.abs(got - ref[name]) / np.maximum(1.0, np.abs(ref[name]))
+            if kind < 2: worst_g = max(worst_g, float(e.max()))
+            else: worst_gm = max(worst_gm, float(e.max()))
+            assert e.max() <= gbar, (c, k, kind, seed, name, float(e.max()))
+        ng += 1
+    n += 1
+    frames += int(np.sum(p['lengths']))
+    if time.time() - last > 20:
+        last = time.time()
+        print('  ... %d launches, %d with gradients, worst log Z error %.2e, worst gradient error %.2e' % (n, ng, worst_z, worst_g), flush=True)
+print('soak ok: %d log Z launches (%d with the four gradients), %d frames, %.0f s; random / integer / masked -1e9 / masked -inf: %s; '
+      'worst error of log Z %.2e absolute, %.2e relative to max(1, |log Z|) (bar: 1e-4 + 1e-6 |log Z|), of a gradient entry %.2e (bar 2e-5, integer lattices 1e-4; masked lattices %.2e, reported only)'
+      % (n, ng, frames, time.time() - t0, kinds, worst_abs, worst_z, worst_g, worst_gm))

@@ -2,11 +2,10 @@
 groups at <= 16 states and -inf guards by v_max): random / integer / masked (-1e9 and -inf) lattices, ragged batches, 1..32 states,
 span limits 2..1024, end penalties on and off; log Z to the unit tests' bar (rtol 1e-6, atol 1e-4), and for every third problem the
 four gradients to 2e-5 (integer lattices, whose rounding errors repeat instead of averaging out: to the path's 1e-4; a one-state
-integer lattice of 420 frames is 3.4e-5 off before round 5's changes and after).  On the masked lattices the gradients are only REPORTED: these are videos that violate their ordering constraints
-everywhere, every path carries -1e4 narration penalties and -1e9 masks, log Z ~ -1e5, the ring slots' fp32 exponents (relative to a
-per-state reference that only moves up) round coarsely, and the posteriors of kernel and twin differ by up to a few 1e-4 -- the
-kernels before round 5's changes give the same numbers to six digits on those problems (DESIGN 3b, accuracy);
-the worst absolute and relative errors are reported.
+integer lattice of 420 frames is 3.4e-5 off before round 5's changes and after).  On the masked lattices the gradients are only
+REPORTED: videos that violate their ordering constraints everywhere / states whose likely lengths lie beyond the span limit, log Z ~
+-1e5; the posteriors of kernel and twin differ by up to 8e-4 there, the kernels before round 5's changes give the same numbers to six
+digits, and the cause is not found (DESIGN 3b lists what was ruled out).
 usage: soak_logz.py [seconds] [seed]     (prints a line every ~20 s)"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -1081,3 +1081,26 @@ def test_many_short_videos_past_the_16_bit_grid_limits():
         g_len += g2['len']; g_trans += g2['trans']
     np.testing.assert_allclose(g['len'].cpu().numpy(), g_len.cpu().numpy(), rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(g['trans'].cpu().numpy(), g_trans.cpu().numpy(), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize('c,k', [(5, 8), (16, 40), (23, 70)])
+def test_logz_with_true_minus_infinity_masks(c, k):
+    """-inf masks (the reference's constrained path with the masks taken to the limit): a video that can walk the chain has a log Z
+    equal to the twin's; one that is too short to reach the only allowed end state can only close through the -1e9 of a real label
+    at the EOS position (reference semimarkov_modules.py:462-471) and has log Z ~ -1e9 in kernel and twin alike -- never a NaN
+    (round 5: the chain wave's -inf guards are a v_max against a huge finite reference, every exp2 of -inf is 0 and log2(0) = -inf
+    carries through)."""
+    ops = _ops()
+    lengths = [6 * c, c - 2, 3 * c]                             # the second video cannot visit c states in c - 2 frames
+    p = masked_problem(40 + c, lengths, c, k, neg_inf=True)
+    dev = torch.device('cuda:0')
+    b, tmax, cm = p['elp'].shape
+    batch = ops.Batch(p['lengths'], [c], k, c_max=cm, t_max=tmax, total_frames=b * tmax)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    z = ops.logz(batch, t(p['elp'].reshape(b * tmax, cm)), t(p['trans'][None]), t(p['init'][None]), t(p['lens'][None]), t(p['endpen']))
+    torch.cuda.synchronize()
+    z = z.cpu().numpy()
+    ref = F.logz(p['elp'], p['lengths'], p['trans'], p['init'], p['lens'], p['endpen'])
+    assert not np.isnan(z).any(), z
+    assert ref[1] < -9e8 and z[1] < -9e8, (z, ref)
+    np.testing.assert_allclose(z, ref, rtol=1e-6, atol=1e-4)

@@ -939,8 +939,12 @@ class SemiMarkovModule(nn.Module):
             bi = pc._batch_index_dev = torch.as_tensor(pc.batch_index, device=z.device)
         nb = int(max(pc.batch_index)) + 1
         sums = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, z)
-        cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
-        return sums / cnt
+        # (videos per source batch: a property of the packed corpus, made once -- three launches less per training step)
+        inv = getattr(pc, '_batch_inv_count_dev', None)
+        if inv is None or inv.device != z.device or inv.dtype != z.dtype:
+            cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
+            inv = pc._batch_inv_count_dev = (1.0 / cnt).detach()
+        return sums * inv
 
     def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None):

@@ -62,13 +62,20 @@ __device__ __forceinline__ double smm_lse2(double a, double b)
     return (mx == SMM_NEG_INF) ? mx : mx + (double)t;
 }
 
+// A wave-uniform double, told to the compiler: it then lives in a scalar register pair.
+__device__ __forceinline__ double smm_uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 // One block (B sources) of one state's ring.  Same slot / register / rotation scheme as smm_ring_block of the Viterbi
 // kernel: push step t = s + B - 1, u = t mod R; logical length register r lives in physical register (r - u) mod R and
 // one register crosses lanes per step.  The B candidates of a slot are gathered first (register aliases, no copies:
 // the loops are unrolled) and folded in together.
 template <int R, int B>
 __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R], float (&L)[R], double &ref, double &hd,
-                                                   const double *h_blk, double *a_blk, int j, int jj, int lane)
+                                                   const double *h_blk, double *a_blk, int j, int jj, int lane, const double lm)
 {
     constexpr int RING = 64 * R;
     double src[B];
@@ -81,16 +88,26 @@ __device__ __forceinline__ void smm_lse_ring_block(float (&M)[R], float (&S)[R],
         for (int i = 1; i < B; ++i) src[i] = hv[i - 1];
         hd = hv[B - 1];
     }
-    // reference of the state: integer-valued, only ever moves up
+    // Reference of the state (of h + lm, lm = the state's largest ring length score: the ring's L are kept relative to it, see the
+    // pusher waves' set-up): integer-valued, >= the block's own sources (every c0 <= 0).  It moves UP with every new maximum at once.
+    // Round 5: it also moves DOWN -- h is the path's advantage over emitting c for ever and FALLS wherever segments pay for their
+    // lengths (a state whose likely lengths lie beyond the span limit: hundreds of nats per segment), and a reference that only moved
+    // up stood thousands of units above every live candidate after a few hundred frames: an fp32 c0 of -3500 resolves 2.4e-4, and
+    // scripts/soak_logz.py found log Z 4e-4 and posteriors up to 8e-4 off the twin's on such lattices (a 200-frame video of three
+    // states: the forward message 4.6e-4 off at its end; 1e-6 with this and lm).  Down by at most 2^15 a block, towards the block's own
+    // maximum: the slots' exponents move by the same exact integer, and over a slot's life of at most RING / B <= 256 blocks they
+    // stay below 2^24.  (A drop of 1e9 behind a mask is followed at that pace, i.e. not at all -- as before.)
     double hm = src[0];
 #pragma unroll
     for (int i = 1; i < B; ++i) hm = smm_fmax(hm, src[i]);
-    const double nr = smm_fmax(ref, __builtin_ceil(hm));      // (h_blk is in log2 units)
+    const double ch = __builtin_ceil(hm + lm);                 // (h_blk is in log2 units)
+    const double nr = smm_fmax(ch, ref - 32768.0);             // (no finite source in the block: ch = -inf and the reference just drifts)
     const float dlt = (float)(nr - ref);
     ref = nr;
+    const double nrl = nr - lm;
     float c0[B];
 #pragma unroll
-    for (int i = 0; i < B; ++i) c0[i] = (float)(src[i] - nr);
+    for (int i = 0; i < B; ++i) c0[i] = (float)(src[i] - nrl);
     // the length score every slot sees at each of the B steps, and the rotation of the ring
     float Ls[B][R];
 #pragma unroll
@@ -361,12 +378,19 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
         if (NW == 8) rank = (w == 4) ? NP - 1 : ((w == NW - 1) ? 3 : w - 1);   // the chain wave's SIMD partner owns the fewest states
         const int nv_all = (C - rank + NP - 1) / NP;                       // states rank, rank+NP, ...
         const int nv = nv_all < 0 ? 0 : (nv_all > SPW ? SPW : nv_all);
+        // Round 5: a state's length scores ride in the ring RELATIVE to the largest of them, lmx (which joins h in the state's reference):
+        // a slot's exponent t = c0 + L is an fp32 number, and with the scores themselves in it every candidate carried 2^-24 |score| of
+        // rounding -- 2e-5 nats where a state's likely lengths lie beyond the span limit (scores of -300 .. -500 for EVERY allowed
+        // length).  Relative to lmx the lengths that carry the mass have |L| of a few units; the ones hundreds of nats below weigh
+        // e^-100 as before.
         float M[SPW][R], S[SPW][R], L[SPW][R];
-        double ref[SPW], hd[SPW];
+        double ref[SPW], hd[SPW], lmx[SPW];
 #pragma unroll
         for (int js = 0; js < SPW; ++js) {
             const int c = js * NP + rank;
             const bool on = js < nv;
+            double lv[R];
+            double lm = SMM_NEG_INF;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 // block protocol (source position -B at push step 0): slot p waits for k = (p + B + 1) mod RING; lengths
@@ -374,10 +398,18 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                 const int k = (lane * R + r + B + 1) & (64 * R - 1);
                 M[js][r] = SMM_M_EMPTY;
                 S[js][r] = 0.f;
-                L[js][r] = (on && k > K0 && k <= kp - 1) ? (float)(len[(size_t)k * cm + c] * SMM_LOG2E) : -__builtin_huge_valf();
+                lv[r] = (on && k > K0 && k <= kp - 1) ? len[(size_t)k * cm + c] * SMM_LOG2E : SMM_NEG_INF;
+                lm = smm_fmax(lm, lv[r]);
             }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) lm = smm_fmax(lm, __shfl_xor(lm, off));
+            if (!(lm > -1e300)) lm = 0.0;                                  // (no length beyond K0 in reach: every L is -inf anyway)
+            lm = smm_uniform(lm);                                           // (a scalar register pair per state)
+#pragma unroll
+            for (int r = 0; r < R; ++r) L[js][r] = (lv[r] > -1e300) ? (float)(lv[r] - lm) : -__builtin_huge_valf();
+            lmx[js] = lm;
             const double h0 = on ? sh_h0[c] : 0.0;
-            ref[js] = (h0 > -1e300 && h0 < 1e300) ? __builtin_ceil(h0 * SMM_LOG2E) : 0.0;
+            ref[js] = (h0 > -1e300 && h0 < 1e300) ? __builtin_ceil(h0 * SMM_LOG2E + lm) : 0.0;
             hd[js] = SMM_NEG_INF;
         }
         // mover role of this wave: block-relative element e = lane + 64 q  <->  (row e / cm, column e % cm)
@@ -431,7 +463,7 @@ smm_logz_kernel(SmmDpArgs a, double *logz)
                     if (js >= nv) break;
                     const int c = js * NP + rank;
                     smm_lse_ring_block<R, B>(M[js], S[js], L[js], ref[js], hd[js], &sh_h[(jj + 1) & 1][0][c],
-                                             &sh_apart[(jj + 1) & 1][0][c], j, jj % UB, lane);
+                                             &sh_apart[(jj + 1) & 1][0][c], j, jj % UB, lane, lmx[js]);
                 }
                 __syncthreads();                             // end of block j
             }

@@ -1,11 +1,11 @@
 """Randomised soak of the log-partition kernels against the C twin (round 5: after the chain wave moved to log2 units, four lane
 groups at <= 16 states and -inf guards by v_max): random / integer / masked (-1e9 and -inf) lattices, ragged batches, 1..32 states,
 span limits 2..1024, end penalties on and off; log Z to the unit tests' bar (rtol 1e-6, atol 1e-4), and for every third problem the
-four gradients to 2e-5 (integer lattices, whose rounding errors repeat instead of averaging out: to the path's 1e-4; a one-state
-integer lattice of 420 frames is 3.4e-5 off before round 5's changes and after).  On the masked lattices the gradients are only
-REPORTED: videos that violate their ordering constraints everywhere / states whose likely lengths lie beyond the span limit, log Z ~
--1e5; the posteriors of kernel and twin differ by up to 8e-4 there, the kernels before round 5's changes give the same numbers to six
-digits, and the cause is not found (DESIGN 3b lists what was ruled out).
+four gradients to 2e-5 (integer lattices, whose rounding errors repeat instead of averaging out, and masked lattices -- videos that
+violate their ordering constraints everywhere, states whose likely lengths lie beyond the span limit, log Z ~ -1e5: to the path's 1e-4).
+History: the first runs of this soak found the masked lattices' posteriors up to 8e-4 off the twin's (the kernels before round 5 gave
+the same numbers); the cause was a per-state reference that only moved up while h fell, and length scores of -500 inside fp32
+exponents; with both fixed the worst masked-lattice gradient error is a few 1e-5.
 usage: soak_logz.py [seconds] [seed]     (prints a line every ~20 s)"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -58,7 +58,7 @@ while time.time() - t0 < budget:
         worst_z = max(worst_z, float((ae / np.maximum(1.0, np.abs(ref_z[fin]))).max()))
         assert (ae <= 1e-4 + 1e-6 * np.abs(ref_z[fin])).all(), (c, k, kind, seed, float(ae.max()))
     if with_grad and fin.all():
-        gbar = float('inf') if kind >= 2 else (1e-4 if kind == 1 else 2e-5)    # (integer lattices: the path's 1e-4 -- their rounding errors do not average out)
+        gbar = 2e-5 if kind == 0 else 1e-4                                       # (integer / masked lattices: the path's 1e-4)
         ge = gr['elp'].cpu().numpy().reshape(bb, tm, cm)
         kp = min(k, tm)
         for got, want in ((ge[i, :t], ref['elp'][i, :t]) for i, t in enumerate(p['lengths'])):
@@ -78,5 +78,5 @@ while time.time() - t0 < budget:
         last = time.time()
         print('  ... %d launches, %d with gradients, worst log Z error %.2e, worst gradient error %.2e' % (n, ng, worst_z, worst_g), flush=True)
 print('soak ok: %d log Z launches (%d with the four gradients), %d frames, %.0f s; random / integer / masked -1e9 / masked -inf: %s; '
-      'worst error of log Z %.2e absolute, %.2e relative to max(1, |log Z|) (bar: 1e-4 + 1e-6 |log Z|), of a gradient entry %.2e (bar 2e-5, integer lattices 1e-4; masked lattices %.2e, reported only)'
+      'worst error of log Z %.2e absolute, %.2e relative to max(1, |log Z|) (bar: 1e-4 + 1e-6 |log Z|), of a gradient entry %.2e (bar 2e-5, integer lattices 1e-4; masked lattices %.2e, bar 1e-4)'
       % (n, ng, frames, time.time() - t0, kinds, worst_abs, worst_z, worst_g, worst_gm))

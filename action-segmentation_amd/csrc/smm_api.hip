@@ -931,8 +931,8 @@ static int run_emission(const smm_shape *s, const Staged &st, const float *x, co
                         int first = 0, int count = -1)
 {
     if (!x || !w || !cst || !inv_var || s->d < 1 || (!elp64 && !elp32)) return SMM_ERR_ARG;
-    if ((size_t)((s->d + 15) & ~15) * (st.c_need <= 16 ? 21 : 37) * sizeof(double) > 160 * 1024)
-        return SMM_ERR_UNSUPPORTED;   // the group's weight table must fit the CU's LDS (D <= 640 at 32 states)
+    if (smm_emission_lds_bytes(s->d, st.c_need) > 160 * 1024)
+        return SMM_ERR_UNSUPPORTED;   // the group's weight table must fit the CU's LDS (D <= 544 at 32 states)
     SmmEmArgs a{st.videos, st.order, st.n_states, x, w, cst, inv_var, cons, elp64, elp32, s->d, s->c_max, s->b};
     if (count < 0) smm_launch_emission(a, st.c_need, st.em_tpw, st.em_blocks, st.em_cum, s->total_frames, stream);
     else smm_launch_emission(a, st.c_need, st.em_tpw, st.em_cum_host[first + count] - st.em_cum_host[first], st.em_cum,

@@ -26,6 +26,12 @@
 // enough bytes are in flight: x is fetched in CHUNKS of 4 macro-steps (4 KB per wave) through a 3-deep register
 // pipeline that runs across tile boundaries -- two chunks are always in flight while the third feeds the MFMAs.
 typedef double smm_d4 __attribute__((ext_vector_type(4)));
+// LDS row stride of the weight table (doubles) by the launch's 4-state groups behind the first 16 states: the smallest
+// stride == 4 (mod 8) that holds the 16 + 4 ng columns -- 4 rows apart (the two k groups of a ds_read_b64 half-wave) are then
+// 128 B apart modulo the 256-B bank span.  (Round 5: it was 36 for every class set above 16 states; at D = 300 that is 90 KB
+// and ONE workgroup per CU -- 3.0 TB/s at 23 states where D = 256 runs at 3.7, profiles/round5_emission_d.txt; CrossTask's
+// largest tasks have 23 states: stride 28 = 70 KB leaves two.)
+constexpr int smm_em_row_stride(int ng) { return ng <= 1 ? 20 : (ng <= 3 ? 28 : 36); }
 typedef float smm_f4 __attribute__((ext_vector_type(4)));
 
 #define SMM_EM_WAVES 8
@@ -87,14 +93,14 @@ smm_emission_kernel(const SmmVideo *__restrict__ videos, const int32_t *__restri
     // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
     const int nbv = blk_cum[slot + 1] - blk_cum[slot];
     const int D16 = (D + 15) & ~15;
-    constexpr int WS = (NT == 2) ? 36 : 20;                          // LDS row stride (doubles)
+    constexpr int WS = smm_em_row_stride(NT == 2 ? NG : 0), NC = (NT == 2) ? 16 + 4 * NG : 16;   // LDS row stride, columns filled (doubles)
     const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // more than the first 16-state tile?
     const int ng1 = (NT == 2 && C > 16) ? (C - 13) >> 2 : 0;         // groups of 4 states behind it: ceil((C - 16) / 4)
     double *ivl = wl + (size_t)D16 * WS;
     {
         const double *__restrict__ w = wall + (size_t)g * D * cm;
-        for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
-            const int d = i / (16 * NT), c = i - d * (16 * NT);
+        for (int i = threadIdx.x; i < D16 * NC; i += SMM_EM_WAVES * 64) {
+            const int d = i / NC, c = i - d * NC;
             wl[(size_t)d * WS + c] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
         }
         for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
@@ -315,14 +321,14 @@ smm_emission_pair_kernel(const SmmVideo *__restrict__ videos, const int32_t *__r
     // this video's share of the grid: ~tpw tiles per wave (so short videos do not fill LDS for one tile per wave)
     const int nbv = blk_cum[slot + 1] - blk_cum[slot];
     const int D16 = (D + 15) & ~15;
-    constexpr int WS = (NT == 2) ? 36 : 20;                          // LDS row stride (doubles)
+    constexpr int WS = smm_em_row_stride(NT == 2 ? NG : 0), NC = (NT == 2) ? 16 + 4 * NG : 16;   // LDS row stride, columns filled (doubles)
     const int nt = (NT == 2 && C > 16) ? 2 : 1;                      // more than the first 16-state tile?
     const int ng1 = (NT == 2 && C > 16) ? (C - 13) >> 2 : 0;         // groups of 4 states behind it: ceil((C - 16) / 4)
     double *ivl = wl + (size_t)D16 * WS;
     {
         const double *__restrict__ w = wall + (size_t)g * D * cm;
-        for (int i = threadIdx.x; i < D16 * 16 * NT; i += SMM_EM_WAVES * 64) {
-            const int d = i / (16 * NT), c = i - d * (16 * NT);
+        for (int i = threadIdx.x; i < D16 * NC; i += SMM_EM_WAVES * 64) {
+            const int d = i / NC, c = i - d * NC;
             wl[(size_t)d * WS + c] = (d < D && c < C) ? w[(size_t)d * cm + c] : 0.0;
         }
         for (int d = threadIdx.x; d < D16; d += SMM_EM_WAVES * 64) ivl[d] = (d < D) ? iv[d] : 0.0;
@@ -721,6 +727,12 @@ int smm_emission_tiles_per_wave(int64_t total_frames, int b)
     return (int)(tpw < 1 ? 1 : (tpw > SMM_EM_TILES_PER_WAVE ? SMM_EM_TILES_PER_WAVE : tpw));
 }
 
+size_t smm_emission_lds_bytes(int d, int c_need)
+{
+    const int d16 = (d + 15) & ~15, ng = c_need <= 16 ? 0 : (c_need - 13) >> 2;
+    return sizeof(double) * d16 * (smm_em_row_stride(ng) + 1);
+}
+
 int smm_emission_blocks(int t, int tpw)
 {
     const int tiles = (t + 15) / 16;
@@ -738,7 +750,7 @@ void smm_launch_emission(const SmmEmArgs &a, int ct, int tpw, int n_blocks, cons
     blk_cum += vid0;
     const int d16 = (a.d + 15) & ~15;
     dim3 grid(n_blocks), block(SMM_EM_WAVES * 64);
-    const size_t lds_w = sizeof(double) * d16 * (ct <= 16 ? 21 : 37);        // weights (row stride 20 / 36) + inv_var
+    const size_t lds_w = smm_emission_lds_bytes(a.d, ct);                      // weights (row stride 20 / 28 / 36) + inv_var
     const size_t lds_w2 = sizeof(double) * d16 * (ct <= 16 ? 21 : 33);       // (v2's layout)
     const bool vec = (a.d & 3) == 0;
     // v2 (x staged through LDS in whole lines): row stride == 8 (mod 16) floats, >= D

@@ -29,6 +29,7 @@ int smm_zero_multi_async(void *const *dst_dev, const size_t *bytes, int n, hipSt
 // smm_emission_tiles_per_wave / smm_emission_blocks
 int smm_emission_tiles_per_wave(int64_t total_frames, int b);
 int smm_emission_blocks(int t, int tpw);
+size_t smm_emission_lds_bytes(int d, int c_need);   // LDS of one workgroup: the largest class set's weight table + inv_var
 void smm_launch_emission(const SmmEmArgs &a, int c_need, int tpw, int n_blocks, const int32_t *blk_cum, int64_t total_frames,
                          hipStream_t stream, int blk_base = 0, int vid0 = 0, int nvid = -1);
 void smm_launch_widen(const float *src, double *dst, size_t n, hipStream_t stream);

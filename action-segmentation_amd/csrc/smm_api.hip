@@ -1288,11 +1288,14 @@ extern "C" int smm_decode_f32(const smm_shape *shape, const int64_t *lengths_hos
     // there, while the second stream scores and decodes the rest; the caller's stream waits for it at the end
     const int n1 = st.n_split, n2 = shape->b - st.n_split;
     rc = run_viterbi(shape, st, st.elp, trans, init, len_scores, endpen, class_map, spans, labels, best, n_segs, hs, 0, n1, true, false);
-    if (rc != SMM_OK) return rc;
-    rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs, 0, n1);
-    if (rc != SMM_OK) return rc;
+    if (rc != SMM_OK) { aux_events_put(dev, fj); return rc; }
     const hipEvent_t fork = fj.first, join = fj.second;
     int rc2 = SMM_OK;
+    rc = run_emission(shape, st, x, w, cst, inv_var, cons, st.elp, elp32, hs, 0, n1);
+    if (rc != SMM_OK) { aux_events_put(dev, fj); return rc; }
+    // (the fork sits BEHIND the critical videos' emission on purpose: forked in front of it, the rest's emission workgroups fill
+    // the CUs the critical videos' DP workgroups need -- one per CU, 245 VGPRs -- and that launch starts late: cfg3 2.81 -> 2.89 ms
+    // per step, critical launch 2.31 -> 2.65 ms, three alternating runs on one box, round 5)
     if (hipEventRecord(fork, hs) != hipSuccess || hipStreamWaitEvent(aux, fork, 0) != hipSuccess) rc2 = SMM_ERR_HIP;
 #ifdef SMM_DEV
     const int dbg_split = env().split_debug;                  // (timing experiments: results INCOMPLETE)

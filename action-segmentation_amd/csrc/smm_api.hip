@@ -33,6 +33,7 @@ struct SmmEnv {
     int small_wg = 1;         // SMM_SMALL_WG=0: no four-wave workgroups for <= 16-state videos; 2: wherever they apply, whatever the part's size (tests; same results)
     int chunk = 1;            // SMM_CHUNK=0: no time-split decode of long videos (same results)
     int chunk_p = 0;          // SMM_CHUNK_P: positions per unit of a time-split decode (0: from the launch's CU-time; tests force small ones)
+    int chunk_lmin = 0;       // SMM_CHUNK_LMIN: least own part of a unit (0: SMM_CHUNK_LMIN below; never less than kp - 1 or 130)
     int chunk_wc = 512;       // SMM_CHUNK_WC: warm-up positions of a unit in front of the kp - 1 it is certified on (at most kp)
     int no_bt_window = 0;     // SMM_NO_BT_WINDOW=1: the general back-trace also for kp <= 64 (same results)
     int fit_grid = 0;         // SMM_FIT_GRID: workgroups of the class-sums kernel (tuning aid)
@@ -59,7 +60,7 @@ void env_read()
         {"SMM_SPEC", &e.spec, nullptr}, {"SMM_NO_SPLIT", &e.no_split, nullptr}, {"SMM_SPLIT_MIN_US", nullptr, &e.split_min_us},
         {"SMM_SPLIT_NS", nullptr, &e.split_ns}, {"SMM_SPLIT_MARGIN", &e.split_margin, nullptr},
         {"SMM_PLAN_CACHE", &e.plan_cache, nullptr}, {"SMM_SMALL_WG", &e.small_wg, nullptr}, {"SMM_CHUNK", &e.chunk, nullptr}, {"SMM_CHUNK_P", &e.chunk_p, nullptr},
-        {"SMM_CHUNK_WC", &e.chunk_wc, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
+        {"SMM_CHUNK_WC", &e.chunk_wc, nullptr}, {"SMM_CHUNK_LMIN", &e.chunk_lmin, nullptr}, {"SMM_NO_BT_WINDOW", &e.no_bt_window, nullptr},
         {"SMM_FIT_GRID", &e.fit_grid, nullptr}, {"SMM_VERBOSE", &e.verbose, nullptr},
 #ifdef SMM_DEV
         {"SMM_DEBUG_FLAGS", &e.debug_flags, nullptr}, {"SMM_SPLIT_DEBUG", &e.split_debug, nullptr},
@@ -249,6 +250,7 @@ struct SmmPlan {
 // Upper bounds of a time-split plan (the workspace is sized before anything is planned): a unit's own part is never shorter
 // than SMM_CHUNK_LMIN positions, so a video of T frames has at most T / SMM_CHUNK_LMIN + 1 units
 constexpr int SMM_CHUNK_LMIN = 512;                 // ... or 2 kp where that is less (kp > 64: at least 130)
+constexpr int SMM_CHUNK_LMIN_FINE = 384;            // (plan_chunks: where one more unit per video still fits one round of workgroups)
 static size_t chunk_units_max(const smm_shape *s) { return (size_t)(s->total_frames / 128) + 2 * (size_t)s->b; }
 static size_t chunk_ext_meta_bytes(size_t b, size_t units, size_t n_cv)
 {
@@ -640,7 +642,7 @@ struct ChunkPlan {
     std::vector<SmmChunkVideo> cvs;
 };
 
-static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out, int n_cu_given = 0)
+static void plan_chunks_lmin(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out, int n_cu_given, int lmin_cfg)
 {
     const SmmEnv &ev = env();
     if (!ev.chunk || (s->flags & (SMM_SHAPE_NO_EOS | SMM_SHAPE_NO_TIME_SPLIT)) || kp_max <= 64) return;      // (kp <= 64: the window back-trace's launches are left alone)
@@ -668,7 +670,7 @@ static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n
         const int T = hv[i].T, C = n_states[hv[i].group], kpv = hv[i].kp;
         // warm-up: the recursion forgets its start behind the next segment boundary, and a segment is shorter than kp
         const int ov = std::max(std::min(ev.chunk_wc, kpv), 16) + kpv - 1;
-        const int lmin = std::max(kpv - 1, std::min(SMM_CHUNK_LMIN, 2 * kpv));
+        const int lmin = std::max(kpv - 1, std::min(lmin_cfg, 2 * kpv));
         const int pmin = ov + lmin;
         // positions per unit: what the launch's CU-time lasts on this video's state count (+ 10 %), at least pmin
         int P = ev.chunk_p > 0 ? ev.chunk_p : (int)(1.1 * t_cu / ns(C));
@@ -704,6 +706,21 @@ static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n
         }
         out.cvs.push_back(cv);
     }
+}
+
+// The least own part of a unit: SMM_CHUNK_LMIN, or the finer SMM_CHUNK_LMIN_FINE where the launch then still runs in ONE round of
+// workgroups (units + unsplit videos <= CUs).  cfg2 (64 videos x 2048 frames, K = 256): four units per video on 256 CUs instead of
+// three on 192, 0.378 -> 0.369 ms per step, two alternating runs on one box; five or six units per video (320 / 384 workgroups, a
+// second round): 0.49-0.50 ms.  SMM_CHUNK_LMIN (environment) overrides both.
+static void plan_chunks(const smm_shape *s, const SmmVideo *hv, const int32_t *n_states, int kp_max, bool band, ChunkPlan &out, int n_cu_given = 0)
+{
+    const SmmEnv &ev = env();
+    if (ev.chunk_lmin > 0) { plan_chunks_lmin(s, hv, n_states, kp_max, band, out, n_cu_given, std::max(ev.chunk_lmin, 130)); return; }
+    const int n_cu = n_cu_given > 0 ? n_cu_given : device_cus();
+    ChunkPlan fine;
+    plan_chunks_lmin(s, hv, n_states, kp_max, band, fine, n_cu_given, SMM_CHUNK_LMIN_FINE);
+    if (!fine.cvs.empty() && (int)fine.units.size() + (s->b - (int)fine.cvs.size()) <= n_cu) { out = std::move(fine); return; }
+    plan_chunks_lmin(s, hv, n_states, kp_max, band, out, n_cu_given, SMM_CHUNK_LMIN);
 }
 
 static int stage_uncached(const smm_shape *s, const int64_t *lengths, const int64_t *frame_off, const int32_t *group,

@@ -205,9 +205,13 @@ def test_time_split_plan_layout(monkeypatch):
         assert f1 + o1 == e0                                  # a unit's own part begins where the previous unit ends
         assert n1 - o1 >= 1 and (f1 + n1 == 10000 or n1 - o1 >= 1023)
     assert max(n for _, _, n, _ in u) - min(n for _, _, n, _ in u[:-1]) <= 1
-    # cfg2: 64 x 2048 at K = 256 -> three units each; a launch with three videos per CU: none; hard masks: none; K <= 64: none
+    # cfg2: 64 x 2048 at K = 256 -> FOUR units each (256 workgroups on 256 CUs: one round); 80 such videos -> three each (a fourth
+    # would make 320 workgroups, a second round); a launch with three videos per CU: none; hard masks: none; K <= 64: none
     u = units_of([2048] * 64, 16, 256)
-    assert len(u) == 3 * 64 and all(o in (0, 256 + 255) for _, _, _, o in u)
+    assert len(u) == 4 * 64 and all(o in (0, 256 + 255) for _, _, _, o in u)
+    assert all(n - o >= 384 or f + n == 2048 for _, f, n, o in u)          # (own parts: the floor of the fine plan; the last takes what is left)
+    u = units_of([2048] * 80, 16, 256)
+    assert len(u) == 3 * 80 and all(n - o >= 511 for _, _, n, o in u)
     assert units_of([6000] * 800, 16, 1024) == []
     assert units_of([10000], 20, 1024, no_time_split=True) == []
     assert units_of([2048] * 8, 12, 64) == []

@@ -166,7 +166,8 @@ double smm_band_frame_ns(int n_states);
  * libsmmdp call is in flight on any stream, and no hipGraph captured from a call will be replayed afterwards (a captured
  * call points at its plan's buffer).  smm_cached_plan_bytes: device bytes currently held by resident plans.
  * smm_env_reload: read the SMM_* tuning switches from the environment again (they are read once, at first use:
- * SMM_SPEC, SMM_NO_SPLIT, SMM_SPLIT_MIN_US / _NS / _MARGIN, SMM_PLAN_CACHE, SMM_NO_BT_WINDOW, SMM_FIT_GRID, SMM_VERBOSE --
+ * SMM_SPEC, SMM_NO_SPLIT, SMM_SPLIT_MIN_US / _NS / _MARGIN, SMM_PLAN_CACHE, SMM_NO_BT_WINDOW, SMM_FIT_GRID, SMM_SMALL_WG,
+ * SMM_CHUNK, SMM_CHUNK_P / _WC / _LMIN, SMM_VERBOSE --
  * none of them changes a result; switches that do exist only in -DSMM_DEV builds of the library).
  */
 size_t smm_release_cached_plans(void);

@@ -40,92 +40,138 @@
 
 // ------------------------------------------------------------------------------------------------ serial prefix sums
 // cumE[a_j][c] for every unit j >= 1 of one split video: cum = 0; cum = cum + elp[n][c], n = 0, 1, ... in THIS order (the
-// unsplit kernel's mover wave and chain wave do exactly these additions).  One workgroup per split video: eight waves
-// stream 64 rows each into LDS (512 rows per round trip -- a single wave would wait ~1.5 us for every 64 rows), wave 0
-// adds them up, one lane per state, while the next 512 rows are in flight.
+// unsplit kernel's mover wave and chain wave do exactly these additions).  One workgroup per split video: wave 0 adds, one
+// lane per state -- one dependent chain of fp64 additions, ~5 cycles each, the kernel's floor -- and waves 1..7 feed it: rounds
+// of 256 rows, fetched THREE rounds ahead into registers (a round trip to HBM is ~2 us, a round of additions 0.6), written
+// transposed into one of TWO LDS tiles while wave 0 adds the other up; one barrier per round.  (The first version of this
+// kernel had one tile of 512 rows and every wave both fetching and waiting -- load, barrier, add, barrier, store per round:
+// cfg1's 7 400 rows took 81 us; this one 60.  Ablation builds, same box: without the additions 37 us, without the loads 55,
+// six rounds in flight instead of three 60: the two roles' times ADD UP although they run side by side -- the producers'
+// transposed LDS writes and the adder's LDS reads share the CU's one LDS pipeline -- and the HBM latency is covered.)
 #define SMM_ANCH_WAVES 8
-#define SMM_ANCH_ROWS 64                          // rows per wave and round
+#ifndef SMM_ANCH_ROWS
+#define SMM_ANCH_ROWS 256                         // rows per round
+#endif
+#ifndef SMM_ANCH_PD
+#define SMM_ANCH_PD 3                             // rounds in flight in the producers' registers
+#endif
+// NE: elements per producer lane and round, >= 256 c_max / 448 (10 / 14 / 19 for c_max <= 16 / 24 / 32); PD: rounds in flight in the
+// producers' registers
+template <int NE, int PD>
 __global__ void __launch_bounds__(SMM_ANCH_WAVES * 64)
 smm_cum_anchor_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, double *anchors)
 {
-    extern __shared__ __attribute__((aligned(16))) double tile[];       // TRANSPOSED: [cm][RPT + 2] -- a state's rows of a round are contiguous
+    extern __shared__ __attribute__((aligned(16))) double tile[];       // [2][cm][RB + 2], TRANSPOSED: a state's rows of a round are contiguous
     const SmmChunkVideo cv = cvs[blockIdx.x];
     const SmmVideo pv = a.videos[cv.vid];
     const int cm = a.c_max, C = a.n_states[pv.group];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const double *elp = a.elp + (size_t)pv.frame_off * cm;
     const int n_end = a.videos[cv.first_unit + cv.n_chunks - 1].pad >> 2;    // the last unit's first position: nothing is needed beyond
-    constexpr int RPT = SMM_ANCH_WAVES * SMM_ANCH_ROWS;                       // rows per round
-    constexpr int TS = RPT + 2;                                               // doubles per state of the transposed tile (16-byte rows, odd multiple of 16 B: no bank pile-up)
-    const int per_lane = (SMM_ANCH_ROWS * cm + 63) / 64;                      // elements per lane of a wave's slab (<= 32)
-    double reg[32];
-    auto fetch = [&](int row0) {                                              // this wave's slab of the round that starts at row0
-        const int64_t e0 = (int64_t)(row0 + w * SMM_ANCH_ROWS) * cm, e_max = (int64_t)n_end * cm - 1;
+    constexpr int RB = SMM_ANCH_ROWS;
+    constexpr int TS = RB + 2;                                                // doubles per state of a tile (16-byte rows, odd multiple of 16 B)
+    constexpr int NP = (SMM_ANCH_WAVES - 1) * 64;                             // producer lanes
+    const int n_rounds = (n_end + RB - 1) / RB;
+    const size_t tile_doubles = (size_t)cm * TS;
+    const int pl = (int)threadIdx.x - 64;                                     // producer lane id (waves 1..7)
+    const int64_t e_max = (int64_t)n_end * cm - 1;
+    double reg[PD][NE];
+    auto fetch = [&](int round, double (&dst)[NE]) {
+        const int64_t e0 = (int64_t)round * RB * cm;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            if (q < per_lane) {
-                int64_t e = e0 + lane + 64 * q;
-                reg[q] = elp[e <= e_max ? e : e_max];                         // (clamped: rows beyond n_end are never added)
-            }
+        for (int q = 0; q < NE; ++q) {
+            const int e = pl + NP * q;
+            const int64_t eg = e0 + e;
+            dst[q] = elp[(e < RB * cm && eg <= e_max) ? eg : e_max];          // (clamped: rows beyond n_end are never added)
+        }
+    };
+    auto park = [&](int round, const double (&src)[NE]) {
+        double *t = tile + (size_t)(round & 1) * tile_doubles;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = pl + NP * q;
+            if (e < RB * cm) t[(size_t)(e % cm) * TS + e / cm] = src[q];
         }
     };
     double cum = 0.0;
     int next_unit = 1;
     int next_at = a.videos[cv.first_unit + 1].pad >> 2;
-    fetch(0);
-    for (int row0 = 0; row0 < n_end; row0 += RPT) {
-        // (element e of the wave's slab = row e / cm, state e % cm; two rows of a state per 16-byte LDS read in the sum below)
+    // Two roles, two loops, the same n_rounds + 1 barriers in both (every wave is in one role for good: the producers' registers
+    // and the adder's do not share a live range).  Iteration i: the producers park round i (fetched PD iterations ago) and fetch
+    // round i + PD into the registers it leaves; wave 0 adds round i - 1 up from the other tile.  A tile is written again two
+    // iterations after it was read.
+    if (w > 0) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int e = lane + 64 * q;
-            if (q < per_lane && e < SMM_ANCH_ROWS * cm) tile[(size_t)(e % cm) * TS + w * SMM_ANCH_ROWS + e / cm] = reg[q];
-        }
-        __syncthreads();
-        if (row0 + RPT < n_end) fetch(row0 + RPT);                            // in flight while wave 0 adds this round up
-        if (w == 0 && lane < C) {
-            const int rows = (n_end - row0 < RPT) ? n_end - row0 : RPT;
-            const double *col = tile + (size_t)lane * TS;
-            const double2 *col2 = reinterpret_cast<const double2 *>(col);
-            int r = 0;
-            while (r < rows) {
-                // cumE[n] = sum of the rows before n: the anchor of a unit that starts at n is taken BEFORE row n is added
-                if (row0 + r == next_at) {
-                    anchors[(size_t)(cv.first_unit - a.b_videos + next_unit) * cm + lane] = cum;
-                    ++next_unit;
-                    next_at = next_unit < cv.n_chunks ? (a.videos[cv.first_unit + next_unit].pad >> 2) : 0x7fffffff;
-                }
-                // ... then straight on to the next anchor or the end of the round.  The additions are one dependent chain
-                // (~6 cycles each); the LDS reads run ahead of it, sixteen 16-byte reads (32 rows) in flight
-                const int stop = (next_at - row0 < rows) ? next_at - row0 : rows;
-                if (r & 1) { cum = cum + col[r]; ++r; if (r >= stop) continue; }
-                if (r + 32 <= stop) {
-                    double2 v[16];
+        for (int q = 0; q < PD; ++q)
+            if (q < n_rounds) fetch(q, reg[q]);
+        for (int i0 = 0; i0 <= n_rounds; i0 += PD) {
+            // (unrolled over the register sets: a set chosen by a run-time index would live in scratch)
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = col2[(r >> 1) + u];
-                    for (; r + 64 <= stop; r += 32) {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            cum = cum + v[u].x;
-                            cum = cum + v[u].y;
-                            v[u] = col2[((r + 32) >> 1) + u];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        cum = cum + v[u].x;
-                        cum = cum + v[u].y;
-                    }
-                    r += 32;
-                }
-                for (; r + 2 <= stop; r += 2) {
-                    const double2 v = col2[r >> 1];
-                    cum = cum + v.x;
-                    cum = cum + v.y;
-                }
-                if (r < stop) { cum = cum + col[r]; ++r; }
+            for (int q = 0; q < PD; ++q) {
+                const int i = i0 + q;
+                if (i > n_rounds) break;
+                if (i < n_rounds) { park(i, reg[q]); if (i + PD < n_rounds) fetch(i + PD, reg[q]); }
+                __syncthreads();
             }
         }
-        __syncthreads();
+    } else {
+        for (int i = 0; i <= n_rounds; ++i) {
+            if (i >= 1 && lane < C) {
+                const int row0 = (i - 1) * RB;
+                const int rows = (n_end - row0 < RB) ? n_end - row0 : RB;
+                const double *col = tile + (size_t)((i - 1) & 1) * tile_doubles + (size_t)lane * TS;
+                const double2 *col2 = reinterpret_cast<const double2 *>(col);
+                int r = 0;
+                while (r < rows) {
+                    // cumE[n] = sum of the rows before n: the anchor of a unit that starts at n is taken BEFORE row n is added
+                    if (row0 + r == next_at) {
+                        anchors[(size_t)(cv.first_unit - a.b_videos + next_unit) * cm + lane] = cum;
+                        ++next_unit;
+                        next_at = next_unit < cv.n_chunks ? (a.videos[cv.first_unit + next_unit].pad >> 2) : 0x7fffffff;
+                    }
+                    // ... then straight on to the next anchor or the end of the round.  The additions are one dependent chain; the
+                    // LDS reads run ahead of it, sixteen 16-byte reads (32 rows) in flight
+                    const int stop = (next_at - row0 < rows) ? next_at - row0 : rows;
+                    if (r & 1) { cum = cum + col[r]; ++r; if (r >= stop) continue; }
+                    // (batches of 32 rows in TWO register sets: the reads of the next batch are issued in front of this batch's
+                    // additions -- with one set, each read waits for the addition that frees its register and the chain then waits
+                    // an LDS round trip per batch)
+                    const int nb = (stop - r) >> 5;
+                    if (nb >= 1) {
+                        double2 va[16], vb[16];
+                        const double2 *p = col2 + (r >> 1);
+    #pragma unroll
+                        for (int u = 0; u < 16; ++u) va[u] = p[u];
+                        for (int b = 0; b < nb; b += 2) {
+                            if (b + 1 < nb) {
+    #pragma unroll
+                                for (int u = 0; u < 16; ++u) vb[u] = p[16 * (b + 1) + u];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                            for (int u = 0; u < 16; ++u) { cum = cum + va[u].x; cum = cum + va[u].y; }
+                            if (b + 1 < nb) {
+                                if (b + 2 < nb) {
+    #pragma unroll
+                                    for (int u = 0; u < 16; ++u) va[u] = p[16 * (b + 2) + u];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                                for (int u = 0; u < 16; ++u) { cum = cum + vb[u].x; cum = cum + vb[u].y; }
+                            }
+                        }
+                        r += 32 * nb;
+                    }
+                    for (; r + 2 <= stop; r += 2) {
+                        const double2 v = col2[r >> 1];
+                        cum = cum + v.x;
+                        cum = cum + v.y;
+                    }
+                    if (r < stop) { cum = cum + col[r]; ++r; }
+                }
+            }
+            __syncthreads();
+        }
     }
     // (a unit that starts exactly at n_end: the loop above ends before row n_end)
     if (w == 0 && lane < C && next_unit < cv.n_chunks && next_at == n_end)
@@ -503,15 +549,20 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
 
 void smm_launch_cum_anchors(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, double *anchors, hipStream_t stream)
 {
-    const size_t lds = sizeof(double) * (SMM_ANCH_WAVES * SMM_ANCH_ROWS + 2) * (size_t)a.c_max;
-    static bool raised[64] = {};
+    const size_t lds = sizeof(double) * 2 * (SMM_ANCH_ROWS + 2) * (size_t)a.c_max;                  // two tiles
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(smm_cum_anchor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-        raised[dev] = true;
-    }
-    hipLaunchKernelGGL(smm_cum_anchor_kernel, dim3(n_split), dim3(SMM_ANCH_WAVES * 64), lds, stream, a, cvs, anchors);
+    auto go = [&](auto kern, bool *raised) {
+        if (!raised[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+            raised[dev] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_split), dim3(SMM_ANCH_WAVES * 64), lds, stream, a, cvs, anchors);
+    };
+    static bool r10[64] = {}, r14[64] = {}, r19[64] = {};
+    if (a.c_max <= 16) go(smm_cum_anchor_kernel<(SMM_ANCH_ROWS * 16 + 447) / 448 + 0, SMM_ANCH_PD>, r10);
+    else if (a.c_max <= 24) go(smm_cum_anchor_kernel<(SMM_ANCH_ROWS * 24 + 447) / 448, SMM_ANCH_PD>, r14);
+    else go(smm_cum_anchor_kernel<(SMM_ANCH_ROWS * 32 + 447) / 448, SMM_ANCH_PD>, r19);
 }
 
 void smm_launch_chunk_stitch(const SmmDpArgs &a, const SmmChunkVideo *cvs, int n_split, int32_t *redo, hipStream_t stream)

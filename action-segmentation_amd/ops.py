@@ -289,8 +289,9 @@ def factor_tables_bwd(meta, poisson_log_rates, gaussian_means, gaussian_cov, tra
     lib = _lib.load()
     dev, f64, f32 = trans.device, torch.float64, torch.float32
     n, d = meta.n, meta.d
-    out = (torch.empty(n, dtype=f64, device=dev), torch.empty((n, n), dtype=f64, device=dev),
-           torch.empty(n, dtype=f64, device=dev), torch.empty((n, d), dtype=f64, device=dev))
+    # (one flat buffer, four views: the caller converts the gradients to the parameters' dtype in ONE launch -- flat_of)
+    flat = torch.empty(2 * n + n * n + n * d, dtype=f64, device=dev)
+    out = (flat[:n], flat[n:n + n * n].view(n, n), flat[n + n * n:2 * n + n * n], flat[2 * n + n * n:].view(n, d))
     _lib.check(lib.smm_factor_tables_bwd_f64(
         ctypes.byref(meta.shape), _dev(poisson_log_rates, f32, 'poisson_log_rates'), _dev(gaussian_means, f32, 'gaussian_means'),
         _dev(gaussian_cov, f32, 'gaussian_cov'), _u8(init_constraints, 'init_constraints'),
@@ -300,7 +301,7 @@ def factor_tables_bwd(meta, poisson_log_rates, gaussian_means, gaussian_cov, tra
         _dev(g_len, f64, 'g_len'), _dev(g_w_class_major, f64, 'g_w'), _dev(g_cst, f64, 'g_cst'),
         _dev(out[0], f64, 'g_init_logits'), _dev(out[1], f64, 'g_transition_logits'), _dev(out[2], f64, 'g_poisson_log_rates'),
         _dev(out[3], f64, 'g_gaussian_means'), _stream()))
-    return out
+    return out + (flat,)
 
 
 def viterbi(batch, elp, trans, init, len_scores, endpen=None, class_map=None, want_spans=True, want_labels=True,

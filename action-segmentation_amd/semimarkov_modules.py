@@ -93,10 +93,12 @@ class _FactorTables(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         # the emission chain rule hands g_w over as a transposed view of its class-major buffer: undo the view
         g_w_cm = None if g_w is None else g_w.transpose(1, 2).contiguous()
-        gi, gt, gr, gm = ops.factor_tables_bwd(ctx.meta, log_rates, means, cov, trans, init, cont(g_trans), cont(g_init),
-                                               cont(g_len), g_w_cm, cont(g_cst), ctx.init_cons, ctx.trans_cons)
-        f32 = torch.float32
-        return None, None, None, gi.to(f32), gt.to(f32), gr.to(f32), gm.to(f32), None
+        gi, gt, gr, gm, flat = ops.factor_tables_bwd(ctx.meta, log_rates, means, cov, trans, init, cont(g_trans), cont(g_init),
+                                                     cont(g_len), g_w_cm, cont(g_cst), ctx.init_cons, ctx.trans_cons)
+        # the four gradients are views of one fp64 buffer: one conversion launch for all of them
+        f = flat.to(torch.float32)
+        n, d = gi.numel(), gm.size(1)
+        return (None, None, None, f[:n], f[n:n + n * n].view(n, n), f[n + n * n:2 * n + n * n], f[2 * n + n * n:].view(n, d), None)
 
 
 class SemiMarkovModule(nn.Module):
@@ -934,17 +936,17 @@ class SemiMarkovModule(nn.Module):
         """Per source batch the mean log-likelihood the reference's ``log_likelihood(spans=None)`` returns for it
         (semimarkov_modules.py:657: ``dist.partition.mean()``): fp64 [n_batches], differentiable."""
         z = self.log_partition_packed(pc)
-        bi = getattr(pc, '_batch_index_dev', None)
-        if bi is None or bi.device != z.device:
-            bi = pc._batch_index_dev = torch.as_tensor(pc.batch_index, device=z.device)
-        nb = int(max(pc.batch_index)) + 1
-        sums = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, z)
-        # (videos per source batch: a property of the packed corpus, made once -- three launches less per training step)
-        inv = getattr(pc, '_batch_inv_count_dev', None)
-        if inv is None or inv.device != z.device or inv.dtype != z.dtype:
+        # the means per source batch as ONE product with a [n_batches, n_videos] matrix of 1 / count entries -- a property of the
+        # packed corpus, made once (a zero fill, an index_add and a multiplication each way before: six launches per training step)
+        mean_of = getattr(pc, '_batch_mean_matrix_dev', None)
+        if mean_of is None or mean_of.device != z.device or mean_of.dtype != z.dtype:
+            bi = torch.as_tensor(pc.batch_index, device=z.device)
+            nb = int(max(pc.batch_index)) + 1
             cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
-            inv = pc._batch_inv_count_dev = (1.0 / cnt).detach()
-        return sums * inv
+            mean_of = torch.zeros((nb, z.numel()), dtype=z.dtype, device=z.device)
+            mean_of[bi, torch.arange(z.numel(), device=z.device)] = (1.0 / cnt)[bi]
+            pc._batch_mean_matrix_dev = mean_of.detach()
+        return torch.mv(mean_of, z)
 
     def log_likelihood(self, features, lengths, valid_classes_per_instance, spans=None, add_eos=True, use_mean_z=False,
                        additional_allowed_ends_per_instance=None, constraints=None):

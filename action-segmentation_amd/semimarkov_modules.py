@@ -938,10 +938,20 @@ class SemiMarkovModule(nn.Module):
         z = self.log_partition_packed(pc)
         # the means per source batch as ONE product with a [n_batches, n_videos] matrix of 1 / count entries -- a property of the
         # packed corpus, made once (a zero fill, an index_add and a multiplication each way before: six launches per training step)
+        nb = int(max(pc.batch_index)) + 1
+        if nb * z.numel() > (1 << 22):
+            # (a corpus of many thousands of videos: the dense matrix would be tens of megabytes and more; the sums by index)
+            bi = getattr(pc, '_batch_index_dev', None)
+            if bi is None or bi.device != z.device:
+                bi = pc._batch_index_dev = torch.as_tensor(pc.batch_index, device=z.device)
+            inv = getattr(pc, '_batch_inv_count_dev', None)
+            if inv is None or inv.device != z.device or inv.dtype != z.dtype:
+                cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
+                inv = pc._batch_inv_count_dev = (1.0 / cnt).detach()
+            return torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, z) * inv
         mean_of = getattr(pc, '_batch_mean_matrix_dev', None)
         if mean_of is None or mean_of.device != z.device or mean_of.dtype != z.dtype:
             bi = torch.as_tensor(pc.batch_index, device=z.device)
-            nb = int(max(pc.batch_index)) + 1
             cnt = torch.zeros(nb, dtype=z.dtype, device=z.device).index_add(0, bi, torch.ones_like(z))
             mean_of = torch.zeros((nb, z.numel()), dtype=z.dtype, device=z.device)
             mean_of[bi, torch.arange(z.numel(), device=z.device)] = (1.0 / cnt)[bi]

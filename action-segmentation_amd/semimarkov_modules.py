@@ -42,6 +42,9 @@ def sliding_sum(inputs, k):
     return out
 
 
+BATCH_MEAN_DENSE_MAX = 1 << 22     # log_likelihood_packed: entries of the [batches, videos] mean matrix; beyond that, sums by index
+
+
 class _LogPartition(torch.autograd.Function):
     """log Z of every video of one launch as a differentiable function of the fp64 factor tables (emission factors w,
     cst; transition, initial and length tables; stacked per parameter group).  Forward: smm_emission_f64 +
@@ -939,7 +942,7 @@ class SemiMarkovModule(nn.Module):
         # the means per source batch as ONE product with a [n_batches, n_videos] matrix of 1 / count entries -- a property of the
         # packed corpus, made once (a zero fill, an index_add and a multiplication each way before: six launches per training step)
         nb = int(max(pc.batch_index)) + 1
-        if nb * z.numel() > (1 << 22):
+        if nb * z.numel() > BATCH_MEAN_DENSE_MAX:
             # (a corpus of many thousands of videos: the dense matrix would be tens of megabytes and more; the sums by index)
             bi = getattr(pc, '_batch_index_dev', None)
             if bi is None or bi.device != z.device:

@@ -169,11 +169,15 @@ def test_cli_supervised_gradient_training_stops_on_dev(tmp_path, capsys):
     assert 'best dev mof' in capsys.readouterr().out
 
 
-@pytest.mark.parametrize('constrain', [False, True])
-def test_packed_log_likelihood_equals_per_batch(constrain):
+@pytest.mark.parametrize('constrain,by_index', [(False, False), (True, False), (False, True)])
+def test_packed_log_likelihood_equals_per_batch(constrain, by_index, monkeypatch):
     """One launch for many single-task batches (log_likelihood_packed) == the reference's batch-by-batch calls: the
-    per-batch values and the gradient of their mean (what --batch_accumulation forms) agree to 1e-9."""
+    per-batch values and the gradient of their mean (what --batch_accumulation forms) agree to 1e-9.  by_index: the per-batch
+    means the way very large corpora take them (sums by index instead of one product with a dense matrix)."""
     from action_segmentation_amd.batching import pack_batches
+    from action_segmentation_amd import semimarkov_modules
+    if by_index:
+        monkeypatch.setattr(semimarkov_modules, 'BATCH_MEAN_DENSE_MAX', 0)
     data = synth.SynthDatasplit('tiny', seed=12)
     narr = ['train'] if constrain else []
     args = synth.make_args(data.max_k, cuda=True, batch_size=2, sm_constrain_transitions=constrain,

@@ -212,7 +212,7 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
     const int nu = cv.n_chunks;
 
     __shared__ int sh_bad;
-    __shared__ double sh_dref;
+    __shared__ double sh_dref[SMM_CHUNK_MAX_UNITS];
     __shared__ unsigned sh_kmin[2], sh_near[2], sh_nlo[2], sh_nhi[2];   // (two sets, used in turn: see decide)
     __shared__ int sh_tie_s2[SMM_STITCH_MAXSEG];
     __shared__ double sh_tie_c2[SMM_STITCH_MAXSEG];
@@ -247,60 +247,67 @@ smm_chunk_stitch_kernel(SmmDpArgs a, const SmmChunkVideo *cvs, int32_t *redo)
     auto u_gam = [&](int j) { return a.hist + sh_uoff[j] + (size_t)2 * C * (sh_ut[j] + 1); };
 
     // ---------------------------------------------------------------------------------------------- certify the cuts
-    for (int j = 1; j < nu; ++j) {
+    // Two passes with ONE barrier between them (the cuts are independent of each other; one after the other, each behind two
+    // barriers and two dependent trips to the histories, they took ~3 us a cut).  Pass 1: wave w takes the cuts w + 1, w + 1 + waves,
+    // ...: the reference difference of a cut = h(unit j) - h(unit j - 1) at r for the state that leads h there in unit j.
+    const int n_waves = (int)blockDim.x >> 6;
+    for (int j = 1 + w; j < nu; j += n_waves) {
         const int r = u_a(j) + cv.ov;                             // unit j's own part begins behind r = the end of unit j-1
         const int a1 = u_a(j), a0 = u_a(j - 1), t1 = u_t(j), t0 = u_t(j - 1);
         const double *h1 = u_h(j), *h0 = u_h(j - 1);
-        const double *c1 = u_cum(j), *c0 = u_cum(j - 1);
-        if (r != a0 + t0 || r - (kp - 1) - a1 < 1) { if (threadIdx.x == 0) sh_bad = 16; break; }   // (the host's layout: never)
-        // the reference difference: the state that leads h at r in unit j
-        if (w == 0) {
-            double v = (lane < C) ? h1[(size_t)lane * (t1 + 1) + (r - a1)] : SMM_NEG_INF;
-            const double v0 = (lane < C) ? h0[(size_t)lane * (t0 + 1) + (r - a0)] : SMM_NEG_INF;
-            if (!(smm_finite_bits(v) && smm_finite_bits(v0))) v = SMM_NEG_INF;
-            double m = v;
-            int mc = lane;
+        if (r != a0 + t0 || r - (kp - 1) - a1 < 1) { if (lane == 0) sh_bad = 16; continue; }   // (the host's layout: never)
+        double v = (lane < C) ? h1[(size_t)lane * (t1 + 1) + (r - a1)] : SMM_NEG_INF;
+        const double v0 = (lane < C) ? h0[(size_t)lane * (t0 + 1) + (r - a0)] : SMM_NEG_INF;
+        if (!(smm_finite_bits(v) && smm_finite_bits(v0))) v = SMM_NEG_INF;
+        double m = v;
+        int mc = lane;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double m2 = __shfl_xor(m, off);
-                const int c2 = __shfl_xor(mc, off);
-                if (m2 > m || (m2 == m && c2 < mc)) { m = m2; mc = c2; }
-            }
-            const double d = smm_readlane(v, mc) - smm_readlane(v0, mc);
-            if (lane == 0) { sh_dref = d; if (!smm_finite_bits(d) || m == SMM_NEG_INF) sh_bad = 1; }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double m2 = __shfl_xor(m, off);
+            const int c2 = __shfl_xor(mc, off);
+            if (m2 > m || (m2 == m && c2 < mc)) { m = m2; mc = c2; }
         }
-        __syncthreads();
-        const double dref = sh_dref;
-        const double cscale = fabs(c1[(size_t)(r - a1) * C]);     // the magnitude of the prefix sums there
+        const double d = smm_readlane(v, mc) - smm_readlane(v0, mc);
+        if (lane == 0) { sh_dref[j] = d; if (!smm_finite_bits(d) || m == SMM_NEG_INF) sh_bad = 1; }
+    }
+    __syncthreads();
+    // Pass 2: every thread checks ITS position of every cut (r - (kp - 1) .. r: one per thread, kp <= the workgroup), the states in
+    // batches of eight with all sixteen loads of a batch in flight (h is state-major: consecutive threads read consecutive
+    // doubles); nothing waits between the cuts.
+    if (!sh_bad) {
         int bad = 0;
-        // positions r - (kp - 1) .. r: one per thread (kp <= 1024 = the workgroup), the states in batches of eight with all
-        // sixteen loads of a batch in flight (h is state-major: consecutive threads read consecutive doubles)
-        const int s = r - (kp - 1) + (int)threadIdx.x;
-        if ((int)threadIdx.x < kp) {
-            for (int cb = 0; cb < C; cb += 8) {
-                double x1[8], x0[8];
+        for (int j = 1; j < nu; ++j) {
+            const int r = u_a(j) + cv.ov;
+            const int a1 = u_a(j), a0 = u_a(j - 1), t1 = u_t(j), t0 = u_t(j - 1);
+            const double *h1 = u_h(j), *h0 = u_h(j - 1);
+            const double *c1 = u_cum(j), *c0 = u_cum(j - 1);
+            const double dref = sh_dref[j];
+            const double cscale = fabs(c1[(size_t)(r - a1) * C]);     // the magnitude of the prefix sums there
+            const int s = r - (kp - 1) + (int)threadIdx.x;
+            if ((int)threadIdx.x < kp) {
+                for (int cb = 0; cb < C; cb += 8) {
+                    double x1[8], x0[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c = cb + q < C ? cb + q : C - 1;
-                    x1[q] = h1[(size_t)c * (t1 + 1) + (s - a1)];
-                    x0[q] = h0[(size_t)c * (t0 + 1) + (s - a0)];
-                }
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = cb + q < C ? cb + q : C - 1;
+                        x1[q] = h1[(size_t)c * (t1 + 1) + (s - a1)];
+                        x0[q] = h0[(size_t)c * (t0 + 1) + (s - a0)];
+                    }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const bool f1 = smm_finite_bits(x1[q]), f0 = smm_finite_bits(x0[q]);
-                    if (f1 != f0) { bad = 1; continue; }              // -inf on one side only (or a NaN)
-                    if (!f1) { if (smm_nan_bits(x1[q]) || smm_nan_bits(x0[q]) || x1[q] != x0[q]) bad = 1; continue; }
-                    const double tol = 0x1p-32 * (fabs(x1[q]) + fabs(x0[q]) + cscale + 1.0);
-                    if (!(fabs((x1[q] - x0[q]) - dref) <= tol)) bad = 1;
+                    for (int q = 0; q < 8; ++q) {
+                        const bool f1 = smm_finite_bits(x1[q]), f0 = smm_finite_bits(x0[q]);
+                        if (f1 != f0) { bad = 1; continue; }              // -inf on one side only (or a NaN)
+                        if (!f1) { if (smm_nan_bits(x1[q]) || smm_nan_bits(x0[q]) || x1[q] != x0[q]) bad = 1; continue; }
+                        const double tol = 0x1p-32 * (fabs(x1[q]) + fabs(x0[q]) + cscale + 1.0);
+                        if (!(fabs((x1[q] - x0[q]) - dref) <= tol)) bad = 1;
+                    }
                 }
             }
+            // the prefix sums of the two units are the same additions: the same bits
+            for (int e = threadIdx.x; e < C; e += blockDim.x)
+                if (__double_as_longlong(c1[(size_t)(r - a1) * C + e]) != __double_as_longlong(c0[(size_t)(r - a0) * C + e])) bad = 1;
         }
-        // the prefix sums of the two units are the same additions: the same bits
-        for (int e = threadIdx.x; e < C; e += blockDim.x)
-            if (__double_as_longlong(c1[(size_t)(r - a1) * C + e]) != __double_as_longlong(c0[(size_t)(r - a0) * C + e])) bad = 1;
         if (bad) sh_bad = 1;
-        __syncthreads();
-        if (sh_bad) break;
     }
     __syncthreads();
 
